@@ -1,0 +1,278 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE itself.
+
+Run once in the build container (where the upstream repository is mounted
+read-only at /root/reference):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py
+
+The reference is imported unmodified; the only shim is an empty ``cyipopt``
+module (the solver binding is not installed and none of the functions
+exercised here touch it).  The outputs are plain data (seeded inputs and the
+reference's results) stored as ``.npz``; no reference source is stored.
+
+Fixtures:
+  g1_single_step.npz   test-suite geometry, N=100/200, D=2, full S
+  g2_adversarial.npz   N=48, D=3..5, non-proportional lambdas, diag and full S, autograd d/du, d/dS
+  g3_rollout_c1.npz    N=100, ds=2, da=2, H=10, gamma in {-1, 1e-5, 1}
+  g4_rollout_c2.npz    N=128, ds=3, da=1, H=20, R_delta + nonzero references
+  g5_cost.npz          literal cost cases of the reference's tests
+  g6_gp.npz            Ky / Ky_inv / K* / predict
+  g7_quirks.npz        dtype quirks of the rollout
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = os.environ.get("GPMPC_REFERENCE", "/root/reference")
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.modules.setdefault("cyipopt", types.ModuleType("cyipopt"))
+
+from src.gpr import GaussianProcessRegression                      # noqa: E402
+from src.dynamics import Dynamics                                  # noqa: E402
+from src.mpc import RiskSensitiveMPC                               # noqa: E402
+from src.tools.uncertainty_prop import (                           # noqa: E402
+    mean_prop, variance_prop, covariance_prop,
+    mean_prop_torch, variance_prop_torch, covariance_prop_torch)
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+T = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)     # noqa: E731
+
+
+def se_K(X, lam, sf=1.0):
+    d = (X[:, None, :] - X[None, :, :])
+    return sf ** 2 * np.exp(-0.5 * np.sum(d * d / lam, axis=2))
+
+
+def g1():
+    out = {}
+    rng = np.random.default_rng(101)
+    u = np.array([2.0, 1.0])
+    S = np.array([[1.0, 0.5], [0.5, 2.0]])
+    lam1, lam2 = np.array([1.0, 1.0]), np.array([2.0, 2.0])
+    sigma = 0.5
+    for tag, N, sf1, sf2 in (("a", 100, 1.0, 1.0), ("b", 200, 1.0, 1.0), ("c", 100, 0.8, 1.5)):
+        X = rng.multivariate_normal(u, S, N)
+        y = np.sum(X * X, axis=1) + rng.normal(0, sigma, N)
+        Ky1 = se_K(X, lam1, sf1) + sigma ** 2 * np.eye(N)
+        Ky2 = se_K(X, lam2, sf2) + sigma ** 2 * np.eye(N)
+        Ki1, Ki2 = torch.linalg.inv(T(Ky1)), torch.linalg.inv(T(Ky2))
+        m1, d1 = mean_prop_torch(Ki1, T(lam1), T(u), T(S), T(X), T(y), sf1)
+        m2, d2 = mean_prop_torch(Ki2, T(lam2), T(u), T(S), T(X), T(y), sf2)
+        v1 = variance_prop_torch(Ki1, T(lam1), T(u), T(S), T(X), m1, d1["beta"], sf1)
+        v2 = variance_prop_torch(Ki2, T(lam2), T(u), T(S), T(X), m2, d2["beta"], sf2)
+        cv = covariance_prop_torch(T(lam1), T(lam2), T(u), T(S), T(X), m1, m2, d1["beta"], d2["beta"], sf1, sf2)
+        out.update({f"{tag}_X": X, f"{tag}_y": y, f"{tag}_Kinv1": Ki1.numpy(), f"{tag}_Kinv2": Ki2.numpy(),
+                    f"{tag}_sf": np.array([sf1, sf2]),
+                    f"{tag}_mu": np.array([m1.item(), m2.item()]),
+                    f"{tag}_beta1": d1["beta"].numpy(), f"{tag}_l1": d1["l"].numpy(),
+                    f"{tag}_var": np.array([v1.item(), v2.item()]), f"{tag}_cov": np.array(cv.item())})
+        if sf1 == 1.0 and N == 100:   # numpy loop formulas only support sigma_f = 1
+            nm, nd = mean_prop(Ky1, np.diag(lam1), u, S, X, y)
+            nv = variance_prop(Ky1, np.diag(lam1), u, S, X, y)
+            nc = covariance_prop(Ky1, Ky2, np.diag(lam1), np.diag(lam2), u, S, X, y)
+            out.update({f"{tag}_np_mu": np.array(nm), f"{tag}_np_var": np.array(nv), f"{tag}_np_cov": np.array(nc),
+                        f"{tag}_np_beta": nd["beta"], f"{tag}_np_l": nd["l"]})
+    out.update({"u": u, "S": S, "lam1": lam1, "lam2": lam2, "sigma": np.array(sigma)})
+    np.savez(os.path.join(OUT, "g1_single_step.npz"), **out)
+
+
+def g2():
+    out = {}
+    rng = np.random.default_rng(202)
+    N = 48
+    cases = []
+    for D in (3, 4, 5):
+        for full in (False, True):
+            cases.append((D, full))
+    out["cases"] = np.array([[D, int(f)] for D, f in cases])
+    for k, (D, full) in enumerate(cases):
+        X = rng.uniform(-2, 2, (N, D))
+        y1 = np.sin(X).sum(axis=1) + 0.05 * rng.normal(size=N)
+        y2 = np.cos(X[:, 0]) * X[:, 1] + 0.05 * rng.normal(size=N)
+        lam1, lam2 = rng.uniform(0.5, 3.0, D), rng.uniform(0.5, 3.0, D)
+        sf1, sf2, sn = 1.3, 0.7, 0.05
+        u = rng.uniform(-1, 1, D)
+        if full:
+            Aq = rng.normal(size=(D, D))
+            S = 0.05 * (Aq @ Aq.T) + 0.01 * np.eye(D)
+        else:
+            S = np.diag(rng.uniform(0.001, 0.2, D))
+        Ki1 = torch.linalg.inv(T(se_K(X, lam1, sf1) + sn ** 2 * np.eye(N)))
+        Ki2 = torch.linalg.inv(T(se_K(X, lam2, sf2) + sn ** 2 * np.eye(N)))
+        ut = T(u).requires_grad_(True)
+        St = T(S).requires_grad_(True)
+        m1, d1 = mean_prop_torch(Ki1, T(lam1), ut, St, T(X), T(y1), sf1)
+        v1 = variance_prop_torch(Ki1, T(lam1), ut, St, T(X), m1, d1["beta"], sf1)
+        dm_du, dm_dS = torch.autograd.grad(m1, (ut, St), retain_graph=True)
+        dv_du, dv_dS = torch.autograd.grad(v1, (ut, St), retain_graph=True)
+        m2, d2 = mean_prop_torch(Ki2, T(lam2), ut, St, T(X), T(y2), sf2)
+        v2 = variance_prop_torch(Ki2, T(lam2), ut, St, T(X), m2, d2["beta"], sf2)
+        cv = covariance_prop_torch(T(lam1), T(lam2), ut, St, T(X), m1, m2, d1["beta"], d2["beta"], sf1, sf2)
+        # numpy loop covariance (sigma_f = 1 and one shared y): the mathematically consistent form
+        Ky1u = se_K(X, lam1) + sn ** 2 * np.eye(N)
+        Ky2u = se_K(X, lam2) + sn ** 2 * np.eye(N)
+        nc = covariance_prop(Ky1u, Ky2u, np.diag(lam1), np.diag(lam2), u, S, X, y1)
+        Ki1u, Ki2u = torch.linalg.inv(T(Ky1u)), torch.linalg.inv(T(Ky2u))
+        mu1u, du1 = mean_prop_torch(Ki1u, T(lam1), T(u), T(S), T(X), T(y1))
+        mu2u, du2 = mean_prop_torch(Ki2u, T(lam2), T(u), T(S), T(X), T(y1))
+        cvu = covariance_prop_torch(T(lam1), T(lam2), T(u), T(S), T(X), mu1u, mu2u, du1["beta"], du2["beta"])
+        p = f"c{k}_"
+        out.update({p + "X": X, p + "y1": y1, p + "y2": y2, p + "lam1": lam1, p + "lam2": lam2,
+                    p + "hyp": np.array([sf1, sf2, sn]), p + "u": u, p + "S": S,
+                    p + "Kinv1": Ki1.numpy(), p + "Kinv2": Ki2.numpy(),
+                    p + "mu": np.array([m1.item(), m2.item()]), p + "var": np.array([v1.item(), v2.item()]),
+                    p + "cov_torch": np.array(cv.item()),
+                    p + "dm_du": dm_du.numpy(), p + "dm_dS": dm_dS.numpy(),
+                    p + "dv_du": dv_du.numpy(), p + "dv_dS": dv_dS.numpy(),
+                    p + "unit_Kinv1": Ki1u.numpy(), p + "unit_Kinv2": Ki2u.numpy(),
+                    p + "unit_cov_numpy": np.array(nc), p + "unit_cov_torch": np.array(cvu.item())})
+    np.savez(os.path.join(OUT, "g2_adversarial.npz"), **out)
+
+
+def _build_mpc(rng, N, ds, da, H, gamma, lam, sn, Q, R, R_delta=None):
+    D = ds + da
+    S = rng.uniform(-2, 2, (N, ds))
+    A = rng.uniform(-1, 1, (N, da))
+    Y = S + 0.1 * np.tanh(S) + 0.1 * A.sum(axis=1, keepdims=True)
+    mpc = RiskSensitiveMPC(gamma, H, ds, da, Q, R, R_delta)
+    for a in range(ds):
+        g = mpc.dynamics.gpr_err[a]
+        g.set_lambdas(lam[a])
+        g.set_sigma_n(sn)
+        g.set_sigma_f(1.0)
+    mpc.dynamics.append_train_data(S, A, Y)
+    return mpc, np.concatenate((S, A), axis=1), Y
+
+
+def _rollout_fixture(name, seed, N, ds, da, H, gammas, lam_rng, sn, Q, R, R_delta=None,
+                     x_ref=None, u_ref=None, last_u=None, n_traj=2):
+    rng = np.random.default_rng(seed)
+    D = ds + da
+    lam = rng.uniform(lam_rng[0], lam_rng[1], (ds, D))
+    out = {"lambdas": lam, "sigma_f": np.ones(ds), "sigma_n": np.full(ds, sn), "Q": Q, "R": R,
+           "gammas": np.array(gammas), "dims": np.array([N, ds, da, H])}
+    mpc, X, Y = _build_mpc(rng, N, ds, da, H, gammas[0], lam, sn, Q, R, R_delta)
+    out.update({"X": X, "Y": Y,
+                "Ky_inv": np.stack([g.Ky_inv.detach().numpy() for g in mpc.dynamics.gpr_err])})
+    if x_ref is not None:
+        mpc.set_xref(x_ref); out["x_ref"] = x_ref
+    if u_ref is not None:
+        mpc.set_uref(u_ref); out["u_ref"] = u_ref
+    if R_delta is not None:
+        out["R_delta"] = R_delta
+        mpc.last_traj = np.asarray(last_u, dtype=np.float64)
+        out["last_traj"] = mpc.last_traj
+    x0 = rng.uniform(-1, 1, (n_traj, ds))
+    U = rng.uniform(-1, 1, (n_traj, H, da))
+    out.update({"x0": x0, "U": U})
+    means = np.zeros((n_traj, H + 1, ds)); vars_ = np.zeros((n_traj, H + 1, ds))
+    costs = np.zeros((len(gammas), n_traj)); grads = np.zeros((len(gammas), n_traj, H, da))
+    for b in range(n_traj):
+        mpc.curr_state = torch.tensor(x0[b]).type(torch.float64)
+        for gi, gm in enumerate(gammas):
+            mpc.gamma = gm
+            mpc.curr_cost = None
+            c = mpc.objective(U[b].reshape(-1).copy())
+            g = mpc.gradient(U[b].reshape(-1).copy())
+            costs[gi, b] = c
+            grads[gi, b] = np.asarray(g).reshape(H, da)
+        sm, sc = mpc.dynamics.forward_propagate_torch(H, mpc.curr_state, torch.tensor(U[b]).type(torch.float64))
+        means[b] = torch.stack(sm).detach().numpy()
+        vars_[b] = torch.stack([torch.diag(s) for s in sc]).detach().numpy()
+        offd = max(float((s - torch.diag(torch.diag(s))).abs().max()) for s in sc)
+        assert offd == 0.0
+    out.update({"means": means, "vars": vars_, "costs": costs, "grads": grads})
+    np.savez(os.path.join(OUT, name), **out)
+
+
+def g3():
+    _rollout_fixture("g3_rollout_c1.npz", 303, N=100, ds=2, da=2, H=10, gammas=[-1.0, 1e-5, 1.0],
+                     lam_rng=(2.0, 6.0), sn=1e-2, Q=0.1 * np.eye(2), R=0.01 * np.eye(2))
+
+
+def g4():
+    _rollout_fixture("g4_rollout_c2.npz", 404, N=128, ds=3, da=1, H=20, gammas=[-1.0, 1e-5],
+                     lam_rng=(2.0, 6.0), sn=1e-2, Q=np.diag([0.1, 0.2, 0.05]), R=np.array([[0.01]]),
+                     R_delta=np.array([[0.03]]), x_ref=np.array([0.3, -0.2, 0.1]), u_ref=np.array([0.1]),
+                     last_u=0.25 * np.ones(20))
+
+
+def g5():
+    out = {}
+    # test_mpc.py:15-57 (cost / cost_torch, full non-symmetric Sigma)
+    Q = np.array([[2.0, 0], [0, 2.0]]); R = np.array([[1.0, 1], [1, 1.0]])
+    x = np.array([[1.0, 1], [3, 3]]); u = np.array([[2.0, 2]])
+    sig = np.array([[[1.0, 2], [3, 4]], [[5.0, 6], [7, 8]]])
+    xr, ur = np.array([0.5, 0.5]), np.array([0.6, 0.6])
+    mpc = RiskSensitiveMPC(1, 1, 2, 2, Q, R)
+    out.update({"a_Q": Q, "a_R": R, "a_x": x, "a_u": u, "a_sig": sig, "a_xref": xr, "a_uref": ur,
+                "a_gamma": np.array(1.0),
+                "a_cost_np": np.array(mpc.cost(x, u, sig, xr, ur)),
+                "a_cost_torch": np.array(mpc.cost_torch(T(x), T(u), T(sig), T(xr), T(ur)).item())})
+    # test_mpc.py:169-243 (R_delta)
+    Rd = np.array([[0.5, 0], [0, 1.5]])
+    x = np.array([[1.0, 1], [2, 2], [3, 3]]); u = np.array([[2.0, 2], [4, 4]])
+    sig = np.array([[[1.0, 2], [3, 4]], [[5.0, 6], [7, 8]], [[9.0, 10], [11, 12]]])
+    mpc = RiskSensitiveMPC(1.1, 2, 2, 2, Q, R, Rd)
+    mpc.last_traj = [0 for _ in range(4)]
+    c = mpc.cost_torch([T(x[i]) for i in range(3)], T(u), [T(sig[i]) for i in range(3)], T(xr), T(ur))
+    out.update({"b_Rd": Rd, "b_x": x, "b_u": u, "b_sig": sig, "b_gamma": np.array(1.1),
+                "b_last": np.zeros(4), "b_cost_torch": np.array(c.item())})
+    # test_mpc.py:245-274 (gamma = -1 scalar closed form)
+    H = 5
+    xs = np.array([5.0, 4, 3, 2, 1, 0]); sg = np.array([1 / 6, 1 / 7, 1 / 8, 1 / 9, 1 / 10, 1 / 11])
+    closed = sum(-np.log(1 - 2 * sg[i]) + xs[i] ** 2 / (0.5 - sg[i]) for i in range(H + 1))
+    mpc = RiskSensitiveMPC(-1, H, 1, 1, 2 * np.eye(1), np.array([[0.0]]), np.array([[0.0]]))
+    c = mpc.cost_torch(T(xs).reshape(H + 1, 1), torch.zeros((H, 1), dtype=torch.float64),
+                       T(sg).reshape(H + 1, 1, 1), torch.zeros(1, dtype=torch.float64),
+                       torch.zeros(1, dtype=torch.float64))
+    out.update({"c_x": xs, "c_sig": sg, "c_closed": np.array(closed), "c_cost_torch": np.array(c.item())})
+    np.savez(os.path.join(OUT, "g5_cost.npz"), **out)
+
+
+def g6():
+    rng = np.random.default_rng(606)
+    N, D, p = 64, 3, 7
+    X = rng.uniform(-2, 2, (N, D)); y = np.sin(X).sum(axis=1) + 0.1 * rng.normal(size=N)
+    lam = np.array([0.7, 1.9, 3.1]); sf, sn = 1.4, 0.2
+    g = GaussianProcessRegression(D)
+    g.set_lambdas(lam); g.set_sigma_f(sf); g.set_sigma_n(sn)
+    g.append_train_data(X, y)
+    Xp = rng.uniform(-2, 2, (p, D))
+    Ks = g.compute_pred_train_covariance(Xp).detach().numpy()
+    Ks1 = g.compute_pred_train_covariance(Xp[0]).detach().numpy()
+    f0, _ = g.predict_latent_vars(Xp)
+    f1, cf = g.predict_latent_vars(Xp, covar=True)
+    f2, cy = g.predict_latent_vars(Xp, covar=True, targets=True)
+    # append in two chunks + one single point gives the same state as the reference's cat path
+    g2_ = GaussianProcessRegression(D)
+    g2_.set_lambdas(lam); g2_.set_sigma_f(sf); g2_.set_sigma_n(sn)
+    g2_.append_train_data(X[:40], y[:40]); g2_.append_train_data(X[40:63], y[40:63])
+    g2_.append_train_data(X[63], float(y[63]))
+    assert np.allclose(g2_.Ky.detach().numpy(), g.Ky.detach().numpy())
+    np.savez(os.path.join(OUT, "g6_gp.npz"), X=X, y=y, lam=lam, hyp=np.array([sf, sn]), Xp=Xp,
+             Kf=g.Kf.detach().numpy(), Ky=g.Ky.detach().numpy(), Ky_inv=g.Ky_inv.detach().numpy(),
+             Ks=Ks, Ks_single=Ks1, f=f0, f_cov=f1, cov_f=cf, cov_y=cy)
+
+
+def g7():
+    d = Dynamics(2, 1)
+    rng = np.random.default_rng(707)
+    S = rng.uniform(-1, 1, (6, 2)); A = rng.uniform(-1, 1, (6, 1))
+    d.append_train_data(S, A, S + 0.1 * A)
+    sm, sc = d.forward_propagate_torch(1, torch.zeros(2, dtype=torch.float64), torch.zeros((1, 1), dtype=torch.float64))
+    act = (1e-3 * torch.eye(1)).type(torch.float64)[0, 0].item()    # dynamics.py:162 promoted to fp64
+    np.savez(os.path.join(OUT, "g7_quirks.npz"), init_var=np.array(sc[0][0, 0].item()),
+             action_var=np.array(act), float32_1e3=np.array(float(np.float32(1e-3))))
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    for fn in (g1, g2, g3, g4, g5, g6, g7):
+        fn()
+        print("wrote", fn.__name__)

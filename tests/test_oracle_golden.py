@@ -1,0 +1,157 @@
+"""Pin the CPU oracle to the golden vectors produced by the reference itself
+(tests/golden/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gpmpc_oracle as O
+
+T = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)  # noqa: E731
+TIGHT = dict(rtol=1e-11, atol=1e-12)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+@pytest.mark.parametrize("mode", ["faithful", "o2"])
+def test_g1_single_step(golden, tag, mode):
+    z = golden("g1_single_step.npz")
+    u, S = T(z["u"]), T(z["S"])
+    X, y = T(z[f"{tag}_X"]), T(z[f"{tag}_y"])
+    sf1, sf2 = z[f"{tag}_sf"]
+    m1, b1, l1 = O.mean_prop(T(z[f"{tag}_Kinv1"]), T(z["lam1"]), u, S, X, y, sf1)
+    m2, b2, _ = O.mean_prop(T(z[f"{tag}_Kinv2"]), T(z["lam2"]), u, S, X, y, sf2)
+    v1 = O.variance_prop(T(z[f"{tag}_Kinv1"]), T(z["lam1"]), u, S, X, m1, b1, sf1, mode)
+    v2 = O.variance_prop(T(z[f"{tag}_Kinv2"]), T(z["lam2"]), u, S, X, m2, b2, sf2, mode)
+    cv = O.covariance_prop(T(z["lam1"]), T(z["lam2"]), u, S, X, m1, m2, b1, b2, sf1, sf2)
+    np.testing.assert_allclose([m1.item(), m2.item()], z[f"{tag}_mu"], **TIGHT)
+    np.testing.assert_allclose(b1.numpy(), z[f"{tag}_beta1"], **TIGHT)
+    np.testing.assert_allclose(l1.numpy(), z[f"{tag}_l1"], **TIGHT)
+    vtol = TIGHT if mode == "faithful" else dict(rtol=1e-8)
+    np.testing.assert_allclose([v1.item(), v2.item()], z[f"{tag}_var"], **vtol)
+    np.testing.assert_allclose(cv.item(), z[f"{tag}_cov"], rtol=1e-10)
+
+
+def test_g1_numpy_loop_rung(golden):
+    """Rung 2 of the reference's ladder: loop formulas vs vectorised ones,
+    with the reference's own absolute tolerances (test_uncertainty_prop.py:182-385)."""
+    z = golden("g1_single_step.npz")
+    X, y, u, S = z["a_X"], z["a_y"], z["u"], z["S"]
+    Ky1 = np.linalg.inv(z["a_Kinv1"])
+    Ky2 = np.linalg.inv(z["a_Kinv2"])
+    mu, beta, l = O.mean_prop_loops(Ky1, z["lam1"], u, S, X, y)
+    assert abs(mu - z["a_np_mu"]) < 1e-7 * max(1, abs(mu))
+    assert abs(mu - z["a_mu"][0]) < 1e-7 * max(1, abs(mu))
+    assert np.linalg.norm(l - z["a_l1"]) < 1e-5
+    var = O.variance_prop_loops(Ky1, z["lam1"], u, S, X, y)
+    assert abs(var - z["a_np_var"]) < 1e-5 * abs(var)
+    assert abs(var - z["a_var"][0]) < 1e-5 * abs(var)
+
+
+@pytest.mark.parametrize("k", range(6))
+def test_g2_adversarial(golden, k):
+    z = golden("g2_adversarial.npz")
+    p = f"c{k}_"
+    sf1, sf2, _ = z[p + "hyp"]
+    X = T(z[p + "X"])
+    u = T(z[p + "u"]).requires_grad_(True)
+    S = T(z[p + "S"]).requires_grad_(True)
+    m1, b1, _ = O.mean_prop(T(z[p + "Kinv1"]), T(z[p + "lam1"]), u, S, X, T(z[p + "y1"]), sf1)
+    v1 = O.variance_prop(T(z[p + "Kinv1"]), T(z[p + "lam1"]), u, S, X, m1, b1, sf1)
+    m2, b2, _ = O.mean_prop(T(z[p + "Kinv2"]), T(z[p + "lam2"]), u, S, X, T(z[p + "y2"]), sf2)
+    v2 = O.variance_prop(T(z[p + "Kinv2"]), T(z[p + "lam2"]), u, S, X, m2, b2, sf2)
+    np.testing.assert_allclose([m1.item(), m2.item()], z[p + "mu"], **TIGHT)
+    np.testing.assert_allclose([v1.item(), v2.item()], z[p + "var"], **TIGHT)
+    dm_du, dm_dS = torch.autograd.grad(m1, (u, S), retain_graph=True)
+    dv_du, dv_dS = torch.autograd.grad(v1, (u, S), retain_graph=True)
+    np.testing.assert_allclose(dm_du.numpy(), z[p + "dm_du"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(dm_dS.numpy(), z[p + "dm_dS"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(dv_du.numpy(), z[p + "dv_du"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(dv_dS.numpy(), z[p + "dv_dS"], rtol=1e-8, atol=1e-10)
+    cv = O.covariance_prop(T(z[p + "lam1"]), T(z[p + "lam2"]), u, S, X, m1, m2, b1, b2, sf1, sf2)
+    np.testing.assert_allclose(cv.item(), z[p + "cov_torch"], rtol=1e-10)
+    # unit sigma_f / shared y: bug-compatible == reference torch, corrected == reference numpy loop
+    ud, Sd = T(z[p + "u"]), T(z[p + "S"])
+    y = T(z[p + "y1"])
+    mu1, bu1, _ = O.mean_prop(T(z[p + "unit_Kinv1"]), T(z[p + "lam1"]), ud, Sd, X, y)
+    mu2, bu2, _ = O.mean_prop(T(z[p + "unit_Kinv2"]), T(z[p + "lam2"]), ud, Sd, X, y)
+    bug = O.covariance_prop(T(z[p + "lam1"]), T(z[p + "lam2"]), ud, Sd, X, mu1, mu2, bu1, bu2)
+    fix = O.covariance_prop(T(z[p + "lam1"]), T(z[p + "lam2"]), ud, Sd, X, mu1, mu2, bu1, bu2, bug_compatible=False)
+    np.testing.assert_allclose(bug.item(), z[p + "unit_cov_torch"], rtol=1e-10)
+    np.testing.assert_allclose(fix.item(), z[p + "unit_cov_numpy"], rtol=1e-8)
+    if z["cases"][k][1] == 0:      # diagonal S: the reference's transposition is harmless
+        np.testing.assert_allclose(bug.item(), fix.item(), rtol=1e-9)
+
+
+def _bundle(z):
+    return O.GPBundle(z["X"], z["Y"], z["lambdas"], z["sigma_f"], z["sigma_n"], Ky_inv=z["Ky_inv"])
+
+
+@pytest.mark.parametrize("name", ["g3_rollout_c1.npz", "g4_rollout_c2.npz"])
+@pytest.mark.parametrize("mode", ["faithful", "o2"])
+def test_rollout_cost_gradient(golden, name, mode):
+    z = golden(name)
+    N, ds, da, H = z["dims"]
+    gp = _bundle(z)
+    x_ref = z["x_ref"] if "x_ref" in z else np.zeros(ds)
+    u_ref = z["u_ref"] if "u_ref" in z else np.zeros(da)
+    Rd = z["R_delta"] if "R_delta" in z else None
+    last = z["last_traj"][:da] if "last_traj" in z else None
+    for b in range(z["x0"].shape[0]):
+        for gi, gamma in enumerate(z["gammas"]):
+            r = O.objective_and_gradient(gp, int(H), z["x0"][b], z["U"][b], x_ref, u_ref, z["Q"], z["R"],
+                                         float(gamma), Rd, last, mode)
+            # The reference's own run-to-run reproducibility (BLAS thread count / reduction
+            # order through the cancelling trace) is ~1e-10 on means after 10-20 steps.
+            np.testing.assert_allclose(r["means"], z["means"][b], rtol=1e-7, atol=1e-9)
+            np.testing.assert_allclose(r["vars"], z["vars"][b], rtol=1e-6, atol=1e-12)
+            np.testing.assert_allclose(r["cost"], z["costs"][gi, b], rtol=1e-7)
+            np.testing.assert_allclose(r["grad"], z["grads"][gi, b], rtol=1e-6, atol=1e-9)
+
+
+def test_kinv_rebuild_matches_reference(golden):
+    """Ky_inv rebuilt by the oracle (explicit inverse, gpr.py:171) equals the stored one."""
+    z = golden("g3_rollout_c1.npz")
+    gp = O.GPBundle(z["X"], z["Y"], z["lambdas"], z["sigma_f"], z["sigma_n"])
+    scale = np.abs(z["Ky_inv"]).max()      # cond(Ky) ~ 1e6-1e7 at sigma_n = 1e-2
+    np.testing.assert_allclose(gp.Ky_inv.numpy(), z["Ky_inv"], rtol=0, atol=1e-6 * scale)
+
+
+def test_g5_cost_known_answers(golden):
+    z = golden("g5_cost.npz")
+    x, u, sig = T(z["a_x"]), T(z["a_u"]), T(z["a_sig"])
+    c = O.cost([x[0], x[1]], u, [sig[0], sig[1]], T(z["a_xref"]), T(z["a_uref"]), z["a_Q"], z["a_R"], 1.0)
+    assert abs(c.item() - z["a_cost_np"]) < 1e-6        # test_mpc.py:57
+    assert abs(c.item() - z["a_cost_torch"]) < 1e-12
+    x, u, sig = T(z["b_x"]), T(z["b_u"]), T(z["b_sig"])
+    c = O.cost(list(x), u, list(sig), T(z["a_xref"]), T(z["a_uref"]), z["a_Q"], z["a_R"], 1.1,
+               R_delta=z["b_Rd"], last_u=z["b_last"][:2])
+    assert abs(c.item() - z["b_cost_torch"]) < 1e-12
+    H = 5
+    c = O.cost(list(T(z["c_x"]).reshape(H + 1, 1)), torch.zeros((H, 1), dtype=torch.float64),
+               list(T(z["c_sig"]).reshape(H + 1, 1, 1)), torch.zeros(1, dtype=torch.float64),
+               torch.zeros(1, dtype=torch.float64), 2 * np.eye(1), np.zeros((1, 1)), -1.0,
+               R_delta=np.zeros((1, 1)), last_u=np.zeros(1))
+    assert abs(c.item() - z["c_closed"]) < 1e-7          # test_mpc.py:274
+
+
+def test_g6_gp(golden):
+    z = golden("g6_gp.npz")
+    sf, sn = z["hyp"]
+    Kf, Ky, Ki = O.kernel_matrices(z["X"], z["lam"], sf, sn)
+    np.testing.assert_allclose(Kf.numpy(), z["Kf"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(Ky.numpy(), z["Ky"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(Ki.numpy(), z["Ky_inv"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(O.cross_kernel(z["Xp"], z["X"], T(z["lam"]), sf).numpy(), z["Ks"], rtol=1e-12)
+    np.testing.assert_allclose(O.cross_kernel(z["Xp"][0], z["X"], T(z["lam"]), sf).numpy(), z["Ks_single"], rtol=1e-12)
+    f, cov = O.predict(z["Xp"], z["X"], z["y"], z["Ky_inv"], z["lam"], sf, sn, covar=True)
+    np.testing.assert_allclose(f, z["f"], rtol=1e-10)
+    np.testing.assert_allclose(cov, z["cov_f"], rtol=1e-8, atol=1e-10)
+    _, covy = O.predict(z["Xp"], z["X"], z["y"], z["Ky_inv"], z["lam"], sf, sn, covar=True, targets=True)
+    np.testing.assert_allclose(covy, z["cov_y"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(covy - cov, sn ** 2 * np.eye(len(f)), atol=1e-12)   # test_gpr.py identity
+
+
+def test_g7_quirks(golden):
+    z = golden("g7_quirks.npz")
+    assert O.INIT_STATE_VAR == z["init_var"].item() == 1e-3
+    assert O.ACTION_NOISE_VAR == z["action_var"].item() == z["float32_1e3"].item()
+    assert O.ACTION_NOISE_VAR != 1e-3
