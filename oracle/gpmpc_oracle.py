@@ -40,6 +40,15 @@ def _t(a):
 # --------------------------------------------------------------------------
 # GP state (src/gpr.py)
 # --------------------------------------------------------------------------
+def effective_hyper(value):
+    """Value a hyper-parameter actually takes after a reference setter
+    (src/gpr.py:51-88): ``torch.log(torch.tensor(v)).type(float64)`` then ``exp``.
+    ``torch.tensor`` of a Python float / list of floats is float32, so the log is
+    taken in float32 (relative error ~1e-8); a float64 numpy array stays float64."""
+    t = torch.tensor(value)
+    return torch.exp(torch.log(t).type(F64)).numpy()
+
+
 def scaled_sqdist(Xa, Xb, lambdas):
     """Squared distance in the 1/sqrt(lambda)-scaled space, via cdist as in
     src/gpr.py:167-168 / :272-275."""
@@ -52,7 +61,11 @@ def kernel_matrices(X, lambdas, sigma_f, sigma_n):
     (src/gpr.py:159-171): explicit inverse, no Cholesky."""
     X, lambdas = _t(X), _t(lambdas)
     Kf = (sigma_f ** 2) * torch.exp(-0.5 * scaled_sqdist(X, X, lambdas))
-    Ky = Kf + (sigma_n ** 2) * torch.eye(X.shape[0], dtype=F64)
+    # :170 multiplies a 0-dim float64 tensor with a float32 `torch.eye`: the product is
+    # float32, so the noise variance on the diagonal is float32(sigma_n^2).
+    noise = torch.as_tensor(sigma_n, dtype=F64) ** 2 * torch.eye(X.shape[0])
+    assert noise.dtype == torch.float32
+    Ky = Kf + noise
     return Kf, Ky, torch.linalg.inv(Ky)
 
 

@@ -135,7 +135,9 @@ def test_g5_cost_known_answers(golden):
 
 def test_g6_gp(golden):
     z = golden("g6_gp.npz")
-    sf, sn = z["hyp"]
+    # the fixture was built with set_sigma_f(1.4) / set_sigma_n(0.2): Python floats -> float32 log
+    sf, sn = (float(O.effective_hyper(float(v))) for v in z["hyp"])
+    assert sf != 1.4 and abs(sf - 1.4) < 1e-7
     Kf, Ky, Ki = O.kernel_matrices(z["X"], z["lam"], sf, sn)
     np.testing.assert_allclose(Kf.numpy(), z["Kf"], rtol=1e-12, atol=1e-14)
     np.testing.assert_allclose(Ky.numpy(), z["Ky"], rtol=1e-12, atol=1e-14)
