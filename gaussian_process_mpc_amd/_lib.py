@@ -1,0 +1,118 @@
+"""ctypes binding of libgpmpc_hip.so (C ABI: include/gpmpc.h).
+
+torch is imported first on purpose: its bundled HIP runtime (SONAME libamdhip64.so.7)
+must be the one already mapped when the library is dlopen'ed, so that device pointers
+and streams handed over from torch tensors belong to the same runtime instance.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (loads the HIP runtime the library binds to)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgpmpc_hip.so")
+
+MAX_D = 8
+MAX_DS = 8
+WANT_GRAD = 1
+COV_BUG_COMPAT = 2
+
+_ERR = {-1: "bad argument", -2: "device allocation failed", -3: "HIP call / kernel launch failed",
+        -4: "workspace too small", -5: "pack not built"}
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+class GpmpcError(RuntimeError):
+    pass
+
+
+class CostParamsC(ctypes.Structure):
+    _fields_ = [("gamma", ctypes.c_double),
+                ("Q", ctypes.c_double * (MAX_DS * MAX_DS)),
+                ("R", ctypes.c_double * (MAX_D * MAX_D)),
+                ("R_delta", ctypes.c_double * (MAX_D * MAX_D)),
+                ("x_ref", ctypes.c_double * MAX_DS),
+                ("u_ref", ctypes.c_double * MAX_D),
+                ("last_u", ctypes.c_double * MAX_D),
+                ("has_R_delta", ctypes.c_int),
+                ("reserved", ctypes.c_int)]
+
+
+_vp, _i, _d, _sz, _u = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_size_t, ctypes.c_uint
+_dp = ctypes.POINTER(ctypes.c_double)
+
+# name -> (restype, argtypes); every symbol include/gpmpc.h declares
+SIGNATURES = {
+    "gpmpc_device_count": (_i, []),
+    "gpmpc_version": (ctypes.c_char_p, []),
+    "gpmpc_last_error": (ctypes.c_char_p, []),
+    "gpmpc_pack_create": (_i, [ctypes.POINTER(_vp), _i, _i, _i]),
+    "gpmpc_pack_destroy": (_i, [_vp]),
+    "gpmpc_build_ky": (_i, [_i, _i, _vp, _dp, _d, _d, _vp, _vp, _vp]),
+    "gpmpc_pack_build": (_i, [_vp, _vp, _vp, _vp, _dp, _dp, _vp]),
+    "gpmpc_pack_dims": (_i, [_vp] + [ctypes.POINTER(_i)] * 4),
+    "gpmpc_pack_export": (_i, [_vp, _vp, _vp, _vp]),
+    "gpmpc_moment_match_workspace_bytes": (_sz, [_vp, _i]),
+    "gpmpc_moment_match": (_i, [_vp, _i, _vp, _vp, _u] + [_vp] * 7 + [_vp, _sz, _vp]),
+    "gpmpc_cost": (_i, [_i, _i, _i, _i, ctypes.POINTER(CostParamsC), _vp, _vp, _vp, _vp, _vp]),
+    "gpmpc_rollout_workspace_bytes": (_sz, [_vp, _i, _i, _u]),
+    "gpmpc_rollout": (_i, [_vp, _i, _i, _vp, _vp, ctypes.POINTER(CostParamsC), _u, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "gpmpc_timing_enable": (_i, [_i]),
+    "gpmpc_pair_kernel_time": (_i, [_dp, ctypes.POINTER(ctypes.c_longlong), _i]),
+    "gpmpc_matvec": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
+    "gpmpc_predict_workspace_bytes": (_sz, [_i, _i, _i]),
+    "gpmpc_predict": (_i, [_i, _i, _vp, _dp, _d, _vp, _vp, _d, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises LibraryMissing (never falls back) if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LibraryMissing(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C gaussian_process_mpc_amd/csrc`. There is no CPU fallback.")
+        h = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)          # AttributeError if a declared symbol is missing
+            fn.restype, fn.argtypes = res, args
+        _lib = h
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        detail = lib().gpmpc_last_error().decode() if rc == -3 else ""
+        raise GpmpcError(f"{what} failed: {_ERR.get(rc, rc)} {detail}".strip())
+
+
+def require_gpu():
+    """Device for all numerical work.  Raises if no GPU is visible (no CPU fallback)."""
+    lib()
+    if not torch.cuda.is_available():
+        raise GpmpcError("no HIP device visible: the GP-MPC rollout runs on the MI355X only (no CPU fallback)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a contiguous float64 CUDA tensor (or NULL for None)."""
+    if t is None:
+        return ctypes.c_void_p(0)
+    assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous(), (t.device, t.dtype, t.is_contiguous())
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def host_doubles(a):
+    import numpy as np
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+    return a, a.ctypes.data_as(_dp)

@@ -1,0 +1,107 @@
+// Dispatch of the templated pair kernel and the GP prediction entry point
+// (GaussianProcessRegression.compute_pred_train_covariance / predict_latent_vars, src/gpr.py:253-332).
+#include "gpmpc_internal.h"
+
+int gpmpc_launch_pair(int D, bool diag, bool grad, int tb, int waves, const PairArgs& a, hipStream_t s) {
+    if (waves < 1 || waves > 4) return GPMPC_E_ARG;
+    switch (D) {
+        case 1: return gpmpc_launch_pair_D<1>(diag, grad, tb, waves, a, s);
+        case 2: return gpmpc_launch_pair_D<2>(diag, grad, tb, waves, a, s);
+        case 3: return gpmpc_launch_pair_D<3>(diag, grad, tb, waves, a, s);
+        case 4: return gpmpc_launch_pair_D<4>(diag, grad, tb, waves, a, s);
+        case 5: return gpmpc_launch_pair_D<5>(diag, grad, tb, waves, a, s);
+        case 6: return gpmpc_launch_pair_D<6>(diag, grad, tb, waves, a, s);
+        case 7: return gpmpc_launch_pair_D<7>(diag, grad, tb, waves, a, s);
+        case 8: return gpmpc_launch_pair_D<8>(diag, grad, tb, waves, a, s);
+    }
+    return GPMPC_E_ARG;
+}
+
+// K*[r][i] = sf^2 exp(-1/2 sum_k (xp_rk - x_ik)^2 / lambda_k)      (src/gpr.py:266-283)
+__global__ void k_cross_kernel(const double* __restrict__ Xp, int p, const double* __restrict__ X, int N, int D,
+                               const double* __restrict__ lam, double sf2, double* __restrict__ K) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (i >= N) return;
+    double d2 = 0.0;
+    for (int k = 0; k < D; ++k) {
+        const double d = Xp[(size_t)r * D + k] - X[(size_t)i * D + k];
+        d2 = fma(d * d, 1.0 / lam[k], d2);
+    }
+    K[(size_t)r * N + i] = sf2 * exp(-0.5 * d2);
+}
+
+// out[r] = A[r] . v   (rows of a row-major [rows][N] matrix); one workgroup per row.
+// Used for beta = Ky_inv y (src/tools/uncertainty_prop.py:327, src/gpr.py:306) and mean = K* beta.
+__global__ __launch_bounds__(256) void k_rows_dot(const double* __restrict__ A, const double* __restrict__ v, int N,
+                                                   double* __restrict__ out) {
+    __shared__ double s_scr[16], s_out[1];
+    const int r = blockIdx.x;
+    double acc[1] = {0.0};
+    for (int i = threadIdx.x; i < N; i += blockDim.x) acc[0] = fma(A[(size_t)r * N + i], v[i], acc[0]);
+    block_sum<1>(acc, s_scr, s_out);
+    if (threadIdx.x == 0) out[r] = s_out[0];
+}
+
+// W = K* Ky_inv   ([p][N])
+__global__ void k_pred_w(const double* __restrict__ K, const double* __restrict__ Kinv, int N, double* __restrict__ W) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (c >= N) return;
+    double s = 0.0;
+    for (int k = 0; k < N; ++k) s = fma(K[(size_t)r * N + k], Kinv[(size_t)k * N + c], s);
+    W[(size_t)r * N + c] = s;
+}
+
+// cov[r][s] = K**(r,s) - W[r] . K*[s] + noise_var [r == s]     (src/gpr.py:320-330)
+__global__ __launch_bounds__(256) void k_pred_cov(const double* __restrict__ Xp, int p, int D, const double* __restrict__ lam,
+                                                   double sf2, const double* __restrict__ W, const double* __restrict__ K,
+                                                   int N, double noise_var, double* __restrict__ cov) {
+    __shared__ double s_scr[16], s_out[1];
+    const int r = blockIdx.x, s = blockIdx.y;
+    double v[1] = {0.0};
+    for (int i = threadIdx.x; i < N; i += blockDim.x) v[0] = fma(W[(size_t)r * N + i], K[(size_t)s * N + i], v[0]);
+    block_sum<1>(v, s_scr, s_out);
+    if (threadIdx.x == 0) {
+        double d2 = 0.0;
+        for (int k = 0; k < D; ++k) {
+            const double d = Xp[(size_t)r * D + k] - Xp[(size_t)s * D + k];
+            d2 = fma(d * d, 1.0 / lam[k], d2);
+        }
+        cov[(size_t)r * p + s] = sf2 * exp(-0.5 * d2) - s_out[0] + (r == s ? noise_var : 0.0);
+    }
+}
+
+extern "C" int gpmpc_matvec(int rows, int cols, const double* A_dev, const double* v_dev, double* out_dev, void* stream) {
+    if (rows < 1 || cols < 1 || !A_dev || !v_dev || !out_dev) return GPMPC_E_ARG;
+    hipLaunchKernelGGL(k_rows_dot, dim3(rows), dim3(256), 0, (hipStream_t)stream, A_dev, v_dev, cols, out_dev);
+    GPMPC_HIP(hipGetLastError());
+    return GPMPC_OK;
+}
+
+extern "C" size_t gpmpc_predict_workspace_bytes(int n, int D, int np) {
+    if (n < 1 || np < 1 || D < 1) return 0;
+    return 2 * ((sizeof(double) * (size_t)np * n + 255) & ~(size_t)255) + 256;
+}
+
+extern "C" int gpmpc_predict(int n, int D, const double* X, const double* lambdas_host, double sigma_f,
+                             const double* beta, const double* Kinv, double noise_var, int np, const double* Xp,
+                             double* out_K, double* out_mean, double* out_cov, void* workspace, size_t workspace_bytes,
+                             void* stream) {
+    if (n < 1 || D < 1 || D > GPMPC_MAX_D || np < 1 || !X || !lambdas_host || !Xp || !workspace) return GPMPC_E_ARG;
+    if ((out_mean && !beta) || (out_cov && !Kinv)) return GPMPC_E_ARG;
+    if (workspace_bytes < gpmpc_predict_workspace_bytes(n, D, np)) return GPMPC_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t slab = (sizeof(double) * (size_t)np * n + 255) & ~(size_t)255;
+    double* K = out_K ? out_K : (double*)workspace;
+    double* W = (double*)((char*)workspace + slab);
+    double* lam = (double*)((char*)workspace + 2 * slab);
+    GPMPC_HIP(hipMemcpyAsync(lam, lambdas_host, sizeof(double) * D, hipMemcpyHostToDevice, s));
+    const double sf2 = sigma_f * sigma_f;
+    hipLaunchKernelGGL(k_cross_kernel, dim3((n + 255) / 256, np), dim3(256), 0, s, Xp, np, X, n, D, lam, sf2, K);
+    if (out_mean) hipLaunchKernelGGL(k_rows_dot, dim3(np), dim3(256), 0, s, K, beta, n, out_mean);
+    if (out_cov) {
+        hipLaunchKernelGGL(k_pred_w, dim3((n + 255) / 256, np), dim3(256), 0, s, K, Kinv, n, W);
+        hipLaunchKernelGGL(k_pred_cov, dim3(np, np), dim3(256), 0, s, Xp, np, D, lam, sf2, W, K, n, noise_var, out_cov);
+    }
+    GPMPC_HIP(hipGetLastError());
+    return GPMPC_OK;
+}

@@ -1,0 +1,397 @@
+// Single-step exact moment matching for Gaussian inputs with a FULL covariance S, all ds GPs:
+// the general-S form of mean_prop_torch / variance_prop_torch / covariance_prop_torch
+// (src/tools/uncertainty_prop.py:296-338, :341-399, :402-465).
+//
+//   B = (S + Lambda)^-1,  c_m = sf^2 det(Lambda^-1 S + I)^-1/2,  mu = c_m sum_i beta_i exp(-1/2 v_i^T B v_i)
+//   A = (Lambda/2 + S)^-1, c = det(2 Lambda^-1 S + I)^-1/2,  A/8 = Cm^T Cm (Cholesky),  h_i = Cm v_i
+//   T = c Z0, var = sf^2 - T - mu^2
+//   dmu/du = -B c_m S1,            dmu/dS = -1/2 mu B + 1/2 B (c_m S2) B
+//   dT/du  = -4 c Cm^T Z1,         dT/dS  = -1/2 T A + 8 c Cm^T Z2 Cm        (since A Cm^-1 = 8 Cm^T)
+// with S1 = sum p_i v_i, S2 = sum p_i v_i v_i^T and Z* the pair-kernel moments in h-space.
+#include "gpmpc_internal.h"
+
+int gpmpc_timed_pair(int D, bool diag, bool grad, int tb, int waves, const PairArgs& a, hipStream_t s);
+
+struct MomArgs {
+    const double* XT; const double* beta; const double* lam; const double* sf;
+    int N, Np, ds, D;
+    const double* u; const double* S; int nq;
+    double* pp; double* sp; double* part;
+    int pps, sps, ntiles, nm, grad;
+    double* out_mean; double* out_var; double* out_cov;
+    double* dmean_du; double* dmean_dS; double* dvar_du; double* dvar_dS;
+    unsigned flags;
+};
+
+// sp layout: 0 c | 1 mu | 2 sf2 | 3 Am[D*D] | 3+DD Cm[D*D] | 3+2DD dmu_du[D] | 3+2DD+D dmu_dS[D*D]
+__host__ __device__ static inline int msps_of(int D) { return 3 + 3 * D * D + D; }
+
+// In-place inverse and determinant of a small general matrix (Gauss-Jordan, partial pivoting).
+__device__ static double small_inverse(int n, double* a /*[n][n]*/, double* inv /*[n][n]*/) {
+    for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) inv[r * n + c] = (r == c) ? 1.0 : 0.0;
+    double det = 1.0;
+    for (int k = 0; k < n; ++k) {
+        int piv = k; double best = fabs(a[k * n + k]);
+        for (int r = k + 1; r < n; ++r) { const double v = fabs(a[r * n + k]); if (v > best) { best = v; piv = r; } }
+        if (piv != k) {
+            for (int c = 0; c < n; ++c) {
+                double t = a[k * n + c]; a[k * n + c] = a[piv * n + c]; a[piv * n + c] = t;
+                t = inv[k * n + c]; inv[k * n + c] = inv[piv * n + c]; inv[piv * n + c] = t;
+            }
+            det = -det;
+        }
+        const double pv = a[k * n + k];
+        det *= pv;
+        const double ip = 1.0 / pv;
+        for (int c = 0; c < n; ++c) { a[k * n + c] *= ip; inv[k * n + c] *= ip; }
+        for (int r = 0; r < n; ++r) {
+            if (r == k) continue;
+            const double f = a[r * n + k];
+            for (int c = 0; c < n; ++c) { a[r * n + c] = fma(-f, a[k * n + c], a[r * n + c]); inv[r * n + c] = fma(-f, inv[k * n + c], inv[r * n + c]); }
+        }
+    }
+    return det;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_mom_prep(MomArgs A) {
+    constexpr int NS2 = D * (D + 1) / 2, NV = 1 + D + NS2;
+    __shared__ double s_u[D], s_S[D * D], s_B[D * D];
+    __shared__ double s_scr[16 * NV], s_out[NV];
+    __shared__ double s_tmp[2 * D * D];
+    const int q = blockIdx.x, ds = A.ds;
+    if (threadIdx.x < D) s_u[threadIdx.x] = A.u[(size_t)q * D + threadIdx.x];
+    if (threadIdx.x < D * D) s_S[threadIdx.x] = A.S[(size_t)q * D * D + threadIdx.x];
+    __syncthreads();
+    for (int a = 0; a < ds; ++a) {
+        double* sp = A.sp + ((size_t)q * ds + a) * A.sps;
+        double* pp = A.pp + ((size_t)q * ds + a) * A.pps;
+        if (threadIdx.x == 0) {
+            const double* lam = A.lam + a * D;
+            double detlam = 1.0;
+            for (int k = 0; k < D; ++k) detlam *= lam[k];
+            // B = (S + Lambda)^-1, det(Lambda^-1 S + I) = det(S + Lambda) / det(Lambda)
+            for (int r = 0; r < D; ++r) for (int c = 0; c < D; ++c) s_tmp[r * D + c] = 0.5 * (s_S[r * D + c] + s_S[c * D + r]) + (r == c ? lam[r] : 0.0);
+            const double detm = small_inverse(D, s_tmp, s_B) / detlam;
+            // A = (Lambda/2 + S)^-1, det(2 Lambda^-1 S + I) = det(S + Lambda/2) / det(Lambda/2)
+            double dethalf = 1.0;
+            for (int k = 0; k < D; ++k) dethalf *= 0.5 * lam[k];
+            for (int r = 0; r < D; ++r) for (int c = 0; c < D; ++c) s_tmp[r * D + c] = 0.5 * (s_S[r * D + c] + s_S[c * D + r]) + (r == c ? 0.5 * lam[r] : 0.0);
+            double* Am = sp + 3;
+            const double detv = small_inverse(D, s_tmp, s_tmp + D * D) / dethalf;
+            for (int e = 0; e < D * D; ++e) Am[e] = s_tmp[D * D + e];
+            // Cholesky A/8 = L L^T, Cm = L^T (upper)
+            double* Cm = sp + 3 + D * D;
+            double L[D * D];
+            for (int e = 0; e < D * D; ++e) L[e] = 0.0;
+            for (int r = 0; r < D; ++r)
+                for (int c = 0; c <= r; ++c) {
+                    double s = 0.125 * 0.5 * (Am[r * D + c] + Am[c * D + r]);
+                    for (int l = 0; l < c; ++l) s -= L[r * D + l] * L[c * D + l];
+                    L[r * D + c] = (r == c) ? sqrt(s) : s / L[c * D + c];
+                }
+            for (int r = 0; r < D; ++r) for (int c = 0; c < D; ++c) Cm[r * D + c] = (c >= r) ? L[c * D + r] : 0.0;
+            const double sf = A.sf[a];
+            sp[0] = 1.0 / sqrt(detv);
+            sp[2] = sf * sf;
+            s_tmp[0] = sf * sf / sqrt(detm);        // c_m, picked up below
+            for (int k = 0; k < D; ++k) {
+                double s = 0.0;
+                for (int l = k; l < D; ++l) s += Cm[k * D + l] * s_u[l];
+                pp[k] = s;
+            }
+            for (int e = 0; e < D * D; ++e) pp[D + e] = Cm[e];
+        }
+        __syncthreads();
+        double u[D], Bm[D * D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) u[k] = s_u[k];
+#pragma unroll
+        for (int e = 0; e < D * D; ++e) Bm[e] = s_B[e];
+        double v[NV];
+#pragma unroll
+        for (int m = 0; m < NV; ++m) v[m] = 0.0;
+        for (int i = threadIdx.x; i < A.Np; i += blockDim.x) {
+            double d[D], qf = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) d[k] = u[k] - A.XT[(size_t)k * A.Np + i];
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                double bd = 0.0;
+#pragma unroll
+                for (int l = 0; l < D; ++l) bd = fma(Bm[k * D + l], d[l], bd);
+                qf = fma(bd, d[k], qf);
+            }
+            const double p = A.beta[(size_t)a * A.Np + i] * exp(-0.5 * qf);
+            v[0] += p;
+            int o = 1 + D;
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const double pd = p * d[k];
+                v[1 + k] += pd;
+#pragma unroll
+                for (int l = k; l < D; ++l) { v[o] = fma(pd, d[l], v[o]); ++o; }
+            }
+        }
+        const double cm = s_tmp[0];
+        block_sum<NV>(v, s_scr, s_out);
+        if (threadIdx.x == 0) {
+            const double mu = cm * s_out[0];
+            sp[1] = mu;
+            double* dmu_du = sp + 3 + 2 * D * D;
+            double* dmu_dS = dmu_du + D;
+            double S2[D * D];
+            int o = 1 + D;
+            for (int k = 0; k < D; ++k) for (int l = k; l < D; ++l) { S2[k * D + l] = S2[l * D + k] = s_out[o]; ++o; }
+            for (int k = 0; k < D; ++k) {
+                double s = 0.0;
+                for (int l = 0; l < D; ++l) s += s_B[k * D + l] * s_out[1 + l];
+                dmu_du[k] = -cm * s;
+            }
+            // B S2 B
+            double BS[D * D];
+            for (int r = 0; r < D; ++r) for (int c = 0; c < D; ++c) { double s = 0.0; for (int l = 0; l < D; ++l) s += s_B[r * D + l] * S2[l * D + c]; BS[r * D + c] = s; }
+            for (int r = 0; r < D; ++r) for (int c = 0; c < D; ++c) {
+                double s = 0.0;
+                for (int l = 0; l < D; ++l) s += BS[r * D + l] * s_B[l * D + c];
+                dmu_dS[r * D + c] = -0.5 * mu * s_B[r * D + c] + 0.5 * cm * s;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void k_mom_finish(MomArgs A) {
+    __shared__ double s_z[GPMPC_MAX_DS * (1 + D + D * (D + 1) / 2)];
+    const int q = blockIdx.x, ds = A.ds, nm = A.nm;
+    for (int idx = threadIdx.x; idx < ds * nm; idx += blockDim.x) {
+        const int a = idx / nm, m = idx - a * nm;
+        const double* p = A.part + (((size_t)q * ds + a) * A.ntiles) * nm + m;
+        double s = 0.0;
+        for (int tl = 0; tl < A.ntiles; ++tl) s += p[(size_t)tl * nm];
+        s_z[idx] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x >= ds) return;
+    const int a = threadIdx.x;
+    const double* sp = A.sp + ((size_t)q * ds + a) * A.sps;
+    const double* z = s_z + a * nm;
+    const double c = sp[0], mu = sp[1], sf2 = sp[2];
+    const double T = c * z[0];
+    const double var = sf2 - T - mu * mu;
+    A.out_mean[(size_t)q * ds + a] = mu;
+    A.out_var[(size_t)q * ds + a] = var;
+    if (A.out_cov) A.out_cov[((size_t)q * ds + a) * ds + a] = var;
+    if (!A.grad) return;
+    const double* Am = sp + 3;
+    const double* Cm = sp + 3 + D * D;
+    const double* dmu_du = sp + 3 + 2 * D * D;
+    const double* dmu_dS = dmu_du + D;
+    double Z2[D * D];
+    int o = 1 + D;
+    for (int k = 0; k < D; ++k) for (int l = k; l < D; ++l) { Z2[k * D + l] = Z2[l * D + k] = z[o]; ++o; }
+    for (int k = 0; k < D; ++k) {
+        double s = 0.0;                                   // (Cm^T Z1)_k
+        for (int l = 0; l <= k; ++l) s += Cm[l * D + k] * z[1 + l];
+        const double dT_du = -4.0 * c * s;
+        A.dmean_du[((size_t)q * ds + a) * D + k] = dmu_du[k];
+        A.dvar_du[((size_t)q * ds + a) * D + k] = -dT_du - 2.0 * mu * dmu_du[k];
+    }
+    double ZC[D * D];                                     // Z2 Cm
+    for (int r = 0; r < D; ++r) for (int cc = 0; cc < D; ++cc) { double s = 0.0; for (int l = 0; l <= cc; ++l) s += Z2[r * D + l] * Cm[l * D + cc]; ZC[r * D + cc] = s; }
+    for (int r = 0; r < D; ++r) for (int cc = 0; cc < D; ++cc) {
+        double s = 0.0;                                   // (Cm^T Z2 Cm)_rc
+        for (int l = 0; l <= r; ++l) s += Cm[l * D + r] * ZC[l * D + cc];
+        const double dT_dS = -0.5 * T * Am[r * D + cc] + 8.0 * c * s;
+        A.dmean_dS[(((size_t)q * ds + a) * D + r) * D + cc] = dmu_dS[r * D + cc];
+        A.dvar_dS[(((size_t)q * ds + a) * D + r) * D + cc] = -dT_dS - 2.0 * mu * dmu_dS[r * D + cc];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Cross-covariance Cov[f_a, f_b] for a != b  (src/tools/uncertainty_prop.py:402-465):
+//   beta_a^T Qt beta_b - mu_a mu_b,
+//   Qt_ij = sfa^2 sfb^2 det(R)^-1/2 exp( -1/2 qa_i - 1/2 qb_j + 1/2 z_ij^T Am z_ij ),
+//   R = S(La^-1 + Lb^-1) + I, Am = R^-1 S, z_ij = La^-1 (x_i - u) + Lb^-1 (x_j - u).
+// One exponent per pair:  arg_ij = alpha_i + gamma_j + w_i . r_j  with
+//   alpha_i = -1/2 qa_i + 1/2 p_i^T Am p_i, gamma_j = -1/2 qb_j + 1/2 r_j^T Am r_j, w_i = Am' p_i
+// (consistent form: p = La^-1 (x-u) on the i side, r = Lb^-1 (x-u) on the j side, w_i = (Am + Am^T)/2 ... p_i).
+// GPMPC_COV_BUG_COMPAT reproduces the reference's cross term z2_i^T Am z1_j (:446).
+// One workgroup per (query, ordered GP pair a<b): lane = i, j broadcast from LDS in chunks.
+// ---------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void k_cross_cov(MomArgs A, const int* __restrict__ pairs, int npairs) {
+    __shared__ double s_u[D], s_S[D * D], s_Am[D * D];
+    __shared__ double s_det;
+    __shared__ __attribute__((aligned(16))) double s_j[64 * (D + 2)];
+    __shared__ double s_scr[16], s_out[1];
+    const int q = blockIdx.x / npairs, pr = blockIdx.x - q * npairs;
+    const int a = pairs[2 * pr], b = pairs[2 * pr + 1];
+    const bool bug = (A.flags & GPMPC_COV_BUG_COMPAT) != 0;
+    if (threadIdx.x < D) s_u[threadIdx.x] = A.u[(size_t)q * D + threadIdx.x];
+    if (threadIdx.x < D * D) { const int r = threadIdx.x / D, c = threadIdx.x - r * D; s_S[threadIdx.x] = 0.5 * (A.S[(size_t)q * D * D + r * D + c] + A.S[(size_t)q * D * D + c * D + r]); }
+    __syncthreads();
+    const double* la = A.lam + a * D; const double* lb = A.lam + b * D;
+    if (threadIdx.x == 0) {
+        double R[D * D], Ri[D * D];
+        for (int r = 0; r < D; ++r) for (int c = 0; c < D; ++c) R[r * D + c] = s_S[r * D + c] * (1.0 / la[c] + 1.0 / lb[c]) + (r == c ? 1.0 : 0.0);
+        s_det = small_inverse(D, R, Ri);
+        for (int r = 0; r < D; ++r) for (int c = 0; c < D; ++c) { double s = 0.0; for (int l = 0; l < D; ++l) s += Ri[r * D + l] * s_S[l * D + c]; s_Am[r * D + c] = s; }
+    }
+    __syncthreads();
+    double Am[D * D], u[D], ila[D], ilb[D];
+#pragma unroll
+    for (int e = 0; e < D * D; ++e) Am[e] = s_Am[e];
+#pragma unroll
+    for (int k = 0; k < D; ++k) { u[k] = s_u[k]; ila[k] = 1.0 / la[k]; ilb[k] = 1.0 / lb[k]; }
+
+    double total = 0.0;
+    for (int i0 = 0; i0 < A.Np; i0 += blockDim.x) {
+        const int i = i0 + threadIdx.x;
+        // i side
+        double d[D], p1[D], pc[D], w[D], alpha = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) { d[k] = (i < A.Np ? A.XT[(size_t)k * A.Np + i] : 0.0) - u[k]; p1[k] = ila[k] * d[k]; alpha = fma(-0.5 * d[k], p1[k], alpha); }
+        // quadratic term uses z1 = La^-1 d on the i side in both modes; the cross term uses z2_i in bug mode
+#pragma unroll
+        for (int k = 0; k < D; ++k) pc[k] = bug ? ilb[k] * d[k] : p1[k];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            double s = 0.0, sc = 0.0;
+#pragma unroll
+            for (int l = 0; l < D; ++l) { s = fma(Am[k * D + l], p1[l], s); sc = fma(Am[l * D + k], pc[l], sc); }
+            alpha = fma(0.5 * p1[k], s, alpha);
+            w[k] = sc;                                     // (pc^T Am)_k : cross term = 2 * 1/2 * pc_i^T Am r_j
+        }
+        const double bi = i < A.Np ? A.beta[(size_t)a * A.Np + i] : 0.0;
+        double rowsum = 0.0;
+        for (int jc = 0; jc < A.Np; jc += 64) {
+            __syncthreads();
+            if (threadIdx.x < 64) {
+                const int j = jc + threadIdx.x;
+                double dj[D], r2[D], rc[D], gam = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) { dj[k] = A.XT[(size_t)k * A.Np + j] - u[k]; r2[k] = ilb[k] * dj[k]; gam = fma(-0.5 * dj[k], r2[k], gam); rc[k] = bug ? ila[k] * dj[k] : r2[k]; }
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int l = 0; l < D; ++l) s = fma(Am[k * D + l], r2[l], s);
+                    gam = fma(0.5 * r2[k], s, gam);
+                    s_j[threadIdx.x * (D + 2) + k] = rc[k];
+                }
+                s_j[threadIdx.x * (D + 2) + D] = gam;
+                s_j[threadIdx.x * (D + 2) + D + 1] = A.beta[(size_t)b * A.Np + j];
+            }
+            __syncthreads();
+            for (int jj = 0; jj < 64; ++jj) {
+                const double* sj = &s_j[jj * (D + 2)];
+                double arg = alpha + sj[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k) arg = fma(w[k], sj[k], arg);
+                rowsum = fma(sj[D + 1], exp(arg), rowsum);
+            }
+        }
+        if (i < A.Np) total = fma(bi, rowsum, total);
+    }
+    double v[1] = {total};
+    block_sum<1>(v, s_scr, s_out);
+    if (threadIdx.x == 0) {
+        const double sfa = A.sf[a], sfb = A.sf[b];
+        const double mua = A.out_mean[(size_t)q * A.ds + a], mub = A.out_mean[(size_t)q * A.ds + b];
+        const double cov = sfa * sfa * sfb * sfb / sqrt(s_det) * s_out[0] - mua * mub;
+        A.out_cov[((size_t)q * A.ds + a) * A.ds + b] = cov;
+        if (!bug) A.out_cov[((size_t)q * A.ds + b) * A.ds + a] = cov;
+    }
+}
+
+struct MomPlan { int tiling, tb, waves, ntiles, nm, pps, sps; size_t off_pp, off_sp, off_part, off_pairs, total; };
+
+static void plan_mom(const gpmpc_pack* p, int nq, bool grad, MomPlan* r) {
+    const int D = p->D;
+    r->tb = nq >= 4 ? (grad ? 2 : 4) : 1;
+    const long groups = (nq + r->tb - 1) / r->tb;
+    r->tiling = (groups * p->tilings[0].ntiles * p->ds >= 1024) ? 0 : 1;
+    r->waves = p->tilings[r->tiling].waves;
+    r->ntiles = p->tilings[r->tiling].ntiles;
+    r->nm = gpmpc_num_moments(D, false, grad);
+    r->pps = D + D * D;
+    r->sps = msps_of(D);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    r->off_pp = take(sizeof(double) * (size_t)nq * p->ds * r->pps);
+    r->off_sp = take(sizeof(double) * (size_t)nq * p->ds * r->sps);
+    r->off_part = take(sizeof(double) * (size_t)nq * p->ds * r->ntiles * r->nm);
+    r->off_pairs = take(sizeof(int) * 2 * GPMPC_MAX_DS * GPMPC_MAX_DS);
+    r->total = off;
+}
+
+extern "C" size_t gpmpc_moment_match_workspace_bytes(const gpmpc_pack* p, int nq) {
+    if (!p || nq < 1) return 0;
+    MomPlan a, b;
+    plan_mom(p, nq, true, &a);
+    plan_mom(p, nq, false, &b);
+    return a.total > b.total ? a.total : b.total;
+}
+
+template <int D>
+static int run_mom(const gpmpc_pack* p, MomArgs& A, const MomPlan& r, bool grad, hipStream_t s, int* pairs_dev) {
+    hipLaunchKernelGGL(k_mom_prep<D>, dim3(A.nq), dim3(256), 0, s, A);
+    PairArgs P;
+    P.M = p->M; P.XT = p->XT; P.pp = A.pp; P.part = A.part; P.tiles = p->tilings[r.tiling].tiles_dev;
+    P.Np = p->Np; P.ds = p->ds; P.B = A.nq; P.ntiles = r.ntiles; P.pps = r.pps; P.nm = r.nm;
+    int rc = gpmpc_timed_pair(D, false, grad, r.tb, r.waves, P, s);
+    if (rc != GPMPC_OK) return rc;
+    hipLaunchKernelGGL(k_mom_finish<D>, dim3(A.nq), dim3(64), 0, s, A);
+    if (A.out_cov && p->ds > 1) {
+        int h[2 * GPMPC_MAX_DS * GPMPC_MAX_DS], n = 0;
+        const bool bug = (A.flags & GPMPC_COV_BUG_COMPAT) != 0;
+        for (int a = 0; a < p->ds; ++a)
+            for (int b = 0; b < p->ds; ++b) {
+                if (a == b || (!bug && b < a)) continue;   // the bug-compatible form is not symmetric in (a, b)
+                h[2 * n] = a; h[2 * n + 1] = b; ++n;
+            }
+        GPMPC_HIP(hipMemcpyAsync(pairs_dev, h, sizeof(int) * 2 * n, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_cross_cov<D>, dim3(A.nq * n), dim3(256), 0, s, A, pairs_dev, n);
+    }
+    GPMPC_HIP(hipGetLastError());
+    return GPMPC_OK;
+}
+
+extern "C" int gpmpc_moment_match(const gpmpc_pack* p, int nq, const double* u, const double* S, unsigned flags,
+                                  double* out_mean, double* out_var, double* out_cov, double* dmean_du,
+                                  double* dmean_dS, double* dvar_du, double* dvar_dS, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+    if (!p || !u || !S || !out_mean || !out_var || !workspace || nq < 1) return GPMPC_E_ARG;
+    if (!p->built) return GPMPC_E_STATE;
+    const bool grad = (flags & GPMPC_WANT_GRAD) != 0;
+    if (grad && (!dmean_du || !dmean_dS || !dvar_du || !dvar_dS)) return GPMPC_E_ARG;
+    MomPlan r;
+    plan_mom(p, nq, grad, &r);
+    if (workspace_bytes < r.total) return GPMPC_E_WORKSPACE;
+    char* ws = (char*)workspace;
+    MomArgs A;
+    memset(&A, 0, sizeof(A));
+    A.XT = p->XT; A.beta = p->beta; A.lam = p->lam; A.sf = p->sf;
+    A.N = p->N; A.Np = p->Np; A.ds = p->ds; A.D = p->D;
+    A.u = u; A.S = S; A.nq = nq;
+    A.pp = (double*)(ws + r.off_pp); A.sp = (double*)(ws + r.off_sp); A.part = (double*)(ws + r.off_part);
+    A.pps = r.pps; A.sps = r.sps; A.ntiles = r.ntiles; A.nm = r.nm; A.grad = grad ? 1 : 0;
+    A.out_mean = out_mean; A.out_var = out_var; A.out_cov = out_cov;
+    A.dmean_du = dmean_du; A.dmean_dS = dmean_dS; A.dvar_du = dvar_du; A.dvar_dS = dvar_dS;
+    A.flags = flags;
+    hipStream_t s = (hipStream_t)stream;
+    int* pairs_dev = (int*)(ws + r.off_pairs);
+    switch (p->D) {
+        case 1: return run_mom<1>(p, A, r, grad, s, pairs_dev);
+        case 2: return run_mom<2>(p, A, r, grad, s, pairs_dev);
+        case 3: return run_mom<3>(p, A, r, grad, s, pairs_dev);
+        case 4: return run_mom<4>(p, A, r, grad, s, pairs_dev);
+        case 5: return run_mom<5>(p, A, r, grad, s, pairs_dev);
+        case 6: return run_mom<6>(p, A, r, grad, s, pairs_dev);
+        case 7: return run_mom<7>(p, A, r, grad, s, pairs_dev);
+        case 8: return run_mom<8>(p, A, r, grad, s, pairs_dev);
+    }
+    return GPMPC_E_ARG;
+}

@@ -1,0 +1,207 @@
+// GP state ("pack") construction kernels: everything that depends only on the training data and
+// the hyper-parameters, hoisted out of the per-call path of the reference
+// (src/tools/uncertainty_prop.py:324-327 beta, :392-394 Lambda_part, :399 Ky_inv - beta beta^T;
+// src/gpr.py:163-170 Kf / Ky).
+#include "gpmpc_internal.h"
+
+// X [N][D] -> Xp [Np][D] (zero rows appended) and XT [D][Np]
+__global__ void k_pack_points(const double* __restrict__ X, int N, int Np, int D,
+                              double* __restrict__ Xp, double* __restrict__ XT) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Np) return;
+    for (int k = 0; k < D; ++k) {
+        const double v = i < N ? X[(size_t)i * D + k] : 0.0;
+        Xp[(size_t)i * D + k] = v;
+        XT[(size_t)k * Np + i] = v;
+    }
+}
+
+// beta_a = Ky_inv_a @ y_a  (src/tools/uncertainty_prop.py:327); one wave per row.
+__global__ __launch_bounds__(256) void k_pack_beta(const double* __restrict__ Kinv, const double* __restrict__ Y,
+                                                    int N, int Np, int ds, double* __restrict__ beta) {
+    const int a = blockIdx.y;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= Np) return;
+    double s = 0.0;
+    if (row < N) {
+        const double* __restrict__ r = Kinv + ((size_t)a * N + row) * N;
+        for (int j = lane; j < N; j += 64) s = fma(r[j], Y[(size_t)j * ds + a], s);
+        s = wave_sum(s);
+    }
+    if (lane == 0) beta[(size_t)a * Np + row] = s;
+}
+
+// M_a: element (i,j), i <= j, stored at [j*Np + i]:
+//   w_ij * ( (Kinv[i][j] + Kinv[j][i])/2 - beta_i beta_j ) * sigma_f^4 * exp(-1/4 sum_k (x_ik - x_jk)^2 / lambda_k)
+// with w = 1 on the diagonal and 2 above it; everything else (lower triangle, padding) is zero.
+// 32x32 tiles staged through LDS so that both Kinv[i][j] and Kinv[j][i] are read coalesced.
+__global__ __launch_bounds__(256) void k_pack_weights(const double* __restrict__ Kinv, const double* __restrict__ beta,
+                                                       const double* __restrict__ XT, const double* __restrict__ lam,
+                                                       const double* __restrict__ sf, int N, int Np, int D,
+                                                       double* __restrict__ M) {
+    __shared__ double s_t[32][33];
+    const int a = blockIdx.z;
+    const int ti = blockIdx.x * 32, tj = blockIdx.y * 32;   // tile origin: rows i in [ti,ti+32), cols j in [tj,tj+32)
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
+    const double* __restrict__ Ka = Kinv + (size_t)a * N * N;
+    double* __restrict__ Ma = M + (size_t)a * Np * Np;
+    if (tj + 31 < ti) {   // strictly below the diagonal
+        for (int r = ty; r < 32; r += 8) {
+            const int j = tj + r, i = ti + tx;
+            if (j < Np && i < Np) Ma[(size_t)j * Np + i] = 0.0;
+        }
+        return;
+    }
+    // s_t[r][c] = Kinv[ti + r][tj + c]  (row-major read, coalesced over c)
+    for (int r = ty; r < 32; r += 8) {
+        const int i = ti + r, j = tj + tx;
+        s_t[r][tx] = (i < N && j < N) ? Ka[(size_t)i * N + j] : 0.0;
+    }
+    __syncthreads();
+    const double sf2 = sf[a] * sf[a], sf4 = sf2 * sf2;
+    for (int r = ty; r < 32; r += 8) {
+        const int j = tj + r, i = ti + tx;                   // write M[j][i], coalesced over i
+        if (j >= Np || i >= Np) continue;
+        double out = 0.0;
+        if (i <= j && j < N) {
+            const double kji = Ka[(size_t)j * N + i];        // coalesced over i
+            const double kij = s_t[tx][r];
+            double d2 = 0.0;
+            for (int k = 0; k < D; ++k) {
+                const double d = XT[(size_t)k * Np + i] - XT[(size_t)k * Np + j];
+                d2 = fma(d * d, 1.0 / lam[a * D + k], d2);
+            }
+            const double wsym = 0.5 * (kij + kji) - beta[(size_t)a * Np + i] * beta[(size_t)a * Np + j];
+            out = (i == j ? 1.0 : 2.0) * wsym * sf4 * exp(-0.25 * d2);
+        }
+        Ma[(size_t)j * Np + i] = out;
+    }
+}
+
+// Kf = sigma_f^2 exp(-1/2 d2), Ky = Kf + noise_var I   (src/gpr.py:163-170)
+__global__ void k_build_ky(const double* __restrict__ X, int n, int D, const double* __restrict__ lam,
+                           double sf2, double noise_var, double* __restrict__ Kf, double* __restrict__ Ky) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j >= n) return;
+    double d2 = 0.0;
+    for (int k = 0; k < D; ++k) {
+        const double d = X[(size_t)i * D + k] - X[(size_t)j * D + k];
+        d2 = fma(d * d, 1.0 / lam[k], d2);
+    }
+    const double kf = sf2 * exp(-0.5 * d2);
+    if (Kf) Kf[(size_t)i * n + j] = kf;
+    Ky[(size_t)i * n + j] = kf + (i == j ? noise_var : 0.0);
+}
+
+static void build_tiling(int Np, int waves, int jt, gpmpc_tiling* t, int** host_out) {
+    const int it = 64 * waves;
+    int cap = ((Np + it - 1) / it) * ((Np + jt - 1) / jt);
+    int* h = (int*)malloc(sizeof(int) * 3 * (size_t)cap);
+    int n = 0;
+    for (int i0 = 0; i0 < Np; i0 += it)
+        for (int j0 = 0; j0 < Np; j0 += jt) {
+            int j1 = j0 + jt < Np ? j0 + jt : Np;
+            if (j1 <= i0) continue;                          // wholly below the diagonal
+            h[3 * n] = i0; h[3 * n + 1] = j0; h[3 * n + 2] = j1; ++n;
+        }
+    t->waves = waves; t->jt = jt; t->ntiles = n;
+    *host_out = h;
+}
+
+extern "C" int gpmpc_pack_create(gpmpc_pack** out, int n_train, int state_dim, int action_dim) {
+    if (!out || n_train < 1 || state_dim < 1 || action_dim < 0) return GPMPC_E_ARG;
+    const int D = state_dim + action_dim;
+    if (D > GPMPC_MAX_D || state_dim > GPMPC_MAX_DS || D < 1) return GPMPC_E_ARG;
+    gpmpc_pack* p = (gpmpc_pack*)calloc(1, sizeof(gpmpc_pack));
+    if (!p) return GPMPC_E_ALLOC;
+    p->N = n_train; p->Np = ((n_train + 63) / 64) * 64; p->ds = state_dim; p->da = action_dim; p->D = D;
+    const size_t Np = p->Np;
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = hipMalloc(&p->X, sizeof(double) * Np * D);
+    if (e == hipSuccess) e = hipMalloc(&p->XT, sizeof(double) * Np * D);
+    if (e == hipSuccess) e = hipMalloc(&p->beta, sizeof(double) * Np * state_dim);
+    if (e == hipSuccess) e = hipMalloc(&p->M, sizeof(double) * Np * Np * state_dim);
+    if (e == hipSuccess) e = hipMalloc(&p->lam, sizeof(double) * state_dim * D);
+    if (e == hipSuccess) e = hipMalloc(&p->sf, sizeof(double) * state_dim);
+    const int cfg[2][2] = {{4, 256}, {1, 64}};
+    for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+        int* h = nullptr;
+        build_tiling(p->Np, cfg[k][0], cfg[k][1], &p->tilings[k], &h);
+        e = hipMalloc(&p->tilings[k].tiles_dev, sizeof(int) * 3 * (size_t)p->tilings[k].ntiles);
+        if (e == hipSuccess)
+            e = hipMemcpy(p->tilings[k].tiles_dev, h, sizeof(int) * 3 * (size_t)p->tilings[k].ntiles, hipMemcpyHostToDevice);
+        free(h);
+    }
+    if (e != hipSuccess) { gpmpc_set_error("gpmpc_pack_create", e); gpmpc_pack_destroy(p); return GPMPC_E_ALLOC; }
+    *out = p;
+    return GPMPC_OK;
+}
+
+extern "C" int gpmpc_pack_destroy(gpmpc_pack* p) {
+    if (!p) return GPMPC_OK;
+    if (p->X) (void)hipFree(p->X);
+    if (p->XT) (void)hipFree(p->XT);
+    if (p->beta) (void)hipFree(p->beta);
+    if (p->M) (void)hipFree(p->M);
+    if (p->lam) (void)hipFree(p->lam);
+    if (p->sf) (void)hipFree(p->sf);
+    for (int k = 0; k < 2; ++k) if (p->tilings[k].tiles_dev) (void)hipFree(p->tilings[k].tiles_dev);
+    free(p);
+    return GPMPC_OK;
+}
+
+extern "C" int gpmpc_pack_build(gpmpc_pack* p, const double* X_dev, const double* Y_dev, const double* Ky_inv_dev,
+                                const double* lambdas_host, const double* sigma_f_host, void* stream) {
+    if (!p || !X_dev || !Y_dev || !Ky_inv_dev || !lambdas_host || !sigma_f_host) return GPMPC_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    for (int a = 0; a < p->ds; ++a) {
+        p->sf_host[a] = sigma_f_host[a];
+        for (int k = 0; k < p->D; ++k) {
+            p->lam_host[a][k] = lambdas_host[a * p->D + k];
+            if (!(p->lam_host[a][k] > 0.0)) return GPMPC_E_ARG;
+        }
+    }
+    // hyper-parameters are tiny: stage them in pageable host memory owned by the pack (valid until the copy ran)
+    GPMPC_HIP(hipMemcpyAsync(p->lam, lambdas_host, sizeof(double) * p->ds * p->D, hipMemcpyHostToDevice, s));
+    GPMPC_HIP(hipMemcpyAsync(p->sf, sigma_f_host, sizeof(double) * p->ds, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_pack_points, dim3((p->Np + 255) / 256), dim3(256), 0, s, X_dev, p->N, p->Np, p->D, p->X, p->XT);
+    hipLaunchKernelGGL(k_pack_beta, dim3((p->Np + 3) / 4, p->ds), dim3(256), 0, s, Ky_inv_dev, Y_dev, p->N, p->Np, p->ds, p->beta);
+    hipLaunchKernelGGL(k_pack_weights, dim3(p->Np / 32, p->Np / 32, p->ds), dim3(256), 0, s,
+                       Ky_inv_dev, p->beta, p->XT, p->lam, p->sf, p->N, p->Np, p->D, p->M);
+    GPMPC_HIP(hipGetLastError());
+    p->built = 1;
+    return GPMPC_OK;
+}
+
+extern "C" int gpmpc_pack_dims(const gpmpc_pack* p, int* n, int* np, int* ds, int* da) {
+    if (!p) return GPMPC_E_ARG;
+    if (n) *n = p->N;
+    if (np) *np = p->Np;
+    if (ds) *ds = p->ds;
+    if (da) *da = p->da;
+    return GPMPC_OK;
+}
+extern "C" int gpmpc_pack_export(const gpmpc_pack* p, double* beta_out, double* weights_out, void* stream) {
+    if (!p) return GPMPC_E_ARG;
+    if (!p->built) return GPMPC_E_STATE;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t Np = p->Np;
+    if (beta_out) GPMPC_HIP(hipMemcpyAsync(beta_out, p->beta, sizeof(double) * Np * p->ds, hipMemcpyDeviceToDevice, s));
+    if (weights_out) GPMPC_HIP(hipMemcpyAsync(weights_out, p->M, sizeof(double) * Np * Np * p->ds, hipMemcpyDeviceToDevice, s));
+    return GPMPC_OK;
+}
+
+extern "C" int gpmpc_build_ky(int n, int D, const double* X_dev, const double* lambdas_host, double sigma_f,
+                              double noise_var, double* Kf_dev, double* Ky_dev, void* stream) {
+    if (n < 1 || D < 1 || D > GPMPC_MAX_D || !X_dev || !lambdas_host || !Ky_dev) return GPMPC_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    double* lam = nullptr;
+    GPMPC_HIP(hipMallocAsync((void**)&lam, sizeof(double) * D, s));
+    GPMPC_HIP(hipMemcpyAsync(lam, lambdas_host, sizeof(double) * D, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_build_ky, dim3((n + 255) / 256, n), dim3(256), 0, s, X_dev, n, D, lam, sigma_f * sigma_f,
+                       noise_var, Kf_dev, Ky_dev);
+    GPMPC_HIP(hipGetLastError());
+    GPMPC_HIP(hipFreeAsync(lam, s));
+    return GPMPC_OK;
+}

@@ -1,0 +1,206 @@
+// The O(N^2) pair kernel: the dominant kernel of the rollout.
+//
+// For one (trajectory b, GP a) the variance term of exact moment matching is
+//     T = c * sum_{i,j} M_ij * exp(-|h_i + h_j|^2),      h_i = Cm (u - x_i),  Cm^T Cm = (Lambda/2 + S)^-1 / 8
+// which restates  trace((Ky_inv - beta beta^T) @ L)  of the reference
+// (src/tools/uncertainty_prop.py:372-399) as an elementwise sum: M folds every factor that
+// does not depend on (u, S) (built once per data update, pack.hip) and
+// exp(-1/8 (G_ii + 2 G_ij + G_jj)) = exp(-|h_i + h_j|^2)  (:389).
+//
+// With m = h_i + h_j the input-gradients of T need only the moments
+//     Z0 = sum P,  Z1_k = sum P m_k,  Z2_kl = sum P m_k m_l,   P = M_ij exp(-|m|^2)
+// (step.hip turns them into dT/du, dT/dS), so forward value and gradient come out of ONE pass,
+// nothing N x N is ever stored, and only the upper triangle i <= j is visited
+// (M carries weight 2 off the diagonal).
+//
+// Mapping (CDNA4, wave64): lane = row i; a workgroup of W waves owns 64*W rows and walks its
+// j-range in chunks of 64 columns whose transformed points h_j (for TB trajectories) are staged
+// in LDS and read back wave-uniformly (broadcast, conflict-free).  M_ij is read as [j][i], i.e.
+// 512 contiguous bytes per wave and j.  TB trajectories share every M_ij load.  All accumulation
+// is per-lane fp64; the cross-lane reduction happens once per workgroup, in a fixed order, and the
+// per-tile partials are written (not atomically added) so results are bit-reproducible.
+#pragma once
+#include "gpmpc_internal.h"
+
+template <int D, bool DIAG, bool GRAD>
+struct PairTraits {
+    static constexpr int DP = (D + 1) & ~1;   // LDS row stride (doubles), keeps rows 16-byte aligned
+    static constexpr int NM = !GRAD ? 1 : (DIAG ? 1 + 2 * D : 1 + D + D * (D + 1) / 2);
+};
+
+template <int D, bool DIAG>
+__device__ __forceinline__ void pair_transform(const double* __restrict__ prm, const double (&x)[D], double (&h)[D]) {
+    // h = cvec - Cm x
+    if (DIAG) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) h[k] = fma(-prm[D + k], x[k], prm[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            double s = prm[k];
+#pragma unroll
+            for (int l = k; l < D; ++l) s = fma(-prm[D + k * D + l], x[l], s);
+            h[k] = s;
+        }
+    }
+}
+
+template <int D, bool DIAG, bool GRAD, int TB>
+__global__ __launch_bounds__(256) void gpmpc_pair_kernel(PairArgs A) {
+    using TR = PairTraits<D, DIAG, GRAD>;
+    constexpr int DP = TR::DP, NM = TR::NM;
+    __shared__ __attribute__((aligned(16))) double s_hj[TB * 64 * DP];
+    __shared__ double s_red[4 * TB * NM];
+
+    const int bg = blockIdx.x, tile = blockIdx.y, a = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int i0 = A.tiles[tile * 3 + 0], j0 = A.tiles[tile * 3 + 1], j1 = A.tiles[tile * 3 + 2];
+    const int Np = A.Np;
+    const int iw0 = i0 + w * 64;            // first row of this wave
+    const bool active = iw0 < Np;           // wave-uniform (Np is a multiple of 64)
+    const int i = iw0 + lane;
+
+    const double* __restrict__ prm[TB];
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb) {
+        int b = bg * TB + tb;
+        b = b < A.B ? b : A.B - 1;          // pad the last group with a duplicate (its result is not written)
+        prm[tb] = A.pp + ((size_t)b * A.ds + a) * A.pps;
+    }
+
+    double hi[TB][D];
+    if (active) {
+        double x[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) x[k] = A.XT[(size_t)k * Np + i];
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb) pair_transform<D, DIAG>(prm[tb], x, hi[tb]);
+    } else {
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+            for (int k = 0; k < D; ++k) hi[tb][k] = 0.0;
+    }
+
+    double acc[TB][NM];
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+        for (int m = 0; m < NM; ++m) acc[tb][m] = 0.0;
+
+    const double* __restrict__ Ma = A.M + (size_t)a * Np * Np;
+
+    for (int jc = j0; jc < j1; jc += 64) {
+        __syncthreads();
+        // stage h_j for this chunk: 64 columns x TB trajectories
+        for (int idx = tid; idx < 64 * TB; idx += blockDim.x) {
+            const int jj = idx & 63, tb = idx >> 6;
+            double x[D], h[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) x[k] = A.XT[(size_t)k * Np + jc + jj];
+            // tb is not a compile-time constant here: select the parameter block dynamically
+            const double* p = prm[0];
+#pragma unroll
+            for (int t2 = 1; t2 < TB; ++t2) p = (tb == t2) ? prm[t2] : p;
+            pair_transform<D, DIAG>(p, x, h);
+#pragma unroll
+            for (int k = 0; k < D; ++k) s_hj[(tb * 64 + jj) * DP + k] = h[k];
+        }
+        __syncthreads();
+        // rows of this wave all below the chunk's columns -> every M_ij of the chunk is zero
+        if (!active || jc + 63 < iw0) continue;
+
+        const double* __restrict__ Mc = Ma + (size_t)jc * Np + i;
+#pragma unroll 1
+        for (int jb = 0; jb < 64; jb += 8) {
+            double mij[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) mij[q] = Mc[(size_t)(jb + q) * Np];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+#pragma unroll
+                for (int tb = 0; tb < TB; ++tb) {
+                    const double* hj = &s_hj[(tb * 64 + jb + q) * DP];
+                    double m[D], sq[D];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) { m[k] = hi[tb][k] + hj[k]; sq[k] = m[k] * m[k]; }
+                    double s = sq[0];
+#pragma unroll
+                    for (int k = 1; k < D; ++k) s += sq[k];
+                    const double P = mij[q] * exp(-s);
+                    acc[tb][0] += P;
+                    if (GRAD) {
+                        if (DIAG) {
+#pragma unroll
+                            for (int k = 0; k < D; ++k) {
+                                acc[tb][1 + k] = fma(P, m[k], acc[tb][1 + k]);
+                                acc[tb][1 + D + k] = fma(P, sq[k], acc[tb][1 + D + k]);
+                            }
+                        } else {
+                            int o = 1 + D;
+#pragma unroll
+                            for (int k = 0; k < D; ++k) {
+                                const double pm = P * m[k];
+                                acc[tb][1 + k] += pm;
+#pragma unroll
+                                for (int l = k; l < D; ++l) { acc[tb][o] = fma(pm, m[l], acc[tb][o]); ++o; }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // workgroup reduction, fixed order
+    __syncthreads();
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const double s = wave_sum(acc[tb][m]);
+            if (lane == 0) s_red[(w * TB + tb) * NM + m] = s;
+        }
+    __syncthreads();
+    const int nw = blockDim.x >> 6;
+    for (int idx = tid; idx < TB * NM; idx += blockDim.x) {
+        const int tb = idx / NM, m = idx - tb * NM;
+        const int b = bg * TB + tb;
+        if (b < A.B) {
+            double s = 0.0;
+            for (int ww = 0; ww < nw; ++ww) s += s_red[(ww * TB + tb) * NM + m];
+            A.part[(((size_t)b * A.ds + a) * A.ntiles + tile) * A.nm + m] = s;
+        }
+    }
+}
+
+template <int D, bool DIAG, bool GRAD, int TB>
+static int launch_pair_one(int waves, const PairArgs& a, hipStream_t s) {
+    dim3 grid((a.B + TB - 1) / TB, a.ntiles, a.ds), block(64 * waves);
+    hipLaunchKernelGGL((gpmpc_pair_kernel<D, DIAG, GRAD, TB>), grid, block, 0, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { gpmpc_set_error("pair kernel launch", e); return GPMPC_E_LAUNCH; }
+    return GPMPC_OK;
+}
+
+template <int D>
+int gpmpc_launch_pair_D(bool diag, bool grad, int tb, int waves, const PairArgs& a, hipStream_t s) {
+    if (a.nm != gpmpc_num_moments(D, diag, grad)) return GPMPC_E_ARG;
+#define GPMPC_PAIR_CASE(DG, GR)                                                  \
+    if (diag == DG && grad == GR) {                                              \
+        if (tb == 1) return launch_pair_one<D, DG, GR, 1>(waves, a, s);          \
+        if (tb == 2) return launch_pair_one<D, DG, GR, 2>(waves, a, s);          \
+        if (tb == 4) return launch_pair_one<D, DG, GR, 4>(waves, a, s);          \
+        return GPMPC_E_ARG;                                                      \
+    }
+    GPMPC_PAIR_CASE(true, true)
+    GPMPC_PAIR_CASE(true, false)
+    if (!diag && grad) {   // full second moments: 1 + D + D(D+1)/2 accumulators per trajectory, keep TB <= 2
+        if (tb == 1) return launch_pair_one<D, false, true, 1>(waves, a, s);
+        if (tb == 2) return launch_pair_one<D, false, true, 2>(waves, a, s);
+        return GPMPC_E_ARG;
+    }
+    GPMPC_PAIR_CASE(false, false)
+#undef GPMPC_PAIR_CASE
+    return GPMPC_E_ARG;
+}

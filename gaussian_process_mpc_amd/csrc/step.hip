@@ -1,0 +1,475 @@
+// Per-step "head" / "tail" kernels of the rollout: the O(N) mean moments, the O(D) algebra that
+// turns the pair-kernel moments into means, variances and their input Jacobians, the risk-sensitive
+// cost and the reverse (adjoint) sweep over the horizon.
+//
+// Reference path restated here (one trajectory per workgroup, all ds GPs):
+//   Dynamics.forward_propagate_torch   src/dynamics.py:145-189   (u_t, S_t assembly, diag covariance)
+//   mean_prop_torch                    src/tools/uncertainty_prop.py:329-338
+//   variance_prop_torch scalars        src/tools/uncertainty_prop.py:374-377, :399
+//   RiskSensitiveMPC.cost_torch        src/mpc.py:179-198
+//   RiskSensitiveMPC.gradient          src/mpc.py:251 (autograd backward -> analytic adjoint)
+//
+// Closed forms (S diagonal, s_k its entries, lambda_k the GP's squared length-scales):
+//   B_k = 1/(s_k + lambda_k),  c_m = sf^2 prod_k (s_k/lambda_k + 1)^-1/2
+//   mu = c_m sum_i beta_i exp(-1/2 sum_k B_k v_ik^2),  v_i = u - x_i
+//   dmu/du_k = -B_k c_m sum_i p_i v_ik,   dmu/ds_k = -1/2 mu B_k + 1/2 B_k^2 c_m sum_i p_i v_ik^2
+//   A_k = 1/(lambda_k/2 + s_k),  c = prod_k (2 s_k/lambda_k + 1)^-1/2,  h_ik = sqrt(A_k/8) v_ik
+//   T = c Z0,  dT/du_k = -4 sqrt(A_k/8) c Z1_k,  dT/ds_k = A_k (c Z2_kk - T/2)
+//   var = sf^2 - T - mu^2     (no clamp; src/tools/uncertainty_prop.py:399)
+#include "gpmpc_internal.h"
+
+struct RollArgs {
+    // pack
+    const double* XT; const double* beta; const double* lam; const double* sf;
+    int N, Np, ds, da, D;
+    // problem
+    const double* x0; const double* U; int B, H;
+    // state trajectory (outputs or workspace): [B][H+1][ds]
+    double* means; double* vars;
+    // workspace
+    double* pp;    // [B][ds][pps]   pair-kernel parameters of the current step
+    double* sp;    // [B][ds][sps]   per-GP scalars of the current step kept for the finish phase
+    double* part;  // [B][ds][ntiles][nm]
+    double* jac;   // [B][H][2ds][2ds+da] or null
+    int pps, sps, ntiles, nm, grad;
+    // outputs of the tail
+    double* out_cost; double* out_grad;
+    gpmpc_cost_params cost;
+};
+
+// layout of sp (doubles): 0 c | 1 mu | 2 sf2 | 3 A[D] | 3+D scale[D] | 3+2D dmu_du[D] | 3+3D dmu_ds[D]
+__host__ __device__ static inline int sps_of(int D) { return 3 + 4 * D; }
+
+// Finish step t (>= 1) for trajectory b: reduce the pair-kernel partials, write mean/var of step t and its Jacobian.
+__device__ static void finish_step(const RollArgs& A, int b, int t, double* s_z /* [ds*nm] */) {
+    const int ds = A.ds, D = A.D, nm = A.nm;
+    for (int idx = threadIdx.x; idx < ds * nm; idx += blockDim.x) {
+        const int a = idx / nm, m = idx - a * nm;
+        const double* p = A.part + (((size_t)b * ds + a) * A.ntiles) * nm + m;
+        double s = 0.0;
+        for (int tl = 0; tl < A.ntiles; ++tl) s += p[(size_t)tl * nm];
+        s_z[idx] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < ds) {
+        const int a = threadIdx.x;
+        const double* sp = A.sp + ((size_t)b * ds + a) * A.sps;
+        const double* z = s_z + a * nm;
+        const double c = sp[0], mu = sp[1], sf2 = sp[2];
+        const double T = c * z[0];
+        const double var = sf2 - T - mu * mu;
+        A.means[((size_t)b * (A.H + 1) + t) * ds + a] = mu;
+        A.vars[((size_t)b * (A.H + 1) + t) * ds + a] = var;
+        if (A.grad) {
+            const int nc = 2 * ds + A.da;
+            double* jm = A.jac + (((size_t)b * A.H + (t - 1)) * 2 * ds + a) * nc;        // row of mu_a
+            double* jv = A.jac + (((size_t)b * A.H + (t - 1)) * 2 * ds + ds + a) * nc;   // row of var_a
+            for (int k = 0; k < D; ++k) {
+                const double Ak = sp[3 + k], sc = sp[3 + D + k];
+                const double dmu_du = sp[3 + 2 * D + k], dmu_ds = sp[3 + 3 * D + k];
+                const double dT_du = -4.0 * sc * c * z[1 + k];
+                const double dT_ds = Ak * (c * z[1 + D + k] - 0.5 * T);
+                const double dv_du = -dT_du - 2.0 * mu * dmu_du;
+                const double dv_ds = -dT_ds - 2.0 * mu * dmu_ds;
+                if (k < ds) {
+                    jm[k] = dmu_du; jm[ds + k] = dmu_ds;
+                    jv[k] = dv_du;  jv[ds + k] = dv_ds;
+                } else {            // action input: its variance is a constant
+                    jm[2 * ds + (k - ds)] = dmu_du;
+                    jv[2 * ds + (k - ds)] = dv_du;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// Prepare step t (>= 1): input moments from step t-1 and action t-1, the O(N) mean sums, pair parameters.
+template <int D>
+__device__ static void prep_step(const RollArgs& A, int b, int t, double* s_u, double* s_s, double* s_scr, double* s_out) {
+    const int ds = A.ds;
+    if (threadIdx.x < D) {
+        const int k = threadIdx.x;
+        if (k < ds) {
+            s_u[k] = A.means[((size_t)b * (A.H + 1) + (t - 1)) * ds + k];
+            s_s[k] = A.vars[((size_t)b * (A.H + 1) + (t - 1)) * ds + k];
+        } else {
+            s_u[k] = A.U[((size_t)b * A.H + (t - 1)) * A.da + (k - ds)];
+            s_s[k] = GPMPC_ACTION_VAR;
+        }
+    }
+    __syncthreads();
+    for (int a = 0; a < ds; ++a) {
+        double u[D], Bk[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) { u[k] = s_u[k]; Bk[k] = 1.0 / (s_s[k] + A.lam[a * D + k]); }
+        double v[1 + 2 * D];
+#pragma unroll
+        for (int m = 0; m < 1 + 2 * D; ++m) v[m] = 0.0;
+        for (int i = threadIdx.x; i < A.Np; i += blockDim.x) {
+            double d[D], q = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) { d[k] = u[k] - A.XT[(size_t)k * A.Np + i]; q = fma(Bk[k] * d[k], d[k], q); }
+            const double p = A.beta[(size_t)a * A.Np + i] * exp(-0.5 * q);
+            v[0] += p;
+#pragma unroll
+            for (int k = 0; k < D; ++k) { v[1 + k] = fma(p, d[k], v[1 + k]); v[1 + D + k] = fma(p * d[k], d[k], v[1 + D + k]); }
+        }
+        block_sum<1 + 2 * D>(v, s_scr, s_out);
+        if (threadIdx.x == 0) {
+            const double sf = A.sf[a], sf2 = sf * sf;
+            double detm = 1.0, detv = 1.0;
+            for (int k = 0; k < D; ++k) {
+                const double lam = A.lam[a * D + k];
+                detm *= s_s[k] / lam + 1.0;
+                detv *= 2.0 * s_s[k] / lam + 1.0;
+            }
+            const double cm = sf2 / sqrt(detm), c = 1.0 / sqrt(detv);
+            const double mu = cm * s_out[0];
+            double* sp = A.sp + ((size_t)b * ds + a) * A.sps;
+            double* pp = A.pp + ((size_t)b * ds + a) * A.pps;
+            sp[0] = c; sp[1] = mu; sp[2] = sf2;
+            for (int k = 0; k < D; ++k) {
+                const double lam = A.lam[a * D + k];
+                const double Ak = 1.0 / (0.5 * lam + s_s[k]);
+                const double sc = sqrt(0.125 * Ak);
+                sp[3 + k] = Ak; sp[3 + D + k] = sc;
+                sp[3 + 2 * D + k] = -Bk[k] * cm * s_out[1 + k];
+                sp[3 + 3 * D + k] = -0.5 * mu * Bk[k] + 0.5 * Bk[k] * Bk[k] * cm * s_out[1 + D + k];
+                pp[k] = sc * s_u[k];
+                pp[D + k] = sc;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_roll_head(RollArgs A, int t) {
+    __shared__ double s_z[GPMPC_MAX_DS * (1 + 2 * GPMPC_MAX_D)];
+    __shared__ double s_u[GPMPC_MAX_D], s_s[GPMPC_MAX_D];
+    __shared__ double s_scr[16 * (1 + 2 * D)], s_out[1 + 2 * D];
+    const int b = blockIdx.x;
+    if (t == 1) {
+        if (threadIdx.x < A.ds) {
+            A.means[((size_t)b * (A.H + 1)) * A.ds + threadIdx.x] = A.x0[(size_t)b * A.ds + threadIdx.x];
+            A.vars[((size_t)b * (A.H + 1)) * A.ds + threadIdx.x] = GPMPC_INIT_VAR;
+        }
+        __syncthreads();
+    } else {
+        finish_step(A, b, t - 1, s_z);
+    }
+    prep_step<D>(A, b, t, s_u, s_s, s_scr, s_out);
+}
+
+// ---------------------------------------------------------------------------
+// cost (src/mpc.py:179-198) and its derivatives
+// ---------------------------------------------------------------------------
+// Per-step state cost with a general (possibly non-symmetric) covariance Sig [ds][ds]:
+//   (1/gamma) log det(I + gamma Q Sig) + e^T (Q^-1 + gamma Sig)^-1 e,   e = mu - x_ref.
+// (Q^-1 + gamma Sig)^-1 = (I + gamma Q Sig)^-1 Q =: Z, so one LU of Mx = I + gamma Q Sig gives the
+// determinant and Z (no inverse of Q is formed).  Optionally returns d/dmu and d/dSig_kk.
+// w: scratch, ds * 2ds doubles.  gamma == 0: tr(Q Sig) + e^T Q e.
+__device__ static double state_cost(int ds, const gpmpc_cost_params& C, const double* mu, const double* Sig, int sig_ld,
+                                    bool sig_diag, double* w, double* dmu, double* dvar) {
+    const double g = C.gamma;
+    double e[GPMPC_MAX_DS];
+    for (int k = 0; k < ds; ++k) e[k] = mu[k] - C.x_ref[k];
+    if (g == 0.0) {
+        double c = 0.0;
+        for (int k = 0; k < ds; ++k) {
+            double qe = 0.0;
+            for (int l = 0; l < ds; ++l) {
+                qe += C.Q[k * ds + l] * e[l];
+                const double sig_lk = sig_diag ? (l == k ? Sig[k] : 0.0) : Sig[l * sig_ld + k];
+                c += C.Q[k * ds + l] * sig_lk;
+            }
+            c += e[k] * qe;
+            if (dmu) {
+                double qte = 0.0;
+                for (int l = 0; l < ds; ++l) qte += C.Q[l * ds + k] * e[l];
+                dmu[k] = qe + qte;
+                dvar[k] = C.Q[k * ds + k];
+            }
+        }
+        return c;
+    }
+    const int ld = 2 * ds;     // augmented [Mx | Q]
+    for (int r = 0; r < ds; ++r)
+        for (int cc = 0; cc < ds; ++cc) {
+            double s = 0.0;
+            if (sig_diag) s = C.Q[r * ds + cc] * Sig[cc];
+            else for (int l = 0; l < ds; ++l) s += C.Q[r * ds + l] * Sig[l * sig_ld + cc];
+            w[r * ld + cc] = (r == cc ? 1.0 : 0.0) + g * s;
+            w[r * ld + ds + cc] = C.Q[r * ds + cc];
+        }
+    double det = 1.0;
+    for (int k = 0; k < ds; ++k) {           // Gauss-Jordan with partial pivoting
+        int piv = k; double best = fabs(w[k * ld + k]);
+        for (int r = k + 1; r < ds; ++r) { const double v = fabs(w[r * ld + k]); if (v > best) { best = v; piv = r; } }
+        if (piv != k) {
+            for (int cc = 0; cc < ld; ++cc) { const double tmp = w[k * ld + cc]; w[k * ld + cc] = w[piv * ld + cc]; w[piv * ld + cc] = tmp; }
+            det = -det;
+        }
+        const double pv = w[k * ld + k];
+        det *= pv;
+        const double inv = 1.0 / pv;
+        for (int cc = 0; cc < ld; ++cc) w[k * ld + cc] *= inv;
+        for (int r = 0; r < ds; ++r) {
+            if (r == k) continue;
+            const double f = w[r * ld + k];
+            for (int cc = 0; cc < ld; ++cc) w[r * ld + cc] = fma(-f, w[k * ld + cc], w[r * ld + cc]);
+        }
+    }
+    // Z = w[:, ds:]
+    double ze[GPMPC_MAX_DS], zte[GPMPC_MAX_DS], quad = 0.0;
+    for (int k = 0; k < ds; ++k) {
+        double s = 0.0, st = 0.0;
+        for (int l = 0; l < ds; ++l) { s += w[k * ld + ds + l] * e[l]; st += w[l * ld + ds + k] * e[l]; }
+        ze[k] = s; zte[k] = st;
+        quad += e[k] * s;
+    }
+    if (dmu)
+        for (int k = 0; k < ds; ++k) {
+            dmu[k] = ze[k] + zte[k];
+            dvar[k] = w[k * ld + ds + k] - g * zte[k] * ze[k];
+        }
+    return log(det) / g + quad;
+}
+
+// Input-cost terms (src/mpc.py:188-198) for one trajectory; optionally accumulates d/dU into gU [H][da].
+__device__ static double input_cost(int H, int da, const gpmpc_cost_params& C, const double* U, double* gU) {
+    double c = 0.0;
+    for (int j = 0; j < H; ++j) {
+        double d[GPMPC_MAX_D];
+        for (int k = 0; k < da; ++k) d[k] = U[j * da + k] - C.u_ref[k];
+        for (int k = 0; k < da; ++k) {
+            double rd = 0.0, rtd = 0.0;
+            for (int l = 0; l < da; ++l) { rd += C.R[k * da + l] * d[l]; rtd += C.R[l * da + k] * d[l]; }
+            c += d[k] * rd;
+            if (gU) gU[j * da + k] += rd + rtd;
+        }
+        if (C.has_R_delta) {
+            for (int k = 0; k < da; ++k) d[k] = U[j * da + k] - (j == 0 ? C.last_u[k] : U[(j - 1) * da + k]);
+            for (int k = 0; k < da; ++k) {
+                double rd = 0.0, rtd = 0.0;
+                for (int l = 0; l < da; ++l) { rd += C.R_delta[k * da + l] * d[l]; rtd += C.R_delta[l * da + k] * d[l]; }
+                c += d[k] * rd;
+                if (gU) { gU[j * da + k] += rd + rtd; if (j > 0) gU[(j - 1) * da + k] -= rd + rtd; }
+            }
+        }
+    }
+    return c;
+}
+
+// Tail: finish step H, cost, adjoint sweep.  One workgroup (64 threads) per trajectory; the first
+// GPMPC_TAIL_WORKERS threads evaluate the per-step cost terms (each needs an LU scratch in LDS).
+// dynamic LDS: [WORKERS][ds*2ds] LU scratch | [H+1] cost terms | [H+1][2ds] local derivatives
+#define GPMPC_TAIL_WORKERS 32
+__global__ __launch_bounds__(64) void k_roll_tail(RollArgs A) {
+    extern __shared__ double s_dyn[];
+    __shared__ double s_z[GPMPC_MAX_DS * (1 + 2 * GPMPC_MAX_D)];
+    const int b = blockIdx.x, ds = A.ds, da = A.da, H = A.H;
+    finish_step(A, b, H, s_z);
+    double* s_lu = s_dyn;
+    double* s_ct = s_dyn + GPMPC_TAIL_WORKERS * ds * 2 * ds;
+    double* s_dl = s_ct + (H + 1);
+    const double* mu = A.means + (size_t)b * (H + 1) * ds;
+    const double* var = A.vars + (size_t)b * (H + 1) * ds;
+    for (int i = threadIdx.x; i <= H && threadIdx.x < GPMPC_TAIL_WORKERS; i += GPMPC_TAIL_WORKERS)
+        s_ct[i] = state_cost(ds, A.cost, mu + i * ds, var + i * ds, 0, true, s_lu + threadIdx.x * ds * 2 * ds,
+                             A.grad ? s_dl + i * 2 * ds : nullptr, A.grad ? s_dl + i * 2 * ds + ds : nullptr);
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const double* U = A.U + (size_t)b * H * da;
+    double* gU = A.grad ? A.out_grad + (size_t)b * H * da : nullptr;
+    if (gU) for (int q = 0; q < H * da; ++q) gU[q] = 0.0;
+    double total = 0.0;
+    for (int i = 0; i <= H; ++i) total += s_ct[i];
+    total += input_cost(H, da, A.cost, U, gU);
+    A.out_cost[b] = total;
+    if (!A.grad) return;
+    const int nz = 2 * ds, nc = 2 * ds + da;
+    double adj[2 * GPMPC_MAX_DS], nxt[2 * GPMPC_MAX_DS];
+    for (int r = 0; r < nz; ++r) adj[r] = s_dl[H * nz + r];
+    for (int t = H; t >= 1; --t) {
+        const double* J = A.jac + ((size_t)b * H + (t - 1)) * nz * nc;
+        for (int k = 0; k < da; ++k) {
+            double s = 0.0;
+            for (int r = 0; r < nz; ++r) s = fma(J[r * nc + nz + k], adj[r], s);
+            gU[(t - 1) * da + k] += s;
+        }
+        for (int cidx = 0; cidx < nz; ++cidx) {
+            double s = s_dl[(t - 1) * nz + cidx];
+            for (int r = 0; r < nz; ++r) s = fma(J[r * nc + cidx], adj[r], s);
+            nxt[cidx] = s;
+        }
+        for (int r = 0; r < nz; ++r) adj[r] = nxt[r];
+    }
+}
+
+// Stand-alone cost for given means / FULL covariances (cost_torch parity, src/mpc.py:156-200).
+__global__ void k_cost_full(int B, int H, int ds, int da, gpmpc_cost_params C, const double* means, const double* covs,
+                            const double* U, double* out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double w[GPMPC_MAX_DS * 2 * GPMPC_MAX_DS];
+    double total = 0.0;
+    for (int i = 0; i <= H; ++i)
+        total += state_cost(ds, C, means + ((size_t)b * (H + 1) + i) * ds, covs + ((size_t)b * (H + 1) + i) * ds * ds, ds,
+                            false, w, nullptr, nullptr);
+    total += input_cost(H, da, C, U + (size_t)b * H * da, nullptr);
+    out[b] = total;
+}
+
+// ---------------------------------------------------------------------------
+// host side of the rollout
+// ---------------------------------------------------------------------------
+static thread_local char g_err[256] = "";
+void gpmpc_set_error(const char* what, hipError_t e) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+}
+extern "C" const char* gpmpc_last_error(void) { return g_err; }
+extern "C" const char* gpmpc_version(void) { return "gpmpc-hip 0.1 (gfx950)"; }
+extern "C" int gpmpc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static int g_timing = 0;
+static double g_pair_ms = 0.0;
+static long long g_pair_launches = 0;
+struct EvPair { hipEvent_t a, b; };
+static EvPair g_pending[4096];
+static int g_npending = 0;
+
+static void drain_events() {
+    for (int k = 0; k < g_npending; ++k) {
+        float ms = 0.f;
+        if (hipEventSynchronize(g_pending[k].b) == hipSuccess && hipEventElapsedTime(&ms, g_pending[k].a, g_pending[k].b) == hipSuccess) {
+            g_pair_ms += ms; ++g_pair_launches;
+        }
+        (void)hipEventDestroy(g_pending[k].a); (void)hipEventDestroy(g_pending[k].b);
+    }
+    g_npending = 0;
+}
+extern "C" int gpmpc_timing_enable(int on) { g_timing = on; return GPMPC_OK; }
+extern "C" int gpmpc_pair_kernel_time(double* total_ms, long long* launches, int reset) {
+    drain_events();
+    if (total_ms) *total_ms = g_pair_ms;
+    if (launches) *launches = g_pair_launches;
+    if (reset) { g_pair_ms = 0.0; g_pair_launches = 0; }
+    return GPMPC_OK;
+}
+
+int gpmpc_timed_pair(int D, bool diag, bool grad, int tb, int waves, const PairArgs& a, hipStream_t s) {
+    if (!g_timing) return gpmpc_launch_pair(D, diag, grad, tb, waves, a, s);
+    if (g_npending == 4096) drain_events();
+    EvPair ev;
+    GPMPC_HIP(hipEventCreate(&ev.a));
+    GPMPC_HIP(hipEventCreate(&ev.b));
+    GPMPC_HIP(hipEventRecord(ev.a, s));
+    int rc = gpmpc_launch_pair(D, diag, grad, tb, waves, a, s);
+    GPMPC_HIP(hipEventRecord(ev.b, s));
+    g_pending[g_npending++] = ev;
+    return rc;
+}
+
+struct RollPlan { int tiling, tb, waves, ntiles, nm, pps, sps; size_t off_pp, off_sp, off_part, off_jac, off_means, off_vars, total; };
+
+static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag, RollPlan* r) {
+    const int D = p->D;
+    r->tb = B >= 4 ? 4 : 1;
+    if (!diag && grad && r->tb > 2) r->tb = 2;
+    const long groups = (B + r->tb - 1) / r->tb;
+    // big workgroups once they already oversubscribe the 256 CUs; one-wave tiles otherwise
+    r->tiling = (groups * p->tilings[0].ntiles * p->ds >= 1024) ? 0 : 1;
+    r->waves = p->tilings[r->tiling].waves;
+    r->ntiles = p->tilings[r->tiling].ntiles;
+    r->nm = gpmpc_num_moments(D, diag, grad);
+    r->pps = D + D * D;
+    r->sps = sps_of(D);
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += (n * sizeof(double) + 255) & ~(size_t)255; return o; };
+    r->off_pp = take((size_t)B * p->ds * r->pps);
+    r->off_sp = take((size_t)B * p->ds * r->sps);
+    r->off_part = take((size_t)B * p->ds * r->ntiles * r->nm);
+    r->off_jac = take(grad ? (size_t)B * H * 2 * p->ds * (2 * p->ds + p->da) : 0);
+    r->off_means = take((size_t)B * (H + 1) * p->ds);
+    r->off_vars = take((size_t)B * (H + 1) * p->ds);
+    r->total = off;
+}
+
+extern "C" size_t gpmpc_rollout_workspace_bytes(const gpmpc_pack* p, int B, int H, unsigned flags) {
+    if (!p || B < 1 || H < 1) return 0;
+    RollPlan r;
+    plan_rollout(p, B, H, (flags & GPMPC_WANT_GRAD) != 0, true, &r);
+    return r.total;
+}
+
+template <int D>
+static void launch_head(const RollArgs& A, int t, hipStream_t s) {
+    hipLaunchKernelGGL(k_roll_head<D>, dim3(A.B), dim3(256), 0, s, A, t);
+}
+
+extern "C" int gpmpc_rollout(const gpmpc_pack* p, int B, int H, const double* x0, const double* U,
+                             const gpmpc_cost_params* cost, unsigned flags, double* out_means, double* out_vars,
+                             double* out_cost, double* out_grad, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!p || !x0 || !U || !cost || !out_cost || !workspace || B < 1 || H < 1) return GPMPC_E_ARG;
+    if (!p->built) return GPMPC_E_STATE;
+    const bool grad = (flags & GPMPC_WANT_GRAD) != 0;
+    if (grad && !out_grad) return GPMPC_E_ARG;
+    RollPlan r;
+    plan_rollout(p, B, H, grad, true, &r);
+    if (workspace_bytes < r.total) return GPMPC_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    RollArgs A;
+    memset(&A, 0, sizeof(A));
+    A.XT = p->XT; A.beta = p->beta; A.lam = p->lam; A.sf = p->sf;
+    A.N = p->N; A.Np = p->Np; A.ds = p->ds; A.da = p->da; A.D = p->D;
+    A.x0 = x0; A.U = U; A.B = B; A.H = H;
+    A.means = out_means ? out_means : (double*)(ws + r.off_means);
+    A.vars = out_vars ? out_vars : (double*)(ws + r.off_vars);
+    A.pp = (double*)(ws + r.off_pp); A.sp = (double*)(ws + r.off_sp); A.part = (double*)(ws + r.off_part);
+    A.jac = grad ? (double*)(ws + r.off_jac) : nullptr;
+    A.pps = r.pps; A.sps = r.sps; A.ntiles = r.ntiles; A.nm = r.nm; A.grad = grad ? 1 : 0;
+    A.out_cost = out_cost; A.out_grad = out_grad; A.cost = *cost;
+
+    PairArgs P;
+    P.M = p->M; P.XT = p->XT; P.pp = A.pp; P.part = A.part; P.tiles = p->tilings[r.tiling].tiles_dev;
+    P.Np = p->Np; P.ds = p->ds; P.B = B; P.ntiles = r.ntiles; P.pps = r.pps; P.nm = r.nm;
+
+    for (int t = 1; t <= H; ++t) {
+        switch (p->D) {
+            case 1: launch_head<1>(A, t, s); break;
+            case 2: launch_head<2>(A, t, s); break;
+            case 3: launch_head<3>(A, t, s); break;
+            case 4: launch_head<4>(A, t, s); break;
+            case 5: launch_head<5>(A, t, s); break;
+            case 6: launch_head<6>(A, t, s); break;
+            case 7: launch_head<7>(A, t, s); break;
+            case 8: launch_head<8>(A, t, s); break;
+            default: return GPMPC_E_ARG;
+        }
+        int rc = gpmpc_timed_pair(p->D, true, grad, r.tb, r.waves, P, s);
+        if (rc != GPMPC_OK) return rc;
+    }
+    const size_t lds = sizeof(double) * ((size_t)GPMPC_TAIL_WORKERS * p->ds * 2 * p->ds + (size_t)(H + 1) * (1 + 2 * p->ds));
+    if (lds > 60 * 1024) return GPMPC_E_ARG;   // horizon too long for the tail kernel's LDS budget
+    hipLaunchKernelGGL(k_roll_tail, dim3(B), dim3(64), lds, s, A);
+    GPMPC_HIP(hipGetLastError());
+    return GPMPC_OK;
+}
+
+extern "C" int gpmpc_cost(int B, int H, int ds, int da, const gpmpc_cost_params* cost, const double* means,
+                          const double* covs, const double* U, double* out_cost, void* stream) {
+    if (!cost || !means || !covs || !U || !out_cost || B < 1 || H < 1 || ds < 1 || ds > GPMPC_MAX_DS || da < 0 ||
+        da > GPMPC_MAX_D)
+        return GPMPC_E_ARG;
+    hipLaunchKernelGGL(k_cost_full, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, B, H, ds, da, *cost, means,
+                       covs, U, out_cost);
+    GPMPC_HIP(hipGetLastError());
+    return GPMPC_OK;
+}

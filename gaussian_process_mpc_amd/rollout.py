@@ -1,0 +1,180 @@
+"""Thin, batched host API over the C ABI: GP pack, cost parameters, rollout, moment matching.
+
+Everything here is plumbing (device buffers, streams, argument marshalling); the
+arithmetic lives in csrc/*.hip.  Tensors are float64 CUDA tensors; numpy inputs are
+copied to the current device.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import CostParamsC, check, lib, ptr, require_gpu, stream_ptr, host_doubles
+
+
+def _dev(a, device):
+    if isinstance(a, torch.Tensor):
+        return a.detach().to(device=device, dtype=torch.float64).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(np.asarray(a, dtype=np.float64)), device=device)
+
+
+class CostParams:
+    """Parameters of RiskSensitiveMPC.cost_torch (reference src/mpc.py:156-200)."""
+
+    def __init__(self, gamma, Q, R, R_delta=None, x_ref=None, u_ref=None, last_u=None):
+        Q = np.atleast_2d(np.asarray(Q, dtype=np.float64))
+        R = np.atleast_2d(np.asarray(R, dtype=np.float64))
+        self.ds, self.da = Q.shape[0], R.shape[0]
+        if Q.shape != (self.ds, self.ds) or R.shape != (self.da, self.da):
+            raise ValueError("Q and R must be square")
+        if self.ds > _lib.MAX_DS or self.da > _lib.MAX_D:
+            raise ValueError("state / input dimension exceeds the library limits")
+        c = CostParamsC()
+        c.gamma = float(gamma)
+        c.Q[:self.ds * self.ds] = Q.reshape(-1).tolist()
+        c.R[:self.da * self.da] = R.reshape(-1).tolist()
+        if R_delta is not None:
+            Rd = np.atleast_2d(np.asarray(R_delta, dtype=np.float64))
+            c.R_delta[:self.da * self.da] = Rd.reshape(-1).tolist()
+            c.has_R_delta = 1
+            lu = np.zeros(self.da) if last_u is None else np.asarray(last_u, dtype=np.float64).reshape(-1)[:self.da]
+            c.last_u[:self.da] = lu.tolist()
+        xr = np.zeros(self.ds) if x_ref is None else np.asarray(x_ref, dtype=np.float64).reshape(-1)
+        ur = np.zeros(self.da) if u_ref is None else np.asarray(u_ref, dtype=np.float64).reshape(-1)
+        c.x_ref[:self.ds] = xr.tolist()
+        c.u_ref[:self.da] = ur.tolist()
+        self.c = c
+
+
+class GPPack:
+    """Device-resident state of ``ds`` GPs sharing X (reference: what Dynamics +
+    GaussianProcessRegression hold, src/dynamics.py:33-37, src/gpr.py:24-36) folded into
+    the per-data-update constants of the rollout (beta, weight matrices)."""
+
+    def __init__(self, X, Y, Ky_inv, lambdas, sigma_f, device=None):
+        self.device = device if device is not None else require_gpu()
+        self.X = _dev(X, self.device)
+        Y = _dev(Y, self.device)
+        self.Y = Y.reshape(self.X.shape[0], -1)
+        self.N, self.D = self.X.shape
+        self.ds = self.Y.shape[1]
+        self.da = self.D - self.ds
+        Ky_inv = _dev(Ky_inv, self.device).reshape(self.ds, self.N, self.N)
+        self.lambdas = np.ascontiguousarray(np.asarray(lambdas, dtype=np.float64).reshape(self.ds, self.D))
+        self.sigma_f = np.ascontiguousarray(np.asarray(sigma_f, dtype=np.float64).reshape(self.ds))
+        h = ctypes.c_void_p()
+        check(lib().gpmpc_pack_create(ctypes.byref(h), self.N, self.ds, self.da), "gpmpc_pack_create")
+        self._h = h
+        _, lp = host_doubles(self.lambdas)
+        _, sp = host_doubles(self.sigma_f)
+        with torch.cuda.device(self.device):
+            check(lib().gpmpc_pack_build(self._h, ptr(self.X), ptr(self.Y), ptr(Ky_inv), lp, sp, stream_ptr()),
+                  "gpmpc_pack_build")
+        n, npad, ds, da = (ctypes.c_int() for _ in range(4))
+        lib().gpmpc_pack_dims(self._h, ctypes.byref(n), ctypes.byref(npad), ctypes.byref(ds), ctypes.byref(da))
+        self.Np = npad.value
+        self._ws = None
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                torch.cuda.synchronize(self.device)
+                lib().gpmpc_pack_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    @property
+    def handle(self):
+        return self._h
+
+    def workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def beta(self):
+        """(ds, N) copy of the cached beta vectors (for tests)."""
+        out = torch.empty((self.ds, self.Np), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().gpmpc_pack_export(self._h, ptr(out), None, stream_ptr()), "gpmpc_pack_export")
+        return out[:, :self.N]
+
+    def weights(self):
+        """(ds, Np, Np) copy of the folded weight matrices, element (i<=j) at [a, j, i] (for tests)."""
+        out = torch.empty((self.ds, self.Np, self.Np), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().gpmpc_pack_export(self._h, None, ptr(out), stream_ptr()), "gpmpc_pack_export")
+        return out
+
+
+def rollout(pack, x0, U, cost, want_grad=True, want_traj=True):
+    """B shooting rollouts + cost (+ gradient) in one call (C ABI ``gpmpc_rollout``).
+
+    x0: (B, ds) or (ds,); U: (B, H, da) or (H, da).  Returns a dict of CUDA tensors:
+    cost (B,), grad (B, H, da), means (B, H+1, ds), vars (B, H+1, ds)."""
+    dev = pack.device
+    U = _dev(U, dev)
+    if U.dim() == 2:
+        U = U.unsqueeze(0)
+    B, H, da = U.shape
+    x0 = _dev(x0, dev).reshape(-1, pack.ds)
+    if x0.shape[0] == 1 and B > 1:
+        x0 = x0.expand(B, pack.ds).contiguous()
+    if da != pack.da or x0.shape[0] != B or cost.ds != pack.ds or cost.da != pack.da:
+        raise ValueError("shape mismatch between pack, x0, U and cost parameters")
+    flags = _lib.WANT_GRAD if want_grad else 0
+    out = {"cost": torch.empty(B, dtype=torch.float64, device=dev)}
+    if want_grad:
+        out["grad"] = torch.empty((B, H, da), dtype=torch.float64, device=dev)
+    if want_traj:
+        out["means"] = torch.empty((B, H + 1, pack.ds), dtype=torch.float64, device=dev)
+        out["vars"] = torch.empty((B, H + 1, pack.ds), dtype=torch.float64, device=dev)
+    nbytes = lib().gpmpc_rollout_workspace_bytes(pack.handle, B, H, flags)
+    ws = pack.workspace(nbytes)
+    with torch.cuda.device(dev):
+        check(lib().gpmpc_rollout(pack.handle, B, H, ptr(x0), ptr(U), ctypes.byref(cost.c), flags,
+                                  ptr(out.get("means")), ptr(out.get("vars")), ptr(out["cost"]), ptr(out.get("grad")),
+                                  ctypes.c_void_p(ws.data_ptr()), ws.numel(), stream_ptr()), "gpmpc_rollout")
+    return out
+
+
+def moment_match(pack, u, S, want_cov=False, want_grad=False, bug_compatible=False):
+    """Exact moment matching of all ds GPs for nq Gaussian inputs N(u, S) with full S
+    (C ABI ``gpmpc_moment_match``).  u: (nq, D) or (D,); S: (nq, D, D) or (D, D)."""
+    dev = pack.device
+    u = _dev(u, dev).reshape(-1, pack.D)
+    nq = u.shape[0]
+    S = _dev(S, dev).reshape(nq, pack.D, pack.D)
+    flags = (_lib.WANT_GRAD if want_grad else 0) | (_lib.COV_BUG_COMPAT if bug_compatible else 0)
+    ds, D = pack.ds, pack.D
+    e = lambda *shape: torch.empty(shape, dtype=torch.float64, device=dev)  # noqa: E731
+    out = {"mean": e(nq, ds), "var": e(nq, ds)}
+    if want_cov:
+        out["cov"] = e(nq, ds, ds)
+    if want_grad:
+        out.update(dmean_du=e(nq, ds, D), dmean_dS=e(nq, ds, D, D), dvar_du=e(nq, ds, D), dvar_dS=e(nq, ds, D, D))
+    nbytes = lib().gpmpc_moment_match_workspace_bytes(pack.handle, nq)
+    ws = pack.workspace(nbytes)
+    with torch.cuda.device(dev):
+        check(lib().gpmpc_moment_match(pack.handle, nq, ptr(u), ptr(S), flags, ptr(out["mean"]), ptr(out["var"]),
+                                       ptr(out.get("cov")), ptr(out.get("dmean_du")), ptr(out.get("dmean_dS")),
+                                       ptr(out.get("dvar_du")), ptr(out.get("dvar_dS")),
+                                       ctypes.c_void_p(ws.data_ptr()), ws.numel(), stream_ptr()), "gpmpc_moment_match")
+    return out
+
+
+def cost_full(cost, means, covs, U):
+    """Risk-sensitive cost for given means (B,H+1,ds), FULL covariances (B,H+1,ds,ds), inputs (B,H,da)
+    (C ABI ``gpmpc_cost``; reference src/mpc.py:156-200)."""
+    dev = require_gpu()
+    means, covs, U = _dev(means, dev), _dev(covs, dev), _dev(U, dev)
+    if means.dim() == 2:
+        means, covs, U = means.unsqueeze(0), covs.unsqueeze(0), U.unsqueeze(0)
+    B, H1, ds = means.shape
+    out = torch.empty(B, dtype=torch.float64, device=dev)
+    check(lib().gpmpc_cost(B, H1 - 1, ds, U.shape[2], ctypes.byref(cost.c), ptr(means), ptr(covs), ptr(U), ptr(out),
+                           stream_ptr()), "gpmpc_cost")
+    return out

@@ -1,0 +1,179 @@
+/*
+ * gpmpc.h -- C ABI of the MI355X-native GP-MPC rollout library (libgpmpc_hip.so).
+ *
+ * Drop-in boundary for the hot path of Thiagodcv/gaussian-process-mpc.  The
+ * reference has no FFI of its own (it is pure Python on torch); the entry
+ * points below are what a binding for this path has to call, and each one
+ * names the reference interface it replaces (paths relative to the upstream
+ * repository root).  INTEGRATION.md shows the ctypes stub a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *  - All matrices are row-major fp64.  "dev" = device (HBM) pointer, "host" =
+ *    host pointer.  The caller owns every buffer; the library never frees or
+ *    reallocates caller memory and keeps no global state besides the pack.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *    All work is enqueued asynchronously on it; nothing synchronises the
+ *    device.  Calls are re-entrant across streams as long as workspaces differ.
+ *  - Return value: 0 on success, a negative GPMPC_E_* code otherwise.  No
+ *    exception crosses the ABI.  NaNs produced by the arithmetic (negative
+ *    variances, log of a non-positive determinant) are passed through, as in
+ *    the reference.
+ *  - Dimensions: D = ds + da <= GPMPC_MAX_D, ds <= GPMPC_MAX_DS.
+ */
+#ifndef GPMPC_H
+#define GPMPC_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPMPC_MAX_D   8
+#define GPMPC_MAX_DS  8
+
+#define GPMPC_OK            0
+#define GPMPC_E_ARG        -1   /* bad argument (NULL pointer, dimension out of range) */
+#define GPMPC_E_ALLOC      -2   /* device allocation failed */
+#define GPMPC_E_LAUNCH     -3   /* a HIP call or kernel launch failed */
+#define GPMPC_E_WORKSPACE  -4   /* workspace too small */
+#define GPMPC_E_STATE      -5   /* pack not built */
+
+/* flags for gpmpc_rollout / gpmpc_moment_match */
+#define GPMPC_WANT_GRAD      1u   /* also produce d cost / d U (rollout) or input Jacobians (moment_match) */
+#define GPMPC_COV_BUG_COMPAT 2u   /* cross-covariance with the reference's transposed cross term
+                                     (src/tools/uncertainty_prop.py:446) instead of the consistent one */
+
+typedef struct gpmpc_pack gpmpc_pack;   /* opaque: device-resident GP state */
+
+/* Library / device probe.  Returns the number of visible HIP devices (>= 0) or a negative code. */
+int gpmpc_device_count(void);
+const char* gpmpc_version(void);
+const char* gpmpc_last_error(void);     /* thread-local text of the last failing HIP call */
+
+/* ---------------------------------------------------------------------------
+ * GP state ("pack").  Replaces the per-call constant work of
+ *   mean_prop_torch      src/tools/uncertainty_prop.py:324-327 (beta = Ky_inv @ y)
+ *   variance_prop_torch  src/tools/uncertainty_prop.py:392-399 (Lambda_part, Ky_inv - beta beta^T)
+ * and holds what Dynamics/GaussianProcessRegression hold on the device
+ * (src/dynamics.py:33-37, src/gpr.py:24-36): X_train shared by all ds GPs,
+ * per GP: beta, lambdas, sigma_f and the folded weight matrix
+ *   M_a[i][j] = sym(Ky_inv_a - beta_a beta_a^T)[i][j] * sigma_f_a^4
+ *               * exp(-1/4 (x_i-x_j)^T Lambda_a^-1 (x_i-x_j))
+ * stored upper-triangular with off-diagonal weight 2.
+ * ------------------------------------------------------------------------- */
+int gpmpc_pack_create(gpmpc_pack** out, int n_train, int state_dim, int action_dim);
+int gpmpc_pack_destroy(gpmpc_pack* pack);
+
+/* Build K_f, K_y = K_f + noise_var*I for one GP on the device
+ * (GaussianProcessRegression.build_Ky_inv_mat, src/gpr.py:163-170; the inverse at :171 is
+ * taken by the caller).  X dev [n][D]; lambdas host [D]; Kf, Ky dev [n][n] (Kf may be NULL).
+ * noise_var is the value added on the diagonal (the reference adds float32(sigma_n^2)). */
+int gpmpc_build_ky(int n, int D, const double* X_dev, const double* lambdas_host,
+                   double sigma_f, double noise_var, double* Kf_dev, double* Ky_dev, void* stream);
+
+/* Fill the pack.  X dev [N][D]; Y dev [N][ds] (column a = targets of GP a, as
+ * Dynamics.append_train_data stores them, src/dynamics.py:51-60); Ky_inv dev [ds][N][N]
+ * (src/gpr.py:171); lambdas host [ds][D]; sigma_f host [ds]. */
+int gpmpc_pack_build(gpmpc_pack* pack, const double* X_dev, const double* Y_dev,
+                     const double* Ky_inv_dev, const double* lambdas_host,
+                     const double* sigma_f_host, void* stream);
+
+/* Inspection for tests / bindings.  gpmpc_pack_export copies into caller buffers (either may be NULL):
+ * beta_out dev [ds][n_padded] (beta_a = Ky_inv_a y_a, zero padded); weights_out dev
+ * [ds][n_padded][n_padded], element (i <= j) of M_a at [a][j][i], zero elsewhere. */
+int gpmpc_pack_dims(const gpmpc_pack* pack, int* n_train, int* n_padded, int* state_dim, int* action_dim);
+int gpmpc_pack_export(const gpmpc_pack* pack, double* beta_out, double* weights_out, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Single-step exact moment matching for nq Gaussian inputs N(u_q, S_q), all ds GPs.
+ * Replaces mean_prop_torch / variance_prop_torch / covariance_prop_torch
+ * (src/tools/uncertainty_prop.py:296-338, :341-399, :402-465).  S may be a full
+ * symmetric positive-definite matrix.
+ *   u dev [nq][D], S dev [nq][D][D]
+ *   out_mean dev [nq][ds]; out_var dev [nq][ds]
+ *   out_cov  dev [nq][ds][ds] or NULL: full predictive covariance (diagonal = out_var,
+ *            off-diagonal = cross-covariances; flag GPMPC_COV_BUG_COMPAT selects the
+ *            reference's transposed cross term)
+ *   with GPMPC_WANT_GRAD (all four non-NULL):
+ *     dmean_du dev [nq][ds][D], dmean_dS dev [nq][ds][D][D] (symmetrised),
+ *     dvar_du  dev [nq][ds][D], dvar_dS  dev [nq][ds][D][D] (symmetrised)
+ * ------------------------------------------------------------------------- */
+size_t gpmpc_moment_match_workspace_bytes(const gpmpc_pack* pack, int nq);
+int gpmpc_moment_match(const gpmpc_pack* pack, int nq, const double* u_dev, const double* S_dev,
+                       unsigned flags, double* out_mean, double* out_var, double* out_cov,
+                       double* dmean_du, double* dmean_dS, double* dvar_du, double* dvar_dS,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Risk-sensitive cost (RiskSensitiveMPC.cost_torch, src/mpc.py:156-200).
+ * gamma == 0 selects the risk-neutral limit tr(Q Sigma) + e^T Q e (the reference
+ * divides by gamma and cannot evaluate it).
+ * ------------------------------------------------------------------------- */
+typedef struct gpmpc_cost_params {
+    double gamma;
+    double Q[GPMPC_MAX_DS * GPMPC_MAX_DS];            /* [ds][ds] row-major in the leading ds*ds entries */
+    double R[GPMPC_MAX_D * GPMPC_MAX_D];              /* [da][da] */
+    double R_delta[GPMPC_MAX_D * GPMPC_MAX_D];        /* [da][da], used when has_R_delta != 0 */
+    double x_ref[GPMPC_MAX_DS];
+    double u_ref[GPMPC_MAX_D];
+    double last_u[GPMPC_MAX_D];                       /* last_traj[0:da], src/mpc.py:192 */
+    int has_R_delta;
+    int reserved;
+} gpmpc_cost_params;
+
+/* Cost of B given trajectories with FULL covariance matrices (parity with cost_torch on
+ * arbitrary, even non-symmetric, Sigma): means dev [B][H+1][ds], covs dev [B][H+1][ds][ds],
+ * U dev [B][H][da] -> out_cost dev [B]. */
+int gpmpc_cost(int B, int H, int state_dim, int action_dim, const gpmpc_cost_params* cost_host,
+               const double* means_dev, const double* covs_dev, const double* U_dev,
+               double* out_cost, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * The hot path: B independent shooting rollouts + cost + gradient.
+ * Replaces, for each trajectory b,
+ *   Dynamics.forward_propagate_torch(H, x0[b], U[b])      src/dynamics.py:126-191
+ *   RiskSensitiveMPC.cost_torch(...)                        src/mpc.py:156-200
+ *   RiskSensitiveMPC.objective(x) / gradient(x)             src/mpc.py:202-255
+ * (the reference handles one trajectory per call; B > 1 is the batched form).
+ * Semantics kept: Sigma_0 = 1e-3 I (float64), action-noise variance float32(1e-3),
+ * diagonal covariance propagation, no clamp of negative variances.
+ *   x0 dev [B][ds]; U dev [B][H][da]
+ *   out_means dev [B][H+1][ds]; out_vars dev [B][H+1][ds]  (either may be NULL)
+ *   out_cost dev [B]; out_grad dev [B][H][da] (required with GPMPC_WANT_GRAD)
+ * ------------------------------------------------------------------------- */
+size_t gpmpc_rollout_workspace_bytes(const gpmpc_pack* pack, int B, int H, unsigned flags);
+int gpmpc_rollout(const gpmpc_pack* pack, int B, int H, const double* x0_dev, const double* U_dev,
+                  const gpmpc_cost_params* cost_host, unsigned flags,
+                  double* out_means, double* out_vars, double* out_cost, double* out_grad,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* Kernel-level timing of the dominant (pair) kernel for bench.py: when enabled, every
+ * gpmpc_rollout brackets its pair-kernel launches with HIP events on the launch stream.
+ * gpmpc_pair_kernel_time returns accumulated milliseconds and launch count since the last reset
+ * (it synchronises on the recorded events). */
+int gpmpc_timing_enable(int on);
+int gpmpc_pair_kernel_time(double* total_ms, long long* launches, int reset);
+
+/* ---------------------------------------------------------------------------
+ * GP prediction at test points (GaussianProcessRegression.compute_pred_train_covariance /
+ * predict_latent_vars, src/gpr.py:253-332) for ONE GP given by raw arrays.
+ *   X dev [n][D]; lambdas host [D]; beta dev [n] = Ky_inv (y - f_nom(X)) (needed for out_mean);
+ *   Ky_inv dev [n][n] (needed for out_cov); X_pred dev [p][D];
+ *   out_K dev [p][n] or NULL; out_mean dev [p] or NULL (nominal-model term added by the caller);
+ *   out_cov dev [p][p] or NULL = K** - K* Ky_inv K*^T + noise_var * I.
+ * gpmpc_matvec: out[r] = A[r] . v for a row-major [rows][cols] matrix (beta = Ky_inv y,
+ * src/tools/uncertainty_prop.py:327).
+ * ------------------------------------------------------------------------- */
+int gpmpc_matvec(int rows, int cols, const double* A_dev, const double* v_dev, double* out_dev, void* stream);
+size_t gpmpc_predict_workspace_bytes(int n, int D, int p);
+int gpmpc_predict(int n, int D, const double* X_dev, const double* lambdas_host, double sigma_f,
+                  const double* beta_dev, const double* Ky_inv_dev, double noise_var,
+                  int p, const double* X_pred_dev, double* out_K, double* out_mean, double* out_cov,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPMPC_H */

@@ -1,0 +1,209 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the committed golden vectors
+(produced by the reference itself) and against the CPU oracle on seeded inputs.
+
+Tolerances (north star): state means 1e-5 relative, variances 1e-4 relative, fp64.
+The asserted tolerances below are tighter where the arithmetic allows it.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+MEAN_RTOL = 1e-5      # north-star bound; observed ~1e-10
+VAR_RTOL = 1e-4       # north-star bound; observed ~1e-7
+
+
+@pytest.fixture(scope="module")
+def G():
+    import gaussian_process_mpc_amd as g
+    g.require_gpu()
+    return g
+
+
+def _pack_from(G, z):
+    return G.GPPack(z["X"], z["Y"], z["Ky_inv"], z["lambdas"], z["sigma_f"])
+
+
+def _cost_from(G, z, gamma):
+    ds, da = int(z["dims"][1]), int(z["dims"][2])
+    return G.CostParams(gamma, z["Q"], z["R"],
+                        R_delta=z["R_delta"] if "R_delta" in z else None,
+                        x_ref=z["x_ref"] if "x_ref" in z else np.zeros(ds),
+                        u_ref=z["u_ref"] if "u_ref" in z else np.zeros(da),
+                        last_u=z["last_traj"][:da] if "last_traj" in z else None)
+
+
+def test_pack_constants(G, golden):
+    """beta and the folded weight matrix against their definitions (numpy, from the fixture)."""
+    z = golden("g3_rollout_c1.npz")
+    pack = _pack_from(G, z)
+    N, ds = z["X"].shape[0], z["Y"].shape[1]
+    beta = pack.beta().cpu().numpy()
+    W = pack.weights().cpu().numpy()
+    for a in range(ds):
+        b_ref = z["Ky_inv"][a] @ z["Y"][:, a]
+        np.testing.assert_allclose(beta[a], b_ref, rtol=1e-9, atol=1e-9 * np.abs(b_ref).max())
+        d = z["X"][:, None, :] - z["X"][None, :, :]
+        lam_part = np.exp(-0.25 * np.sum(d * d / z["lambdas"][a], axis=2))
+        Wsym = 0.5 * (z["Ky_inv"][a] + z["Ky_inv"][a].T) - np.outer(b_ref, b_ref)
+        M = Wsym * lam_part * z["sigma_f"][a] ** 4
+        ref = np.triu(M, 1) * 2 + np.diag(np.diag(M))          # element (i<=j)
+        got = W[a].T[:N, :N]                                    # stored at [j][i]
+        np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-9 * np.abs(ref).max())
+        assert np.all(W[a][:, N:] == 0) and np.all(W[a][N:, :] == 0)
+        assert np.all(np.tril(got, -1) == 0)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_g1_single_step(G, golden, tag):
+    z = golden("g1_single_step.npz")
+    X, y = z[f"{tag}_X"], z[f"{tag}_y"]
+    Ki = np.stack([z[f"{tag}_Kinv1"], z[f"{tag}_Kinv2"]])
+    pack = G.GPPack(X, np.stack([y, y], axis=1), Ki, np.stack([z["lam1"], z["lam2"]]), z[f"{tag}_sf"])
+    r = G.moment_match(pack, z["u"], z["S"], want_cov=True, bug_compatible=True)
+    np.testing.assert_allclose(r["mean"][0].cpu().numpy(), z[f"{tag}_mu"], rtol=1e-9)
+    np.testing.assert_allclose(r["var"][0].cpu().numpy(), z[f"{tag}_var"], rtol=1e-6)
+    cov = r["cov"][0].cpu().numpy()
+    np.testing.assert_allclose(cov[0, 1], z[f"{tag}_cov"], rtol=1e-7)
+    np.testing.assert_allclose(np.diag(cov), z[f"{tag}_var"], rtol=1e-6)
+    if f"{tag}_np_cov" in z:
+        # reference's own rung-2 tolerances (abs 1e-7 mean, 1e-5 var / cov) against its numpy loops
+        assert abs(r["mean"][0, 0].item() - z[f"{tag}_np_mu"]) < 1e-7 * max(1.0, abs(z[f"{tag}_np_mu"]))
+        assert abs(r["var"][0, 0].item() - z[f"{tag}_np_var"]) < 1e-5 * abs(z[f"{tag}_np_var"])
+
+
+@pytest.mark.parametrize("k", range(6))
+def test_g2_adversarial(G, golden, k):
+    z = golden("g2_adversarial.npz")
+    p = f"c{k}_"
+    sf1, sf2, _ = z[p + "hyp"]
+    pack = G.GPPack(z[p + "X"], np.stack([z[p + "y1"], z[p + "y2"]], axis=1),
+                    np.stack([z[p + "Kinv1"], z[p + "Kinv2"]]), np.stack([z[p + "lam1"], z[p + "lam2"]]),
+                    np.array([sf1, sf2]))
+    r = G.moment_match(pack, z[p + "u"], z[p + "S"], want_cov=True, want_grad=True, bug_compatible=True)
+    np.testing.assert_allclose(r["mean"][0].cpu().numpy(), z[p + "mu"], rtol=1e-9)
+    np.testing.assert_allclose(r["var"][0].cpu().numpy(), z[p + "var"], rtol=1e-6)
+    np.testing.assert_allclose(r["cov"][0, 0, 1].item(), z[p + "cov_torch"], rtol=1e-6, atol=1e-9)
+    sym = lambda A: 0.5 * (A + A.T)                                 # noqa: E731
+    np.testing.assert_allclose(r["dmean_du"][0, 0].cpu().numpy(), z[p + "dm_du"], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(r["dmean_dS"][0, 0].cpu().numpy(), sym(z[p + "dm_dS"]), rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(r["dvar_du"][0, 0].cpu().numpy(), z[p + "dv_du"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(r["dvar_dS"][0, 0].cpu().numpy(), sym(z[p + "dv_dS"]), rtol=1e-5, atol=1e-7)
+    # unit sigma_f, shared y: consistent form == the reference's numpy double loop
+    packu = G.GPPack(z[p + "X"], np.stack([z[p + "y1"], z[p + "y1"]], axis=1),
+                     np.stack([z[p + "unit_Kinv1"], z[p + "unit_Kinv2"]]),
+                     np.stack([z[p + "lam1"], z[p + "lam2"]]), np.ones(2))
+    fix = G.moment_match(packu, z[p + "u"], z[p + "S"], want_cov=True)["cov"][0].cpu().numpy()
+    bug = G.moment_match(packu, z[p + "u"], z[p + "S"], want_cov=True, bug_compatible=True)["cov"][0].cpu().numpy()
+    np.testing.assert_allclose(fix[0, 1], z[p + "unit_cov_numpy"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(fix[1, 0], fix[0, 1], rtol=0, atol=0)
+    np.testing.assert_allclose(bug[0, 1], z[p + "unit_cov_torch"], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("name", ["g3_rollout_c1.npz", "g4_rollout_c2.npz"])
+def test_rollout_golden(G, golden, name):
+    """Rollout + cost + gradient against the reference's own outputs, per trajectory and batched."""
+    z = golden(name)
+    pack = _pack_from(G, z)
+    B = z["x0"].shape[0]
+    for gi, gamma in enumerate(z["gammas"]):
+        cost = _cost_from(G, z, float(gamma))
+        rb = G.rollout(pack, z["x0"], z["U"], cost)                 # batched
+        for b in range(B):
+            r1 = G.rollout(pack, z["x0"][b], z["U"][b], cost)       # single trajectory, as the reference
+            for r, idx in ((r1, 0), (rb, b)):
+                np.testing.assert_allclose(r["means"][idx].cpu().numpy(), z["means"][b], rtol=MEAN_RTOL, atol=1e-9)
+                np.testing.assert_allclose(r["vars"][idx].cpu().numpy(), z["vars"][b], rtol=VAR_RTOL, atol=1e-12)
+                np.testing.assert_allclose(r["cost"][idx].item(), z["costs"][gi, b], rtol=1e-6)
+                np.testing.assert_allclose(r["grad"][idx].cpu().numpy(), z["grads"][gi, b], rtol=1e-4, atol=1e-7)
+            # the batched and the single-trajectory paths use different tilings: agree to rounding
+            np.testing.assert_allclose(rb["means"][b].cpu().numpy(), r1["means"][0].cpu().numpy(), rtol=1e-9, atol=1e-12)
+    # tighter than the north-star bound: what the fp64 path actually achieves
+    np.testing.assert_allclose(rb["means"].cpu().numpy(), z["means"], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(rb["vars"].cpu().numpy(), z["vars"], rtol=1e-5, atol=1e-12)
+
+
+def test_rollout_objective_only_matches(G, golden):
+    z = golden("g4_rollout_c2.npz")
+    pack = _pack_from(G, z)
+    cost = _cost_from(G, z, -1.0)
+    a = G.rollout(pack, z["x0"], z["U"], cost, want_grad=True)
+    b = G.rollout(pack, z["x0"], z["U"], cost, want_grad=False)
+    np.testing.assert_allclose(b["cost"].cpu().numpy(), a["cost"].cpu().numpy(), rtol=1e-12)
+    np.testing.assert_allclose(b["vars"].cpu().numpy(), a["vars"].cpu().numpy(), rtol=1e-10)
+
+
+def test_rollout_reproducible(G, golden):
+    z = golden("g3_rollout_c1.npz")
+    pack = _pack_from(G, z)
+    cost = _cost_from(G, z, -1.0)
+    a = G.rollout(pack, z["x0"], z["U"], cost)
+    b = G.rollout(pack, z["x0"], z["U"], cost)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k       # fixed-order reductions: bit-identical
+
+
+def test_g5_cost_known_answers(G, golden):
+    from gaussian_process_mpc_amd.rollout import cost_full
+    z = golden("g5_cost.npz")
+    c = G.CostParams(1.0, z["a_Q"], z["a_R"], x_ref=z["a_xref"], u_ref=z["a_uref"])
+    got = cost_full(c, z["a_x"], z["a_sig"], z["a_u"]).item()
+    assert abs(got - z["a_cost_np"]) < 1e-6 and abs(got - z["a_cost_torch"]) < 1e-9
+    c = G.CostParams(1.1, z["a_Q"], z["a_R"], R_delta=z["b_Rd"], x_ref=z["a_xref"], u_ref=z["a_uref"], last_u=z["b_last"][:2])
+    got = cost_full(c, z["b_x"], z["b_sig"], z["b_u"]).item()
+    assert abs(got - z["b_cost_torch"]) < 1e-9
+    H = 5
+    c = G.CostParams(-1.0, 2 * np.eye(1), np.zeros((1, 1)), R_delta=np.zeros((1, 1)))
+    got = cost_full(c, z["c_x"].reshape(H + 1, 1), z["c_sig"].reshape(H + 1, 1, 1), np.zeros((H, 1))).item()
+    assert abs(got - z["c_closed"]) < 1e-7
+
+
+def test_risk_neutral_limit(G, golden):
+    """gamma = 0 (analytic limit, an extension: the reference divides by gamma) is the limit of small gamma."""
+    z = golden("g3_rollout_c1.npz")
+    pack = _pack_from(G, z)
+    r0 = G.rollout(pack, z["x0"], z["U"], _cost_from(G, z, 0.0))
+    r1 = G.rollout(pack, z["x0"], z["U"], _cost_from(G, z, 1e-7))
+    np.testing.assert_allclose(r0["cost"].cpu().numpy(), r1["cost"].cpu().numpy(), rtol=1e-6)
+    np.testing.assert_allclose(r0["grad"].cpu().numpy(), r1["grad"].cpu().numpy(), rtol=1e-4, atol=1e-8)
+
+
+@pytest.mark.parametrize("N,ds,da,H,B", [(96, 2, 1, 4, 3), (200, 3, 2, 5, 5), (333, 4, 1, 3, 9), (130, 1, 1, 6, 2)])
+def test_rollout_vs_oracle_seeded(G, N, ds, da, H, B):
+    """Seeded problems (ragged N, several dims, batch sizes that do not fill a trajectory group)
+    against the CPU oracle, including the gradient (autograd in the oracle)."""
+    from oracle import gpmpc_oracle as O
+    from gaussian_process_mpc_amd.synth import synth_problem
+    pb = synth_problem(7, N, ds, da, H, B)
+    gp = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"])
+    pack = G.GPPack(pb["X"], pb["Y"], gp.Ky_inv.numpy(), pb["lambdas"], pb["sigma_f"])
+    for gamma in (-1.0, 1e-5):
+        r = G.rollout(pack, pb["x0"], pb["U"], G.CostParams(gamma, pb["Q"], pb["R"]))
+        for b in range(B):
+            o = O.objective_and_gradient(gp, H, pb["x0"][b], pb["U"][b], pb["x_ref"], pb["u_ref"], pb["Q"], pb["R"],
+                                         gamma, mode="o2")
+            np.testing.assert_allclose(r["means"][b].cpu().numpy(), o["means"], rtol=MEAN_RTOL, atol=1e-9)
+            np.testing.assert_allclose(r["vars"][b].cpu().numpy(), o["vars"], rtol=VAR_RTOL, atol=1e-12)
+            np.testing.assert_allclose(r["cost"][b].item(), o["cost"], rtol=1e-6)
+            np.testing.assert_allclose(r["grad"][b].cpu().numpy(), o["grad"], rtol=1e-4, atol=1e-7)
+
+
+def test_gradient_finite_difference(G):
+    """Analytic adjoint against central differences of the HIP objective itself."""
+    from oracle import gpmpc_oracle as O
+    from gaussian_process_mpc_amd.synth import synth_problem
+    pb = synth_problem(11, 150, 2, 1, 5, 1)
+    gp = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"])
+    pack = G.GPPack(pb["X"], pb["Y"], gp.Ky_inv.numpy(), pb["lambdas"], pb["sigma_f"])
+    cost = G.CostParams(-1.0, pb["Q"], pb["R"])
+    U = pb["U"][0]
+    g = G.rollout(pack, pb["x0"], U, cost)["grad"][0].cpu().numpy()
+    eps = 1e-5
+    for j in range(U.shape[0]):
+        Up, Um = U.copy(), U.copy()
+        Up[j, 0] += eps
+        Um[j, 0] -= eps
+        fd = (G.rollout(pack, pb["x0"], Up, cost, want_grad=False)["cost"].item() -
+              G.rollout(pack, pb["x0"], Um, cost, want_grad=False)["cost"].item()) / (2 * eps)
+        assert abs(fd - g[j, 0]) < 1e-5 * max(1.0, abs(fd)), (j, fd, g[j, 0])
