@@ -18,7 +18,7 @@ struct MomArgs {
     const double* u; const double* S; int nq;
     double* pp; double* sp; double* part;
     int pps, sps, ntiles, nm, grad;
-    double* out_mean; double* out_var; double* out_cov;
+    double* out_mean; double* out_var; double* out_cov; double* out_l;
     double* dmean_du; double* dmean_dS; double* dvar_du; double* dvar_dS;
     unsigned flags;
 };
@@ -122,7 +122,9 @@ __global__ __launch_bounds__(256) void k_mom_prep(MomArgs A) {
                 for (int l = 0; l < D; ++l) bd = fma(Bm[k * D + l], d[l], bd);
                 qf = fma(bd, d[k], qf);
             }
-            const double p = A.beta[(size_t)a * A.Np + i] * exp(-0.5 * qf);
+            const double ex = exp(-0.5 * qf);
+            const double p = A.beta[(size_t)a * A.Np + i] * ex;
+            if (A.out_l && i < A.N) A.out_l[((size_t)q * ds + a) * A.N + i] = s_tmp[0] * ex;
             v[0] += p;
             int o = 1 + D;
 #pragma unroll
@@ -360,7 +362,7 @@ static int run_mom(const gpmpc_pack* p, MomArgs& A, const MomPlan& r, bool grad,
 }
 
 extern "C" int gpmpc_moment_match(const gpmpc_pack* p, int nq, const double* u, const double* S, unsigned flags,
-                                  double* out_mean, double* out_var, double* out_cov, double* dmean_du,
+                                  double* out_mean, double* out_var, double* out_cov, double* out_l, double* dmean_du,
                                   double* dmean_dS, double* dvar_du, double* dvar_dS, void* workspace,
                                   size_t workspace_bytes, void* stream) {
     if (!p || !u || !S || !out_mean || !out_var || !workspace || nq < 1) return GPMPC_E_ARG;
@@ -378,7 +380,7 @@ extern "C" int gpmpc_moment_match(const gpmpc_pack* p, int nq, const double* u, 
     A.u = u; A.S = S; A.nq = nq;
     A.pp = (double*)(ws + r.off_pp); A.sp = (double*)(ws + r.off_sp); A.part = (double*)(ws + r.off_part);
     A.pps = r.pps; A.sps = r.sps; A.ntiles = r.ntiles; A.nm = r.nm; A.grad = grad ? 1 : 0;
-    A.out_mean = out_mean; A.out_var = out_var; A.out_cov = out_cov;
+    A.out_mean = out_mean; A.out_var = out_var; A.out_cov = out_cov; A.out_l = out_l;
     A.dmean_du = dmean_du; A.dmean_dS = dmean_dS; A.dvar_du = dvar_du; A.dvar_dS = dvar_dS;
     A.flags = flags;
     hipStream_t s = (hipStream_t)stream;

@@ -151,9 +151,17 @@ extern "C" int gpmpc_pack_destroy(gpmpc_pack* p) {
     return GPMPC_OK;
 }
 
-extern "C" int gpmpc_pack_build(gpmpc_pack* p, const double* X_dev, const double* Y_dev, const double* Ky_inv_dev,
-                                const double* lambdas_host, const double* sigma_f_host, void* stream) {
-    if (!p || !X_dev || !Y_dev || !Ky_inv_dev || !lambdas_host || !sigma_f_host) return GPMPC_E_ARG;
+// beta given directly: [N][ds] -> [ds][Np] zero padded
+__global__ void k_pack_copy_beta(const double* __restrict__ Bsrc, int N, int Np, int ds, double* __restrict__ beta) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, a = blockIdx.y;
+    if (i < Np) beta[(size_t)a * Np + i] = i < N ? Bsrc[(size_t)i * ds + a] : 0.0;
+}
+
+static int pack_build_impl(gpmpc_pack* p, const double* X_dev, const double* Y_dev, bool y_is_beta,
+                           const double* Ky_inv_dev, const double* lambdas_host, const double* sigma_f_host,
+                           void* stream) {
+    if (!p || !X_dev || !Y_dev || !lambdas_host || !sigma_f_host) return GPMPC_E_ARG;
+    if (!Ky_inv_dev && !y_is_beta) return GPMPC_E_ARG;
     hipStream_t s = (hipStream_t)stream;
     for (int a = 0; a < p->ds; ++a) {
         p->sf_host[a] = sigma_f_host[a];
@@ -162,16 +170,32 @@ extern "C" int gpmpc_pack_build(gpmpc_pack* p, const double* X_dev, const double
             if (!(p->lam_host[a][k] > 0.0)) return GPMPC_E_ARG;
         }
     }
-    // hyper-parameters are tiny: stage them in pageable host memory owned by the pack (valid until the copy ran)
+    // hyper-parameters are tiny; pageable-host copies are staged synchronously by the runtime
     GPMPC_HIP(hipMemcpyAsync(p->lam, lambdas_host, sizeof(double) * p->ds * p->D, hipMemcpyHostToDevice, s));
     GPMPC_HIP(hipMemcpyAsync(p->sf, sigma_f_host, sizeof(double) * p->ds, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_pack_points, dim3((p->Np + 255) / 256), dim3(256), 0, s, X_dev, p->N, p->Np, p->D, p->X, p->XT);
-    hipLaunchKernelGGL(k_pack_beta, dim3((p->Np + 3) / 4, p->ds), dim3(256), 0, s, Ky_inv_dev, Y_dev, p->N, p->Np, p->ds, p->beta);
-    hipLaunchKernelGGL(k_pack_weights, dim3(p->Np / 32, p->Np / 32, p->ds), dim3(256), 0, s,
-                       Ky_inv_dev, p->beta, p->XT, p->lam, p->sf, p->N, p->Np, p->D, p->M);
+    if (y_is_beta)
+        hipLaunchKernelGGL(k_pack_copy_beta, dim3((p->Np + 255) / 256, p->ds), dim3(256), 0, s, Y_dev, p->N, p->Np, p->ds, p->beta);
+    else
+        hipLaunchKernelGGL(k_pack_beta, dim3((p->Np + 3) / 4, p->ds), dim3(256), 0, s, Ky_inv_dev, Y_dev, p->N, p->Np, p->ds, p->beta);
+    if (Ky_inv_dev)
+        hipLaunchKernelGGL(k_pack_weights, dim3(p->Np / 32, p->Np / 32, p->ds), dim3(256), 0, s,
+                           Ky_inv_dev, p->beta, p->XT, p->lam, p->sf, p->N, p->Np, p->D, p->M);
+    else
+        GPMPC_HIP(hipMemsetAsync(p->M, 0, sizeof(double) * (size_t)p->Np * p->Np * p->ds, s));
     GPMPC_HIP(hipGetLastError());
     p->built = 1;
     return GPMPC_OK;
+}
+
+extern "C" int gpmpc_pack_build(gpmpc_pack* p, const double* X_dev, const double* Y_dev, const double* Ky_inv_dev,
+                                const double* lambdas_host, const double* sigma_f_host, void* stream) {
+    return pack_build_impl(p, X_dev, Y_dev, false, Ky_inv_dev, lambdas_host, sigma_f_host, stream);
+}
+
+extern "C" int gpmpc_pack_build_beta(gpmpc_pack* p, const double* X_dev, const double* beta_dev, const double* Ky_inv_dev,
+                                     const double* lambdas_host, const double* sigma_f_host, void* stream) {
+    return pack_build_impl(p, X_dev, beta_dev, true, Ky_inv_dev, lambdas_host, sigma_f_host, stream);
 }
 
 extern "C" int gpmpc_pack_dims(const gpmpc_pack* p, int* n, int* np, int* ds, int* da) {

@@ -1,2 +1,80 @@
-class Dynamics:  # placeholder
-    pass
+"""Dynamics: host-side mirror of the reference class (src/dynamics.py:8-191) -- a bundle of
+``state_dim`` GPs sharing X_train -- whose rollout runs in the HIP library.
+
+``forward_propagate_torch`` keeps the reference signature and return types (lists of H+1 tensors).
+The batched entry ``rollout`` is the build's extension (the reference handles one trajectory per call).
+"""
+import numpy as np
+import torch
+
+from .gpr import GaussianProcessRegression
+from .rollout import CostParams, GPPack, rollout
+
+
+class Dynamics(object):
+    def __init__(self, state_dim, action_dim, nominal_models=None):
+        self.state_dim = state_dim
+        self.action_dim = action_dim
+        self.nominal_models = nominal_models
+        if nominal_models is None:
+            self.gpr_err = [GaussianProcessRegression(state_dim + action_dim) for _ in range(state_dim)]
+        else:
+            self.gpr_err = [GaussianProcessRegression(state_dim + action_dim, nominal_models[i])
+                            for i in range(state_dim)]
+        self.device = self.gpr_err[0].device
+        self._pack = None
+        self._pack_key = None
+
+    def append_train_data(self, state, action, next_state):
+        """(state, action, next_state) observations, one or many (src/dynamics.py:39-60)."""
+        state, action, next_state = np.asarray(state), np.asarray(action), np.asarray(next_state)
+        if len(state.shape) == 1:
+            x = np.concatenate((state, action))
+            for i in range(self.state_dim):
+                self.gpr_err[i].append_train_data(x, next_state[i])
+        else:
+            if len(action.shape) == 1:
+                action = action[:, None]
+            x = np.concatenate((state, action), axis=1)
+            for i in range(self.state_dim):
+                self.gpr_err[i].append_train_data(x, next_state[:, i])
+
+    # -- device pack -----------------------------------------------------------------------
+    def _key(self):
+        # what forward_propagate_torch reads at call time in the reference (src/dynamics.py:150, :170-173):
+        # Ky_inv, exp(log_lambdas), y_train, sigma_f of every GP, X_train of GP 0
+        return tuple((g.version, g.num_train, tuple(g.get_lambdas().tolist()), g.get_sigma_f()) for g in self.gpr_err)
+
+    def pack(self):
+        """The device-resident constants of the rollout, rebuilt only when data or hypers changed."""
+        key = self._key()
+        if self._pack is None or key != self._pack_key:
+            g0 = self.gpr_err[0]
+            if g0.num_train == 0:
+                raise RuntimeError("no training data")
+            Y = torch.cat([g.y_train.reshape(-1, 1) for g in self.gpr_err], dim=1)
+            Kinv = torch.stack([g.Ky_inv.detach() for g in self.gpr_err])
+            lam = np.stack([g.get_lambdas() for g in self.gpr_err])
+            sf = np.array([g.get_sigma_f() for g in self.gpr_err])
+            self._pack = GPPack(g0.X_train, Y, Kinv, lam, sf, device=self.device)
+            self._pack_key = key
+        return self._pack
+
+    # -- rollout ---------------------------------------------------------------------------
+    def rollout(self, curr_state, actions, cost=None, want_grad=False):
+        """Batched rollout: curr_state (ds,) or (B, ds); actions (H, da) or (B, H, da).
+        Returns the dict of gaussian_process_mpc_amd.rollout.rollout."""
+        if cost is None:     # propagation only: a zero cost keeps the fused tail trivial
+            cost = CostParams(0.0, np.zeros((self.state_dim, self.state_dim)), np.zeros((self.action_dim, self.action_dim)))
+        return rollout(self.pack(), curr_state, actions, cost, want_grad=want_grad, want_traj=True)
+
+    def forward_propagate_torch(self, horizon, curr_state, actions):
+        """Means and (diagonal) covariances of the H-step shooting rollout (src/dynamics.py:126-191).
+        Returns (list of H+1 (ds,) tensors, list of H+1 (ds,ds) tensors) on the device; the tensors are
+        results of the HIP kernels and carry no autograd graph (gradients w.r.t. the actions come from
+        RiskSensitiveMPC.gradient / Dynamics.rollout(want_grad=True))."""
+        U = torch.as_tensor(actions).detach().to(self.device, torch.float64).reshape(horizon, self.action_dim)
+        x0 = torch.as_tensor(curr_state).detach().to(self.device, torch.float64).reshape(self.state_dim)
+        r = self.rollout(x0, U)
+        means, vars_ = r["means"][0], r["vars"][0]
+        return [means[t] for t in range(horizon + 1)], [torch.diag(vars_[t]) for t in range(horizon + 1)]

@@ -1,2 +1,154 @@
-class GaussianProcessRegression:  # placeholder, replaced below
-    pass
+"""GaussianProcessRegression: host-side mirror of the reference class (src/gpr.py:5-332) for the
+parts the rollout path touches: training-data state, hyper-parameter setters/getters,
+``build_Ky_inv_mat`` and the predict API.  Arithmetic runs on the device through the C ABI
+(``gpmpc_build_ky``, ``gpmpc_matvec``, ``gpmpc_predict``); the matrix inverse is
+``torch.linalg.inv`` on the device, as in the reference (src/gpr.py:171).
+
+Out of scope (not on the path): hyper-parameter training
+(``update_hyperparams``, marginal-likelihood gradients) and ``update_Ky_inv_mat``.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from ._lib import check, host_doubles, lib, ptr, require_gpu, stream_ptr
+
+
+class GaussianProcessRegression(object):
+    def __init__(self, x_dim, nominal_model=None):
+        self.device = require_gpu()
+        self.x_dim = x_dim
+        self.num_train = 0
+        self.y_train = None
+        self.X_train = None
+        self.Kf = None
+        self.Ky = None
+        self.Ky_inv = None
+        # log-hypers initialised to 0 => lambda = sigma_f = sigma_n = 1 (src/gpr.py:38-40)
+        self.log_lambdas = torch.zeros(x_dim, device=self.device).type(torch.float64).requires_grad_()
+        self.log_sigma_n = torch.tensor(0.0, device=self.device).type(torch.float64).requires_grad_()
+        self.log_sigma_f = torch.tensor(0.0, device=self.device).type(torch.float64).requires_grad_()
+        self.f_nom = nominal_model
+        self.version = 0            # bumped whenever Ky_inv changes (Dynamics uses it to refresh its pack)
+        self._beta = None
+
+    # -- hyper-parameters: same expressions as the reference setters (src/gpr.py:51-88), including the
+    #    dtype inference of torch.tensor (a Python float / list is float32 before the log).  Like the
+    #    reference they do NOT rebuild the matrices.  The log / exp are evaluated on the HOST and the
+    #    result moved to the device, so the values are those of the CPU reference the oracle is pinned
+    #    to (float32 log differs by an ulp between host and device libm).
+    def _log_param(self, value):
+        return torch.log(torch.tensor(value)).type(torch.float64).to(self.device).requires_grad_()
+
+    def set_lambdas(self, lambdas):
+        self.log_lambdas = self._log_param(lambdas)
+
+    def get_lambdas(self):
+        return torch.exp(self.log_lambdas.detach().cpu()).numpy()
+
+    def set_sigma_f(self, sigma_f):
+        self.log_sigma_f = self._log_param(sigma_f)
+
+    def get_sigma_f(self):
+        return torch.exp(self.log_sigma_f.detach().cpu()).item()
+
+    def set_sigma_n(self, sigma_n):
+        self.log_sigma_n = self._log_param(sigma_n)
+
+    def get_sigma_n(self):
+        return torch.exp(self.log_sigma_n.detach().cpu()).item()
+
+    # -- data
+    def append_train_data(self, x, y):
+        """x: (x_dim,) or (n, x_dim) numpy; y: scalar or (n,) numpy (src/gpr.py:90-122)."""
+        if not np.isscalar(y):
+            num_obs = len(y)
+            y = np.asarray(y)[:, None]
+        else:
+            num_obs = 1
+            y = np.array([y])[:, None]
+        if num_obs == 1:
+            x = np.reshape(x, (1, self.x_dim))
+        x = torch.tensor(np.asarray(x), requires_grad=False).type(torch.float64).to(self.device)
+        y = torch.tensor(y, requires_grad=False).type(torch.float64).to(self.device)
+        if self.num_train == 0:
+            self.X_train, self.y_train = x, y
+        else:
+            self.X_train = torch.cat((self.X_train, x), dim=0)
+            self.y_train = torch.cat((self.y_train, y), dim=0)
+        self.num_train += num_obs
+        self.build_Ky_inv_mat()
+
+    def build_Ky_inv_mat(self):
+        """Kf, Ky, Ky_inv from scratch (src/gpr.py:159-171)."""
+        n = self.num_train
+        X = self.X_train.contiguous()
+        lam, lp = host_doubles(self.get_lambdas())
+        sigma_f = self.get_sigma_f()
+        # src/gpr.py:170: sigma_n**2 (0-dim float64) * torch.eye (float32) is a float32 tensor
+        noise = float((torch.exp(self.log_sigma_n.detach().cpu()) ** 2 * torch.ones(1)).item())
+        self.Kf = torch.empty((n, n), dtype=torch.float64, device=self.device)
+        self.Ky = torch.empty((n, n), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().gpmpc_build_ky(n, self.x_dim, ptr(X), lp, sigma_f, noise, ptr(self.Kf), ptr(self.Ky),
+                                       stream_ptr()), "gpmpc_build_ky")
+        self.Ky_inv = torch.linalg.inv(self.Ky)
+        self._beta = None
+        self.version += 1
+
+    # -- prediction
+    def _targets(self):
+        y = self.y_train
+        if self.f_nom is not None:
+            y = y - self.f_nom(self.X_train)
+        return y.reshape(-1).contiguous()
+
+    def beta(self):
+        """Ky_inv (y - f_nom(X)), cached until the matrices change."""
+        if self._beta is None:
+            out = torch.empty(self.num_train, dtype=torch.float64, device=self.device)
+            # keep every operand referenced until the launch returned: a temporary freed while the
+            # argument list is still being built can be handed out again by the caching allocator
+            kinv, tgt = self.Ky_inv.contiguous(), self._targets()
+            with torch.cuda.device(self.device):
+                check(lib().gpmpc_matvec(self.num_train, self.num_train, ptr(kinv), ptr(tgt), ptr(out), stream_ptr()),
+                      "gpmpc_matvec")
+            self._beta = out
+        return self._beta
+
+    def _predict(self, X_pred, want_mean, want_cov, noise_var):
+        Xp = torch.tensor(np.asarray(X_pred), device=self.device).type(torch.float64)
+        single = Xp.dim() == 1
+        Xp = Xp.reshape(-1, self.x_dim).contiguous()
+        p, n = Xp.shape[0], self.num_train
+        K = torch.empty((p, n), dtype=torch.float64, device=self.device)
+        mean = torch.empty(p, dtype=torch.float64, device=self.device) if want_mean else None
+        cov = torch.empty((p, p), dtype=torch.float64, device=self.device) if want_cov else None
+        _, lp = host_doubles(self.get_lambdas())
+        nb = lib().gpmpc_predict_workspace_bytes(n, self.x_dim, p)
+        ws = torch.empty(nb, dtype=torch.uint8, device=self.device)
+        Xt = self.X_train.contiguous()
+        beta = self.beta() if want_mean else None
+        kinv = self.Ky_inv.contiguous() if want_cov else None
+        with torch.cuda.device(self.device):
+            check(lib().gpmpc_predict(n, self.x_dim, ptr(Xt), lp, self.get_sigma_f(), ptr(beta), ptr(kinv), noise_var, p, ptr(Xp),
+                                      ptr(K), ptr(mean), ptr(cov), ctypes.c_void_p(ws.data_ptr()), nb, stream_ptr()),
+                  "gpmpc_predict")
+        return K, mean, cov, Xp, single
+
+    def compute_pred_train_covariance(self, X_pred):
+        """K(X*, X): (p, N) tensor, or (N,) for a single 1-D test point (src/gpr.py:253-283)."""
+        K, _, _, _, single = self._predict(X_pred, False, False, 0.0)
+        return K[0] if single else K
+
+    def predict_latent_vars(self, X_pred, covar=False, targets=False):
+        """Posterior mean (p,1) and optionally covariance (p,p), numpy (src/gpr.py:285-332)."""
+        noise = self.get_sigma_n() ** 2 if (covar and targets) else 0.0
+        _, mean, cov, Xp, _ = self._predict(X_pred, True, covar, noise)
+        f = mean.reshape(-1, 1)
+        if self.f_nom is not None:
+            f = f + self.f_nom(Xp).reshape(-1, 1)
+        if not covar:
+            return f.cpu().detach().numpy(), None
+        return f.cpu().detach().numpy(), cov.cpu().detach().numpy()

@@ -1,2 +1,183 @@
-class RiskSensitiveMPC:  # placeholder
-    pass
+"""RiskSensitiveMPC: host-side mirror of the reference class (src/mpc.py:7-330).
+
+The cyipopt problem-object surface is kept (``objective`` / ``gradient`` / ``constraints`` /
+``jacobian``), as are the constructor, the setters and ``get_optimal_trajectory``.  Differences, all
+forced by moving the rollout into one fused HIP call:
+
+* ``objective(x)`` evaluates cost AND gradient in the same device pass and caches both keyed on the
+  bytes of ``x`` (the reference keeps an autograd graph and back-propagates lazily, src/mpc.py:225-255,
+  and its ``gradient`` ignores ``x``); Ipopt's buffer is copied, never aliased (src/mpc.py:217).
+* ``objective_batch`` / ``evaluate_batch`` evaluate many candidate action sequences at once (the
+  trajectory-sharded batch the multi-GPU path consumes) -- an extension, the reference has no batch API.
+* ``gamma == 0`` is accepted and means the analytic risk-neutral limit.
+"""
+import numpy as np
+import torch
+
+from .dynamics import Dynamics
+from .rollout import CostParams, cost_full, rollout
+
+try:                                    # the solver binding is optional (not installed in the build image)
+    import cyipopt                      # noqa: F401
+    HAVE_CYIPOPT = True
+except Exception:                       # pragma: no cover
+    cyipopt = None
+    HAVE_CYIPOPT = False
+
+
+class RiskSensitiveMPC:
+    def __init__(self, gamma, horizon, state_dim, input_dim, Q, R, R_delta=None):
+        self.gamma = gamma
+        self.horizon = horizon
+        self.state_dim = state_dim
+        self.input_dim = input_dim
+        self.Q = Q
+        self.R = R
+        self.R_delta = R_delta
+        self.dynamics = Dynamics(self.state_dim, self.input_dim, nominal_models=None)
+        self.device = self.dynamics.device
+        self.Q_tor = torch.tensor(np.asarray(self.Q), device=self.device).type(torch.float64)
+        self.R_tor = torch.tensor(np.asarray(self.R), device=self.device).type(torch.float64)
+        self.R_delta_tor = (torch.tensor(np.asarray(self.R_delta), device=self.device).type(torch.float64)
+                            if self.R_delta is not None else None)
+        self.x_ref = torch.zeros(self.state_dim, device=self.device)
+        self.u_ref = torch.zeros(self.input_dim, device=self.device)
+        self.curr_cost = None
+        self.curr_grad = None
+        self.curr_state = None
+        self.backward_taken = False
+        self.curr_u = None
+        self._cache_key = None
+        self.last_traj = np.random.standard_normal(size=(self.horizon * self.input_dim,))   # src/mpc.py:62
+        self.ub = [1e16 for _ in range(self.input_dim)]
+        self.lb = [-1e16 for _ in range(self.input_dim)]
+        self.train_empty = True
+        self.solver_used = None
+
+    # -- setters (src/mpc.py:72-116)
+    def set_ub(self, ub):
+        assert len(ub) == self.input_dim
+        self.ub = ub
+
+    def set_lb(self, lb):
+        assert len(lb) == self.input_dim
+        self.lb = lb
+
+    def set_xref(self, x_ref):
+        assert len(x_ref) == self.state_dim
+        self.x_ref = torch.tensor(np.asarray(x_ref), device=self.device).type(torch.float64)
+        self._cache_key = None
+
+    def set_uref(self, u_ref):
+        assert len(u_ref) == self.input_dim
+        self.u_ref = torch.tensor(np.asarray(u_ref), device=self.device).type(torch.float64)
+        self._cache_key = None
+
+    # -- cost
+    def _cost_params(self, x_ref=None, u_ref=None):
+        xr = self.x_ref if x_ref is None else x_ref
+        ur = self.u_ref if u_ref is None else u_ref
+        to_np = lambda t: t.detach().cpu().numpy().astype(np.float64) if isinstance(t, torch.Tensor) else np.asarray(t, dtype=np.float64)  # noqa: E731
+        last_u = np.asarray(self.last_traj, dtype=np.float64)[0:self.input_dim] if self.R_delta is not None else None
+        return CostParams(self.gamma, self.Q, self.R, R_delta=self.R_delta, x_ref=to_np(xr), u_ref=to_np(ur),
+                          last_u=last_u)
+
+    def cost(self, x, u, sig, x_ref, u_ref):
+        """numpy risk-sensitive cost, no input-rate term (src/mpc.py:118-154); host arithmetic in the
+        reference too."""
+        Q, R, g = np.asarray(self.Q, dtype=float), np.asarray(self.R, dtype=float), self.gamma
+        Qi = np.linalg.inv(Q)
+        eye = np.identity(self.state_dim)
+        total = 0
+        for i in range(self.horizon + 1):
+            e = x[i, :] - x_ref
+            total += np.log(np.linalg.det(eye + g * Q @ sig[i, :, :])) / g
+            total += e.T @ np.linalg.inv(Qi + g * sig[i, :, :]) @ e
+        for j in range(self.horizon):
+            d = u[j, :] - u_ref
+            total += d.T @ R @ d
+        return total
+
+    def cost_torch(self, x, u, sig, x_ref, u_ref):
+        """Risk-sensitive cost incl. the input-rate term for FULL covariance matrices
+        (src/mpc.py:156-200) on the device; x / sig may be lists of tensors or stacked tensors."""
+        xs = torch.stack([t.reshape(-1) for t in x]) if isinstance(x, (list, tuple)) else torch.as_tensor(x)
+        ss = torch.stack(list(sig)) if isinstance(sig, (list, tuple)) else torch.as_tensor(sig)
+        ss = ss.reshape(xs.shape[0], self.state_dim, self.state_dim)
+        out = cost_full(self._cost_params(x_ref, u_ref), xs.reshape(-1, self.state_dim), ss,
+                        torch.as_tensor(u).reshape(-1, self.input_dim))
+        return out[0]
+
+    # -- cyipopt problem object (src/mpc.py:202-267)
+    def _evaluate(self, x):
+        x = np.array(x, dtype=np.float64, copy=True).reshape(-1)
+        key = (x.tobytes(), None if self.curr_state is None else self.curr_state.detach().cpu().numpy().tobytes())
+        if key != self._cache_key:
+            r = rollout(self.dynamics.pack(), self.curr_state, x.reshape(self.horizon, self.input_dim),
+                        self._cost_params(), want_grad=True, want_traj=False)
+            self.curr_cost = float(r["cost"][0].item())
+            self.curr_grad = r["grad"][0].cpu().numpy()
+            self.curr_u = x.reshape(self.horizon, self.input_dim)
+            self.backward_taken = True
+            self._cache_key = key
+        return self.curr_cost, self.curr_grad
+
+    def objective(self, x):
+        return self._evaluate(x)[0]
+
+    def gradient(self, x):
+        """d cost / d U, shape (horizon, input_dim) like the reference (cyipopt flattens it)."""
+        return self._evaluate(x)[1]
+
+    def constraints(self, x):
+        return 0
+
+    def jacobian(self, x):
+        return np.zeros(x.shape)
+
+    # -- batched evaluation (extension)
+    def evaluate_batch(self, U, curr_state=None, want_grad=True):
+        """U: (B, H, da) candidates from one (ds,) or per-candidate (B, ds) start state.
+        Returns the rollout dict (device tensors: cost (B,), grad (B,H,da), means, vars)."""
+        cs = self.curr_state if curr_state is None else curr_state
+        return rollout(self.dynamics.pack(), cs, U, self._cost_params(), want_grad=want_grad, want_traj=True)
+
+    def objective_batch(self, U, curr_state=None):
+        r = self.evaluate_batch(U, curr_state)
+        return r["cost"].cpu().numpy(), r["grad"].cpu().numpy()
+
+    # -- solve (src/mpc.py:269-330)
+    def get_optimal_trajectory(self, curr_state):
+        if self.train_empty:
+            if self.dynamics.gpr_err[0].num_train > 0:
+                self.train_empty = False
+            else:
+                return np.zeros((self.horizon, self.input_dim))
+        self.curr_state = torch.tensor(np.asarray(curr_state), device=self.device).type(torch.float64)
+        self._cache_key = None
+        x0 = np.zeros(shape=len(self.last_traj))          # warm start deliberately off, src/mpc.py:292-293
+        lb, ub = self.horizon * list(self.lb), self.horizon * list(self.ub)
+        if HAVE_CYIPOPT:
+            nlp = cyipopt.Problem(n=len(x0), m=0, problem_obj=self, lb=lb, ub=ub, cl=[0], cu=[0])
+            for k, v in (("mu_strategy", "adaptive"), ("accept_every_trial_step", "yes"), ("max_iter", 300),
+                         ("tol", 1e-4), ("acceptable_tol", 1e-4), ("constr_viol_tol", 1e-4), ("compl_inf_tol", 1e-4),
+                         ("dual_inf_tol", 1e-4), ("mu_target", 1e-4), ("acceptable_iter", 3), ("sb", "yes"),
+                         ("print_level", 0)):
+                nlp.add_option(k, v)
+            x, _ = nlp.solve(x0)
+            self.solver_used = "ipopt"
+        else:
+            x = self._solve_without_ipopt(x0, lb, ub)
+        self.last_traj = x
+        return np.reshape(x, (self.horizon, self.input_dim))
+
+    def _solve_without_ipopt(self, x0, lb, ub):
+        """Stand-in driver when cyipopt is not installed: bounded L-BFGS (scipy) on the same
+        objective/gradient callbacks.  Not Ipopt: optimiser results are not parity-pinned."""
+        from scipy.optimize import minimize
+        big = 1e15
+        bounds = [(None if l <= -big else l, None if u >= big else u) for l, u in zip(lb, ub)]
+        res = minimize(lambda v: self.objective(v), x0, jac=lambda v: np.asarray(self.gradient(v)).reshape(-1),
+                       method="L-BFGS-B", bounds=bounds, options={"maxiter": 300, "ftol": 1e-10, "gtol": 1e-4})
+        self.solver_used = "scipy-lbfgsb"
+        return res.x

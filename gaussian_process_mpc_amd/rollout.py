@@ -52,7 +52,9 @@ class GPPack:
     GaussianProcessRegression hold, src/dynamics.py:33-37, src/gpr.py:24-36) folded into
     the per-data-update constants of the rollout (beta, weight matrices)."""
 
-    def __init__(self, X, Y, Ky_inv, lambdas, sigma_f, device=None):
+    def __init__(self, X, Y, Ky_inv, lambdas, sigma_f, device=None, y_is_beta=False):
+        """Y: (N, ds) targets, or the beta vectors themselves when ``y_is_beta`` (then Ky_inv may be
+        None: only means and cross-covariances are meaningful)."""
         self.device = device if device is not None else require_gpu()
         self.X = _dev(X, self.device)
         Y = _dev(Y, self.device)
@@ -60,7 +62,8 @@ class GPPack:
         self.N, self.D = self.X.shape
         self.ds = self.Y.shape[1]
         self.da = self.D - self.ds
-        Ky_inv = _dev(Ky_inv, self.device).reshape(self.ds, self.N, self.N)
+        if Ky_inv is not None:
+            Ky_inv = _dev(Ky_inv, self.device).reshape(self.ds, self.N, self.N)
         self.lambdas = np.ascontiguousarray(np.asarray(lambdas, dtype=np.float64).reshape(self.ds, self.D))
         self.sigma_f = np.ascontiguousarray(np.asarray(sigma_f, dtype=np.float64).reshape(self.ds))
         h = ctypes.c_void_p()
@@ -69,8 +72,8 @@ class GPPack:
         _, lp = host_doubles(self.lambdas)
         _, sp = host_doubles(self.sigma_f)
         with torch.cuda.device(self.device):
-            check(lib().gpmpc_pack_build(self._h, ptr(self.X), ptr(self.Y), ptr(Ky_inv), lp, sp, stream_ptr()),
-                  "gpmpc_pack_build")
+            build = lib().gpmpc_pack_build_beta if y_is_beta else lib().gpmpc_pack_build
+            check(build(self._h, ptr(self.X), ptr(self.Y), ptr(Ky_inv), lp, sp, stream_ptr()), "gpmpc_pack_build")
         n, npad, ds, da = (ctypes.c_int() for _ in range(4))
         lib().gpmpc_pack_dims(self._h, ctypes.byref(n), ctypes.byref(npad), ctypes.byref(ds), ctypes.byref(da))
         self.Np = npad.value
@@ -141,7 +144,7 @@ def rollout(pack, x0, U, cost, want_grad=True, want_traj=True):
     return out
 
 
-def moment_match(pack, u, S, want_cov=False, want_grad=False, bug_compatible=False):
+def moment_match(pack, u, S, want_cov=False, want_grad=False, bug_compatible=False, want_l=False):
     """Exact moment matching of all ds GPs for nq Gaussian inputs N(u, S) with full S
     (C ABI ``gpmpc_moment_match``).  u: (nq, D) or (D,); S: (nq, D, D) or (D, D)."""
     dev = pack.device
@@ -154,13 +157,15 @@ def moment_match(pack, u, S, want_cov=False, want_grad=False, bug_compatible=Fal
     out = {"mean": e(nq, ds), "var": e(nq, ds)}
     if want_cov:
         out["cov"] = e(nq, ds, ds)
+    if want_l:
+        out["l"] = e(nq, ds, pack.N)
     if want_grad:
         out.update(dmean_du=e(nq, ds, D), dmean_dS=e(nq, ds, D, D), dvar_du=e(nq, ds, D), dvar_dS=e(nq, ds, D, D))
     nbytes = lib().gpmpc_moment_match_workspace_bytes(pack.handle, nq)
     ws = pack.workspace(nbytes)
     with torch.cuda.device(dev):
         check(lib().gpmpc_moment_match(pack.handle, nq, ptr(u), ptr(S), flags, ptr(out["mean"]), ptr(out["var"]),
-                                       ptr(out.get("cov")), ptr(out.get("dmean_du")), ptr(out.get("dmean_dS")),
+                                       ptr(out.get("cov")), ptr(out.get("l")), ptr(out.get("dmean_du")), ptr(out.get("dmean_dS")),
                                        ptr(out.get("dvar_du")), ptr(out.get("dvar_dS")),
                                        ctypes.c_void_p(ws.data_ptr()), ws.numel(), stream_ptr()), "gpmpc_moment_match")
     return out

@@ -80,6 +80,14 @@ int gpmpc_pack_build(gpmpc_pack* pack, const double* X_dev, const double* Y_dev,
                      const double* Ky_inv_dev, const double* lambdas_host,
                      const double* sigma_f_host, void* stream);
 
+/* Same, with beta given instead of the targets: beta dev [N][ds] (column a = beta_a), as the callers of
+ * variance_prop_torch / covariance_prop_torch hold it (src/tools/uncertainty_prop.py:341, :402).
+ * Ky_inv may be NULL: the weight matrices are then zero and only means and cross-covariances
+ * (which need beta alone) are meaningful. */
+int gpmpc_pack_build_beta(gpmpc_pack* pack, const double* X_dev, const double* beta_dev,
+                          const double* Ky_inv_dev, const double* lambdas_host,
+                          const double* sigma_f_host, void* stream);
+
 /* Inspection for tests / bindings.  gpmpc_pack_export copies into caller buffers (either may be NULL):
  * beta_out dev [ds][n_padded] (beta_a = Ky_inv_a y_a, zero padded); weights_out dev
  * [ds][n_padded][n_padded], element (i <= j) of M_a at [a][j][i], zero elsewhere. */
@@ -96,13 +104,15 @@ int gpmpc_pack_export(const gpmpc_pack* pack, double* beta_out, double* weights_
  *   out_cov  dev [nq][ds][ds] or NULL: full predictive covariance (diagonal = out_var,
  *            off-diagonal = cross-covariances; flag GPMPC_COV_BUG_COMPAT selects the
  *            reference's transposed cross term)
+ *   out_l    dev [nq][ds][N] or NULL: the vector l of mean_prop_torch's second return value
+ *            (l_i = c_m exp(-1/2 v_i^T B v_i), src/tools/uncertainty_prop.py:335-336)
  *   with GPMPC_WANT_GRAD (all four non-NULL):
  *     dmean_du dev [nq][ds][D], dmean_dS dev [nq][ds][D][D] (symmetrised),
  *     dvar_du  dev [nq][ds][D], dvar_dS  dev [nq][ds][D][D] (symmetrised)
  * ------------------------------------------------------------------------- */
 size_t gpmpc_moment_match_workspace_bytes(const gpmpc_pack* pack, int nq);
 int gpmpc_moment_match(const gpmpc_pack* pack, int nq, const double* u_dev, const double* S_dev,
-                       unsigned flags, double* out_mean, double* out_var, double* out_cov,
+                       unsigned flags, double* out_mean, double* out_var, double* out_cov, double* out_l,
                        double* dmean_du, double* dmean_dS, double* dvar_du, double* dvar_dS,
                        void* workspace, size_t workspace_bytes, void* stream);
 

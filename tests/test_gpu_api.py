@@ -1,0 +1,199 @@
+"""GPU tests of the host-side mirror of the reference's Python surface (GaussianProcessRegression,
+Dynamics, RiskSensitiveMPC, *_prop_torch): same calls as the reference's own tests, checked against
+the golden vectors the reference produced."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    import gaussian_process_mpc_amd as g
+    g.require_gpu()
+    return g
+
+
+def test_gpr_matrices_and_predict(G, golden):
+    z = golden("g6_gp.npz")
+    gp = G.GaussianProcessRegression(3)
+    gp.set_lambdas(z["lam"])
+    gp.set_sigma_f(1.4)            # Python floats: float32 log, as in the fixture
+    gp.set_sigma_n(0.2)
+    assert gp.get_sigma_f() != 1.4 and abs(gp.get_sigma_f() - 1.4) < 1e-7
+    gp.append_train_data(z["X"][:40], z["y"][:40])
+    gp.append_train_data(z["X"][40:63], z["y"][40:63])
+    gp.append_train_data(z["X"][63], float(z["y"][63]))          # single observation path
+    assert gp.num_train == 64 and gp.X_train.shape == (64, 3) and gp.y_train.shape == (64, 1)
+    np.testing.assert_allclose(gp.Kf.cpu().numpy(), z["Kf"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(gp.Ky.cpu().numpy(), z["Ky"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(gp.Ky_inv.cpu().numpy(), z["Ky_inv"], rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(gp.compute_pred_train_covariance(z["Xp"]).cpu().numpy(), z["Ks"], rtol=1e-12)
+    np.testing.assert_allclose(gp.compute_pred_train_covariance(z["Xp"][0]).cpu().numpy(), z["Ks_single"], rtol=1e-12)
+    f, none = gp.predict_latent_vars(z["Xp"])
+    assert none is None and f.shape == (7, 1)
+    np.testing.assert_allclose(f, z["f"], rtol=1e-9)
+    f, cov = gp.predict_latent_vars(z["Xp"], covar=True)
+    np.testing.assert_allclose(cov, z["cov_f"], rtol=1e-7, atol=1e-9)
+    _, covy = gp.predict_latent_vars(z["Xp"], covar=True, targets=True)
+    np.testing.assert_allclose(covy, z["cov_y"], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(covy - cov, gp.get_sigma_n() ** 2 * np.eye(7), atol=1e-12)   # test_gpr.py identity
+
+
+def test_gpr_closed_form_kernel(G):
+    """Closed-form check in the style of the reference's test_gpr.py:563-609: two points, known kernel."""
+    gp = G.GaussianProcessRegression(2)
+    gp.set_lambdas(np.array([2.0, 0.5]))
+    gp.set_sigma_n(np.array(0.3))
+    gp.set_sigma_f(np.array(1.5))
+    X = np.array([[0.0, 0.0], [1.0, 2.0]])
+    gp.append_train_data(X, np.array([1.0, -1.0]))
+    k01 = 1.5 ** 2 * np.exp(-0.5 * (1.0 / 2.0 + 4.0 / 0.5))
+    Ky = np.array([[2.25, k01], [k01, 2.25]]) + float(np.float32(0.3 ** 2)) * np.eye(2)
+    np.testing.assert_allclose(gp.Ky.cpu().numpy(), Ky, rtol=1e-14)
+    np.testing.assert_allclose(gp.Ky_inv.cpu().numpy(), np.linalg.inv(Ky), rtol=1e-12)
+    with_nom = G.GaussianProcessRegression(2, nominal_model=lambda x: x[:, 0:1] * 2.0)
+    with_nom.set_lambdas(np.array([2.0, 0.5]))
+    with_nom.append_train_data(X, np.array([1.0, -1.0]))
+    f, _ = with_nom.predict_latent_vars(X)
+    Kf = with_nom.Kf.cpu().numpy()
+    resid = np.array([1.0, -1.0]) - 2.0 * X[:, 0]
+    np.testing.assert_allclose(f[:, 0], Kf @ with_nom.Ky_inv.cpu().numpy() @ resid + 2.0 * X[:, 0], rtol=1e-12)
+
+
+@pytest.mark.parametrize("tag", ["a", "c"])
+def test_prop_torch_mirrors(G, golden, tag):
+    """mean_prop_torch / variance_prop_torch / covariance_prop_torch called like the reference's tests
+    (test_uncertainty_prop.py:182-385) with the reference's tolerances (and tighter)."""
+    z = golden("g1_single_step.npz")
+    T = lambda a: torch.tensor(a)      # noqa: E731
+    sf1, sf2 = z[f"{tag}_sf"]
+    X, y, u, S = T(z[f"{tag}_X"]), T(z[f"{tag}_y"]), T(z["u"]), T(z["S"])
+    m1, d1 = G.mean_prop_torch(T(z[f"{tag}_Kinv1"]), T(z["lam1"]), u, S, X, y, sf1)
+    m2, d2 = G.mean_prop_torch(T(z[f"{tag}_Kinv2"]), T(z["lam2"]), u, S, X, y, sf2)
+    assert abs(m1.item() - z[f"{tag}_mu"][0]) < 1e-7 * abs(z[f"{tag}_mu"][0])
+    assert np.linalg.norm(d1["beta"].cpu().numpy() - z[f"{tag}_beta1"]) < 1e-5
+    assert np.linalg.norm(d1["l"].cpu().numpy() - z[f"{tag}_l1"]) < 1e-5
+    np.testing.assert_allclose(d1["l"].cpu().numpy(), z[f"{tag}_l1"], rtol=1e-10, atol=1e-300)
+    v1 = G.variance_prop_torch(T(z[f"{tag}_Kinv1"]), T(z["lam1"]), u, S, X, m1, d1["beta"], sf1)
+    assert abs(v1.item() - z[f"{tag}_var"][0]) < 1e-5 * abs(z[f"{tag}_var"][0])
+    cv = G.covariance_prop_torch(T(z["lam1"]), T(z["lam2"]), u, S, X, m1, m2, d1["beta"], d2["beta"], sf1, sf2)
+    assert abs(cv.item() - z[f"{tag}_cov"]) < 1e-5 * abs(z[f"{tag}_cov"])
+
+
+def _mpc_from(G, z, gamma):
+    N, ds, da, H = (int(v) for v in z["dims"])
+    mpc = G.RiskSensitiveMPC(gamma, H, ds, da, z["Q"], z["R"], z["R_delta"] if "R_delta" in z else None)
+    for a in range(ds):
+        g = mpc.dynamics.gpr_err[a]
+        g.set_lambdas(z["lambdas"][a])
+        g.set_sigma_n(float(z["sigma_n"][a]))
+        g.set_sigma_f(1.0)
+    mpc.dynamics.append_train_data(z["X"][:, :ds], z["X"][:, ds:], z["Y"])
+    if "x_ref" in z:
+        mpc.set_xref(z["x_ref"])
+    if "u_ref" in z:
+        mpc.set_uref(z["u_ref"])
+    if "last_traj" in z:
+        mpc.last_traj = z["last_traj"].copy()
+    return mpc
+
+
+@pytest.mark.parametrize("name", ["g3_rollout_c1.npz", "g4_rollout_c2.npz"])
+def test_dynamics_and_mpc_callbacks(G, golden, name):
+    """End to end through the mirrored classes, Ky_inv rebuilt on the device (explicit inverse as
+    src/gpr.py:171): forward_propagate_torch, objective, gradient vs the reference's outputs."""
+    z = golden(name)
+    N, ds, da, H = (int(v) for v in z["dims"])
+    mpc = _mpc_from(G, z, float(z["gammas"][0]))
+    for a in range(ds):
+        scale = np.abs(z["Ky_inv"][a]).max()
+        np.testing.assert_allclose(mpc.dynamics.gpr_err[a].Ky_inv.cpu().numpy(), z["Ky_inv"][a], rtol=0, atol=1e-6 * scale)
+    for b in range(z["x0"].shape[0]):
+        x0 = torch.tensor(z["x0"][b]).type(torch.float64)
+        means, covs = mpc.dynamics.forward_propagate_torch(H, x0, torch.tensor(z["U"][b]))
+        assert len(means) == H + 1 and len(covs) == H + 1 and covs[1].shape == (ds, ds)
+        np.testing.assert_allclose(torch.stack(means).cpu().numpy(), z["means"][b], rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(torch.stack([torch.diag(c) for c in covs]).cpu().numpy(), z["vars"][b], rtol=1e-4)
+        assert float((covs[3] - torch.diag(torch.diag(covs[3]))).abs().max()) == 0.0
+        mpc.curr_state = x0.to(mpc.device)
+        for gi, gamma in enumerate(z["gammas"]):
+            mpc.gamma = float(gamma)
+            mpc._cache_key = None
+            x = z["U"][b].reshape(-1).copy()
+            c = mpc.objective(x)
+            g = mpc.gradient(x)
+            assert isinstance(c, float) and g.shape == (H, da)
+            np.testing.assert_allclose(c, z["costs"][gi, b], rtol=1e-6)
+            np.testing.assert_allclose(g, z["grads"][gi, b], rtol=1e-4, atol=1e-7)
+    assert mpc.constraints(x) == 0 and np.all(mpc.jacobian(x) == 0) and mpc.jacobian(x).shape == x.shape
+
+
+def test_objective_cache_semantics(G, golden):
+    z = golden("g3_rollout_c1.npz")
+    mpc = _mpc_from(G, z, -1.0)
+    mpc.curr_state = torch.tensor(z["x0"][0]).to(mpc.device)
+    x = z["U"][0].reshape(-1).copy()
+    c0 = mpc.objective(x)
+    x_alias = x                       # Ipopt reuses its buffer: mutate after the call
+    g0 = mpc.gradient(x).copy()
+    x_alias[0] += 0.25
+    c1 = mpc.objective(x_alias)       # new bytes -> new evaluation (the buffer is copied, never aliased)
+    assert c1 != c0
+    g1 = mpc.gradient(x_alias)
+    assert not np.allclose(g0, g1)
+    x_alias[0] -= 0.25
+    assert mpc.objective(x_alias) == c0
+
+
+def test_cost_methods_known_answers(G, golden):
+    z = golden("g5_cost.npz")
+    mpc = G.RiskSensitiveMPC(1, 1, 2, 2, z["a_Q"], z["a_R"])
+    c_np = mpc.cost(z["a_x"], z["a_u"], z["a_sig"], z["a_xref"], z["a_uref"])
+    assert abs(c_np - z["a_cost_np"]) < 1e-9
+    T = lambda a: torch.tensor(a, device=mpc.device).type(torch.float64)   # noqa: E731
+    c_t = mpc.cost_torch(T(z["a_x"]), T(z["a_u"]), T(z["a_sig"]), T(z["a_xref"]), T(z["a_uref"]))
+    assert abs(c_np - c_t.item()) < 1e-5                                    # test_mpc.py:104
+    mpc = G.RiskSensitiveMPC(1.1, 2, 2, 2, z["a_Q"], z["a_R"], z["b_Rd"])
+    mpc.last_traj = [0 for _ in range(4)]
+    c_t = mpc.cost_torch([T(r) for r in z["b_x"]], T(z["b_u"]), [T(s) for s in z["b_sig"]], T(z["a_xref"]), T(z["a_uref"]))
+    assert abs(c_t.item() - z["b_cost_torch"]) < 1e-6                       # test_mpc.py:243
+    H = 5
+    mpc = G.RiskSensitiveMPC(-1, H, 1, 1, 2 * np.identity(1), np.array([[0]]), np.array([[0]]))
+    c_t = mpc.cost_torch(T(z["c_x"]).reshape(H + 1, 1), torch.zeros((H, 1), device=mpc.device).type(torch.float64),
+                         T(z["c_sig"]).reshape(H + 1, 1, 1), torch.zeros(1, device=mpc.device), torch.zeros(1, device=mpc.device))
+    assert abs(z["c_closed"] - c_t.item()) < 1e-7                           # test_mpc.py:274
+
+
+def test_get_optimal_trajectory(G, golden):
+    """Shape contract of the reference's smoke test (test_mpc.py:106-139) plus: the solve lowers the cost."""
+    z = golden("g3_rollout_c1.npz")
+    N, ds, da, H = (int(v) for v in z["dims"])
+    empty = G.RiskSensitiveMPC(-1.0, H, ds, da, z["Q"], z["R"])
+    assert np.all(empty.get_optimal_trajectory(np.zeros(ds)) == 0)          # no data: zeros (mpc.py:285-289)
+    mpc = _mpc_from(G, z, -1.0)
+    mpc.set_lb([-1.0] * da)
+    mpc.set_ub([1.0] * da)
+    traj = mpc.get_optimal_trajectory(z["x0"][0])
+    assert traj.shape == (H, da) and np.all(np.abs(traj) <= 1.0 + 1e-9)
+    assert mpc.objective(traj.reshape(-1)) <= mpc.objective(np.zeros(H * da)) + 1e-12
+    assert mpc.solver_used in ("ipopt", "scipy-lbfgsb")
+
+
+def test_batch_matches_loop_and_pack_refresh(G, golden):
+    z = golden("g4_rollout_c2.npz")
+    mpc = _mpc_from(G, z, -1.0)
+    cost, grad = mpc.objective_batch(z["U"], z["x0"])
+    for b in range(2):
+        mpc.curr_state = torch.tensor(z["x0"][b]).to(mpc.device)
+        np.testing.assert_allclose(mpc.objective(z["U"][b].reshape(-1)), cost[b], rtol=1e-9)
+        np.testing.assert_allclose(mpc.gradient(z["U"][b].reshape(-1)), grad[b], rtol=1e-6, atol=1e-10)
+    # appending one observation (Simulator.run does this every step, simulator.py:55) refreshes the pack
+    p0 = mpc.dynamics.pack()
+    assert mpc.dynamics.pack() is p0
+    mpc.dynamics.append_train_data(np.zeros(3), np.zeros(1), np.array([0.1, -0.1, 0.05]))
+    p1 = mpc.dynamics.pack()
+    assert p1 is not p0 and p1.N == p0.N + 1
+    c2, _ = mpc.objective_batch(z["U"], z["x0"])
+    assert np.all(np.isfinite(c2)) and not np.allclose(c2, cost, rtol=1e-12)

@@ -1,0 +1,174 @@
+"""CPU-only tests: the C-ABI library loads and exports everything include/gpmpc.h declares, host
+logic (marshalling, sharding, collectives over gloo, synthetic generator), and the rule that the
+product never routes through the oracle or a CPU fallback.  No GPU compute calls."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "gaussian_process_mpc_amd")
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as ge
+    ge.build()
+    import gaussian_process_mpc_amd as g
+    return g
+
+
+def test_library_exports_every_declared_symbol(built):
+    from gaussian_process_mpc_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "gpmpc.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(gpmpc_[a-z_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    h = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert getattr(h, name) is not None
+    assert b"gfx950" in built.lib().gpmpc_version()
+
+
+def test_cost_params_struct_layout_matches_header(built, tmp_path):
+    from gaussian_process_mpc_amd._lib import CostParamsC
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "gpmpc.h"\nint main(){printf("%zu %zu %zu %zu",'
+                   'sizeof(gpmpc_cost_params), offsetof(gpmpc_cost_params,R), offsetof(gpmpc_cost_params,x_ref),'
+                   'offsetof(gpmpc_cost_params,has_R_delta));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    size, off_R, off_xref, off_flag = (int(v) for v in subprocess.check_output([str(exe)]).split())
+    assert size == ctypes.sizeof(CostParamsC)
+    assert off_R == CostParamsC.R.offset and off_xref == CostParamsC.x_ref.offset
+    assert off_flag == CostParamsC.has_R_delta.offset
+
+
+def test_no_gpu_means_loud_failure_not_fallback(built):
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    g = built
+    with pytest.raises(g.GpmpcError):
+        g.require_gpu()
+    with pytest.raises(g.GpmpcError):
+        g.GaussianProcessRegression(3)
+    with pytest.raises(g.GpmpcError):
+        g.RiskSensitiveMPC(-1.0, 5, 2, 1, np.eye(2), np.eye(1))
+    with pytest.raises(g.GpmpcError):
+        g.GPPack(np.zeros((4, 3)), np.zeros((4, 2)), np.zeros((2, 4, 4)), np.ones((2, 3)), np.ones(2))
+
+
+def test_abi_argument_validation_without_device(built):
+    lib = built.lib()
+    h = ctypes.c_void_p()
+    assert lib.gpmpc_pack_create(ctypes.byref(h), 0, 2, 1) == -1          # n_train < 1
+    assert lib.gpmpc_pack_create(ctypes.byref(h), 10, 9, 1) == -1         # state_dim > GPMPC_MAX_DS
+    assert lib.gpmpc_pack_create(ctypes.byref(h), 10, 4, 5) == -1         # D > GPMPC_MAX_D
+    assert lib.gpmpc_pack_create(None, 10, 2, 1) == -1
+    assert lib.gpmpc_pack_destroy(None) == 0
+    assert lib.gpmpc_rollout(None, 1, 1, None, None, None, 0, None, None, None, None, None, 0, None) == -1
+    assert lib.gpmpc_moment_match(None, 1, None, None, 0, *([None] * 8), None, 0, None) == -1
+    assert lib.gpmpc_rollout_workspace_bytes(None, 1, 1, 0) == 0
+    assert lib.gpmpc_predict_workspace_bytes(100, 3, 7) >= 2 * 7 * 100 * 8
+    assert lib.gpmpc_matvec(0, 1, None, None, None, None) == -1
+    assert lib.gpmpc_device_count() >= 0
+
+
+def test_product_never_touches_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import oracle/."""
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b", re.M)
+    for dirpath, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not pat.search(txt), f
+                assert "oracle" not in txt.lower() or f == "__init__.py" or "the oracle is pinned" in txt or \
+                    all("import" not in ln for ln in txt.splitlines() if "oracle" in ln.lower()), f
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    hits = [m.start() for m in pat.finditer(bench)]
+    assert len(hits) == 1
+    start = bench.index("def cpu_baseline")
+    end = bench.index("def main")
+    assert start < hits[0] < end
+
+
+def test_cost_params_marshalling(built):
+    g = built
+    Q = np.array([[2.0, 0.5], [0.25, 3.0]])
+    R = np.array([[1.5]])
+    c = g.CostParams(-1.0, Q, R, R_delta=np.array([[0.7]]), x_ref=[0.1, 0.2], u_ref=[0.3], last_u=np.array([9.0, 8.0]))
+    assert c.c.gamma == -1.0 and c.c.has_R_delta == 1
+    assert list(c.c.Q[:4]) == [2.0, 0.5, 0.25, 3.0] and c.c.R[0] == 1.5 and c.c.R_delta[0] == 0.7
+    assert list(c.c.x_ref[:2]) == [0.1, 0.2] and c.c.u_ref[0] == 0.3 and c.c.last_u[0] == 9.0
+    assert g.CostParams(0.0, np.eye(3), np.eye(2)).c.has_R_delta == 0
+    with pytest.raises(ValueError):
+        g.CostParams(1.0, np.eye(9), np.eye(1))
+
+
+def test_synth_problem_is_seeded_and_shaped(built):
+    from gaussian_process_mpc_amd.synth import CONFIGS, synth_problem
+    a = synth_problem(3, 64, 4, 1, 5, 3)
+    b = synth_problem(3, 64, 4, 1, 5, 3)
+    for k in ("X", "Y", "lambdas", "x0", "U"):
+        assert np.array_equal(a[k], b[k])
+    assert a["X"].shape == (64, 5) and a["Y"].shape == (64, 4) and a["U"].shape == (3, 5, 1)
+    assert not np.array_equal(a["X"], synth_problem(4, 64, 4, 1, 5, 3)["X"])
+    assert CONFIGS["C3"] == dict(N=2048, ds=4, da=1, H=20, B=256, gamma=-1.0)
+    assert CONFIGS["C4"]["N"] == 4096 and CONFIGS["C2"]["B"] == 1
+
+
+def test_shard_ranges_partition(built):
+    from gaussian_process_mpc_amd.parallel import shard_range, shard_sizes
+    for n, w in ((256, 8), (1024, 8), (10, 3), (5, 8), (1, 2)):
+        covered = []
+        for r in range(w):
+            lo, hi = shard_range(n, w, r)
+            covered += list(range(lo, hi))
+        assert covered == list(range(n))
+        assert sum(shard_sizes(n, w)) == n and max(shard_sizes(n, w)) - min(shard_sizes(n, w)) <= 1
+
+
+def _gloo_worker(rank, world, port, ragged, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from gaussian_process_mpc_amd.parallel import gather_results, shard_range, shard_sizes, broadcast_kinv
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 7 if ragged else 8
+    H, da = 3, 2
+    cost_all = torch.arange(n, dtype=torch.float64) * 1.5
+    grad_all = torch.arange(n * H * da, dtype=torch.float64).reshape(n, H, da)
+    lo, hi = shard_range(n, world, rank)
+    sizes = shard_sizes(n, world)
+    c, g = gather_results(cost_all[lo:hi].clone(), grad_all[lo:hi].clone(), dist, sizes if ragged else None)
+    c2, g2 = gather_results(cost_all[lo:hi].clone(), None, dist, sizes if ragged else None)
+    kinv = torch.full((2, 4, 4), float(rank + 1), dtype=torch.float64)
+    broadcast_kinv(kinv, dist, src=0)
+    ok = bool(torch.equal(c, cost_all) and torch.equal(g, grad_all) and torch.equal(c2, cost_all) and g2 is None
+              and torch.all(kinv == 1.0))
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_gather_results_gloo_world2(ragged):
+    """The N>1 path of bench.py / the sharded batch API: fused all_gather of [cost | grad] and the
+    pack broadcast, world_size 2 over gloo on CPU."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 400) + (50 if ragged else 0)
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, ragged, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
