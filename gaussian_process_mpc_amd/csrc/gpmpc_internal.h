@@ -14,7 +14,8 @@
 #define GPMPC_ACTION_VAR ((double)1e-3f)
 
 struct gpmpc_tiling {
-    int waves;      // waves per workgroup: the i-tile is 64*waves rows
+    int it;         // rows per tile
+    int waves;      // waves per workgroup of the v1 kernel: it / 64
     int jt;         // j-extent of a tile (multiple of 64)
     int ntiles;
     int* tiles_dev; // [ntiles][3] = {i0, j0, j1}
@@ -31,7 +32,7 @@ struct gpmpc_pack {
     double* sf;     // dev [ds]
     double lam_host[GPMPC_MAX_DS][GPMPC_MAX_D];
     double sf_host[GPMPC_MAX_DS];
-    gpmpc_tiling tilings[2];   // [0] large workgroups for big batches, [1] one-wave tiles for small ones
+    gpmpc_tiling tilings[3];   // [0] 256x256 (big batches), [1] 64x64 one-wave tiles (small batches), [2] 128x256 (v2, RI=2)
 };
 
 // Number of pair-kernel output moments per (trajectory, GP, tile).
@@ -52,6 +53,9 @@ struct PairArgs {
 // Implemented in pair_d*.hip (one translation unit per D so the build parallelises).
 int gpmpc_launch_pair(int D, bool diag, bool grad, int tb, int waves, const PairArgs& a, hipStream_t s);
 template <int D> int gpmpc_launch_pair_D(bool diag, bool grad, int tb, int waves, const PairArgs& a, hipStream_t s);
+// v2 (MFMA moment accumulation; diagonal S, forward+gradient, D <= 7); variant: 0 = TB4/RI2, 1 = TB2/RI4, 2 = TB1/RI4
+int gpmpc_launch_pair_mfma(int D, int variant, const PairArgs& a, hipStream_t s);
+template <int D> int gpmpc_launch_pair_mfma_D(int variant, const PairArgs& a, hipStream_t s);
 
 void gpmpc_set_error(const char* what, hipError_t e);
 #define GPMPC_HIP(call)                                              \

@@ -10,7 +10,7 @@
 // with S1 = sum p_i v_i, S2 = sum p_i v_i v_i^T and Z* the pair-kernel moments in h-space.
 #include "gpmpc_internal.h"
 
-int gpmpc_timed_pair(int D, bool diag, bool grad, int tb, int waves, const PairArgs& a, hipStream_t s);
+int gpmpc_timed_pair(int D, bool diag, bool grad, int tb, int waves, const PairArgs& a, hipStream_t s, int mfma_variant);
 
 struct MomArgs {
     const double* XT; const double* beta; const double* lam; const double* sf;
@@ -343,7 +343,7 @@ static int run_mom(const gpmpc_pack* p, MomArgs& A, const MomPlan& r, bool grad,
     PairArgs P;
     P.M = p->M; P.XT = p->XT; P.pp = A.pp; P.part = A.part; P.tiles = p->tilings[r.tiling].tiles_dev;
     P.Np = p->Np; P.ds = p->ds; P.B = A.nq; P.ntiles = r.ntiles; P.pps = r.pps; P.nm = r.nm;
-    int rc = gpmpc_timed_pair(D, false, grad, r.tb, r.waves, P, s);
+    int rc = gpmpc_timed_pair(D, false, grad, r.tb, r.waves, P, s, -1);
     if (rc != GPMPC_OK) return rc;
     hipLaunchKernelGGL(k_mom_finish<D>, dim3(A.nq), dim3(64), 0, s, A);
     if (A.out_cov && p->ds > 1) {

@@ -94,8 +94,8 @@ __global__ void k_build_ky(const double* __restrict__ X, int n, int D, const dou
     Ky[(size_t)i * n + j] = kf + (i == j ? noise_var : 0.0);
 }
 
-static void build_tiling(int Np, int waves, int jt, gpmpc_tiling* t, int** host_out) {
-    const int it = 64 * waves;
+static void build_tiling(int Np, int it, int jt, gpmpc_tiling* t, int** host_out) {
+    const int waves = it / 64 > 0 ? it / 64 : 1;
     int cap = ((Np + it - 1) / it) * ((Np + jt - 1) / jt);
     int* h = (int*)malloc(sizeof(int) * 3 * (size_t)cap);
     int n = 0;
@@ -105,7 +105,7 @@ static void build_tiling(int Np, int waves, int jt, gpmpc_tiling* t, int** host_
             if (j1 <= i0) continue;                          // wholly below the diagonal
             h[3 * n] = i0; h[3 * n + 1] = j0; h[3 * n + 2] = j1; ++n;
         }
-    t->waves = waves; t->jt = jt; t->ntiles = n;
+    t->it = it; t->waves = waves; t->jt = jt; t->ntiles = n;
     *host_out = h;
 }
 
@@ -124,8 +124,8 @@ extern "C" int gpmpc_pack_create(gpmpc_pack** out, int n_train, int state_dim, i
     if (e == hipSuccess) e = hipMalloc(&p->M, sizeof(double) * Np * Np * state_dim);
     if (e == hipSuccess) e = hipMalloc(&p->lam, sizeof(double) * state_dim * D);
     if (e == hipSuccess) e = hipMalloc(&p->sf, sizeof(double) * state_dim);
-    const int cfg[2][2] = {{4, 256}, {1, 64}};
-    for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+    const int cfg[3][2] = {{256, 256}, {64, 64}, {128, 256}};
+    for (int k = 0; k < 3 && e == hipSuccess; ++k) {
         int* h = nullptr;
         build_tiling(p->Np, cfg[k][0], cfg[k][1], &p->tilings[k], &h);
         e = hipMalloc(&p->tilings[k].tiles_dev, sizeof(int) * 3 * (size_t)p->tilings[k].ntiles);
@@ -146,7 +146,7 @@ extern "C" int gpmpc_pack_destroy(gpmpc_pack* p) {
     if (p->M) (void)hipFree(p->M);
     if (p->lam) (void)hipFree(p->lam);
     if (p->sf) (void)hipFree(p->sf);
-    for (int k = 0; k < 2; ++k) if (p->tilings[k].tiles_dev) (void)hipFree(p->tilings[k].tiles_dev);
+    for (int k = 0; k < 3; ++k) if (p->tilings[k].tiles_dev) (void)hipFree(p->tilings[k].tiles_dev);
     free(p);
     return GPMPC_OK;
 }

@@ -21,6 +21,7 @@
 // per-tile partials are written (not atomically added) so results are bit-reproducible.
 #pragma once
 #include "gpmpc_internal.h"
+#include "fast_exp.h"
 
 template <int D, bool DIAG, bool GRAD>
 struct PairTraits {
@@ -51,6 +52,8 @@ __global__ __launch_bounds__(256) void gpmpc_pair_kernel(PairArgs A) {
     constexpr int DP = TR::DP, NM = TR::NM;
     __shared__ __attribute__((aligned(16))) double s_hj[TB * 64 * DP];
     __shared__ double s_red[4 * TB * NM];
+    __shared__ double s_tab[64];
+    if (threadIdx.x < 64) s_tab[threadIdx.x] = gpmpc_exp2_table[threadIdx.x];   // visible after the first barrier below
 
     const int bg = blockIdx.x, tile = blockIdx.y, a = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(256) void gpmpc_pair_kernel(PairArgs A) {
                     double s = sq[0];
 #pragma unroll
                     for (int k = 1; k < D; ++k) s += sq[k];
-                    const double P = mij[q] * exp(-s);
+                    const double P = mij[q] * gpmpc_exp_neg(s, s_tab);
                     acc[tb][0] += P;
                     if (GRAD) {
                         if (DIAG) {

@@ -17,6 +17,7 @@
 //   T = c Z0,  dT/du_k = -4 sqrt(A_k/8) c Z1_k,  dT/ds_k = A_k (c Z2_kk - T/2)
 //   var = sf^2 - T - mu^2     (no clamp; src/tools/uncertainty_prop.py:399)
 #include "gpmpc_internal.h"
+#include <cstdlib>
 
 struct RollArgs {
     // pack
@@ -363,20 +364,26 @@ extern "C" int gpmpc_pair_kernel_time(double* total_ms, long long* launches, int
     return GPMPC_OK;
 }
 
-int gpmpc_timed_pair(int D, bool diag, bool grad, int tb, int waves, const PairArgs& a, hipStream_t s) {
-    if (!g_timing) return gpmpc_launch_pair(D, diag, grad, tb, waves, a, s);
+// mfma_variant >= 0 selects the v2 kernel (pair_kernel_mfma.h), otherwise v1 (pair_kernel.h)
+static int launch_any_pair(int D, bool diag, bool grad, int tb, int waves, int mfma_variant, const PairArgs& a, hipStream_t s) {
+    if (mfma_variant >= 0) return gpmpc_launch_pair_mfma(D, mfma_variant, a, s);
+    return gpmpc_launch_pair(D, diag, grad, tb, waves, a, s);
+}
+
+int gpmpc_timed_pair(int D, bool diag, bool grad, int tb, int waves, const PairArgs& a, hipStream_t s, int mfma_variant) {
+    if (!g_timing) return launch_any_pair(D, diag, grad, tb, waves, mfma_variant, a, s);
     if (g_npending == 4096) drain_events();
     EvPair ev;
     GPMPC_HIP(hipEventCreate(&ev.a));
     GPMPC_HIP(hipEventCreate(&ev.b));
     GPMPC_HIP(hipEventRecord(ev.a, s));
-    int rc = gpmpc_launch_pair(D, diag, grad, tb, waves, a, s);
+    int rc = launch_any_pair(D, diag, grad, tb, waves, mfma_variant, a, s);
     GPMPC_HIP(hipEventRecord(ev.b, s));
     g_pending[g_npending++] = ev;
     return rc;
 }
 
-struct RollPlan { int tiling, tb, waves, ntiles, nm, pps, sps; size_t off_pp, off_sp, off_part, off_jac, off_means, off_vars, total; };
+struct RollPlan { int tiling, tb, waves, ntiles, nm, pps, sps, mfma; size_t off_pp, off_sp, off_part, off_jac, off_means, off_vars, total; };
 
 static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag, RollPlan* r) {
     const int D = p->D;
@@ -385,6 +392,18 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     const long groups = (B + r->tb - 1) / r->tb;
     // big workgroups once they already oversubscribe the 256 CUs; one-wave tiles otherwise
     r->tiling = (groups * p->tilings[0].ntiles * p->ds >= 1024) ? 0 : 1;
+    // v2 (MFMA moment accumulation) for the rollout hot path when the grid is large enough for 256-thread tiles.
+    // GPMPC_PAIR_VARIANT: -1 forces v1, 0/1/2 force a v2 shape (bench / A-B use).
+    r->mfma = -1;
+    if (diag && grad && D <= 7 && r->tiling == 0) r->mfma = B >= 4 ? 0 : 2;
+    if (const char* ev = getenv("GPMPC_PAIR_VARIANT")) {
+        const int v = atoi(ev);
+        if (v < 0) r->mfma = -1;
+        else if (diag && grad && D <= 7 && v <= 2) r->mfma = v;
+    }
+    if (r->mfma == 0) { r->tb = 4; r->tiling = 2; }
+    if (r->mfma == 1) { r->tb = 2; r->tiling = 0; }
+    if (r->mfma == 2) { r->tb = 1; r->tiling = 0; }
     r->waves = p->tilings[r->tiling].waves;
     r->ntiles = p->tilings[r->tiling].ntiles;
     r->nm = gpmpc_num_moments(D, diag, grad);
@@ -453,7 +472,7 @@ extern "C" int gpmpc_rollout(const gpmpc_pack* p, int B, int H, const double* x0
             case 8: launch_head<8>(A, t, s); break;
             default: return GPMPC_E_ARG;
         }
-        int rc = gpmpc_timed_pair(p->D, true, grad, r.tb, r.waves, P, s);
+        int rc = gpmpc_timed_pair(p->D, true, grad, r.tb, r.waves, P, s, r.mfma);
         if (rc != GPMPC_OK) return rc;
     }
     const size_t lds = sizeof(double) * ((size_t)GPMPC_TAIL_WORKERS * p->ds * 2 * p->ds + (size_t)(H + 1) * (1 + 2 * p->ds));
