@@ -48,6 +48,7 @@ struct PairArgs {
     double* part;         // [B][ds][ntiles][nm]
     const int* tiles;
     int Np, ds, B, ntiles, pps, nm;
+    int ns2;              // leading dims whose second moments are needed (diag+grad path); D = all
 };
 
 // Implemented in pair_d*.hip (one translation unit per D so the build parallelises).

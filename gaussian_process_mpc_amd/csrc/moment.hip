@@ -342,7 +342,7 @@ static int run_mom(const gpmpc_pack* p, MomArgs& A, const MomPlan& r, bool grad,
     hipLaunchKernelGGL(k_mom_prep<D>, dim3(A.nq), dim3(256), 0, s, A);
     PairArgs P;
     P.M = p->M; P.XT = p->XT; P.pp = A.pp; P.part = A.part; P.tiles = p->tilings[r.tiling].tiles_dev;
-    P.Np = p->Np; P.ds = p->ds; P.B = A.nq; P.ntiles = r.ntiles; P.pps = r.pps; P.nm = r.nm;
+    P.Np = p->Np; P.ds = p->ds; P.B = A.nq; P.ntiles = r.ntiles; P.pps = r.pps; P.nm = r.nm; P.ns2 = D;
     int rc = gpmpc_timed_pair(D, false, grad, r.tb, r.waves, P, s, -1);
     if (rc != GPMPC_OK) return rc;
     hipLaunchKernelGGL(k_mom_finish<D>, dim3(A.nq), dim3(64), 0, s, A);

@@ -22,6 +22,7 @@
 #pragma once
 #include "gpmpc_internal.h"
 #include "fast_exp.h"
+#include <cstdlib>
 
 template <int D, bool DIAG, bool GRAD>
 struct PairTraits {
@@ -46,14 +47,17 @@ __device__ __forceinline__ void pair_transform(const double* __restrict__ prm, c
     }
 }
 
-template <int D, bool DIAG, bool GRAD, int TB>
-__global__ __launch_bounds__(256) void gpmpc_pair_kernel(PairArgs A) {
+// WPS: minimum waves per SIMD the register allocator must leave room for (launch bound); 0 = compiler's choice.
+// NS2: second moments are accumulated for the first NS2 dimensions only (DIAG && GRAD).  In the rollout the
+//      input variance of the action dimensions is a constant, so dT/ds_k is not needed for k >= state_dim.
+template <int D, bool DIAG, bool GRAD, int TB, int WPS = 0, int NS2 = D>
+__global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void gpmpc_pair_kernel(PairArgs A) {
     using TR = PairTraits<D, DIAG, GRAD>;
     constexpr int DP = TR::DP, NM = TR::NM;
     __shared__ __attribute__((aligned(16))) double s_hj[TB * 64 * DP];
     __shared__ double s_red[4 * TB * NM];
-    __shared__ double s_tab[64];
-    if (threadIdx.x < 64) s_tab[threadIdx.x] = gpmpc_exp2_table[threadIdx.x];   // visible after the first barrier below
+    __shared__ double s_tab[GPMPC_EXP_N];
+    gpmpc_exp_table_to_lds(s_tab);                        // visible after the first barrier below
 
     const int bg = blockIdx.x, tile = blockIdx.y, a = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(256) void gpmpc_pair_kernel(PairArgs A) {
 #pragma unroll
                             for (int k = 0; k < D; ++k) {
                                 acc[tb][1 + k] = fma(P, m[k], acc[tb][1 + k]);
-                                acc[tb][1 + D + k] = fma(P, sq[k], acc[tb][1 + D + k]);
+                                if (k < NS2) acc[tb][1 + D + k] = fma(P, sq[k], acc[tb][1 + D + k]);
                             }
                         } else {
                             int o = 1 + D;
@@ -177,10 +181,10 @@ __global__ __launch_bounds__(256) void gpmpc_pair_kernel(PairArgs A) {
     }
 }
 
-template <int D, bool DIAG, bool GRAD, int TB>
+template <int D, bool DIAG, bool GRAD, int TB, int WPS = 0, int NS2 = D>
 static int launch_pair_one(int waves, const PairArgs& a, hipStream_t s) {
     dim3 grid((a.B + TB - 1) / TB, a.ntiles, a.ds), block(64 * waves);
-    hipLaunchKernelGGL((gpmpc_pair_kernel<D, DIAG, GRAD, TB>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((gpmpc_pair_kernel<D, DIAG, GRAD, TB, WPS, NS2>), grid, block, 0, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { gpmpc_set_error("pair kernel launch", e); return GPMPC_E_LAUNCH; }
     return GPMPC_OK;
@@ -189,6 +193,10 @@ static int launch_pair_one(int waves, const PairArgs& a, hipStream_t s) {
 template <int D>
 int gpmpc_launch_pair_D(bool diag, bool grad, int tb, int waves, const PairArgs& a, hipStream_t s) {
     if (a.nm != gpmpc_num_moments(D, diag, grad)) return GPMPC_E_ARG;
+    if (diag && grad && tb == 2 && a.ns2 < D) {   // the rollout hot path: skip the action dims' second moments
+        if (D >= 2 && a.ns2 == D - 1) return launch_pair_one<D, true, true, 2, 0, (D >= 2 ? D - 1 : D)>(waves, a, s);
+        if (D >= 3 && a.ns2 == D - 2) return launch_pair_one<D, true, true, 2, 0, (D >= 3 ? D - 2 : D)>(waves, a, s);
+    }
 #define GPMPC_PAIR_CASE(DG, GR)                                                  \
     if (diag == DG && grad == GR) {                                              \
         if (tb == 1) return launch_pair_one<D, DG, GR, 1>(waves, a, s);          \

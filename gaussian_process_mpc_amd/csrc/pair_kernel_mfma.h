@@ -27,7 +27,7 @@ struct PairMfmaTraits {
     static constexpr int GW = (2 * D + 2) & ~1;
     // two G staging buffers; the epilogue reuses the area as 4 x (16 x 16) scratch tiles
     static constexpr int GAREA = (2 * TB * 64 * GW > 4 * 256) ? 2 * TB * 64 * GW : 4 * 256;
-    static constexpr size_t LDS_BYTES = sizeof(double) * (GAREA + 4 * TB * (1 + 2 * D) + 64);
+    static constexpr size_t LDS_BYTES = sizeof(double) * (GAREA + 4 * TB * (1 + 2 * D) + GPMPC_EXP_N);
 };
 
 template <int D, int TB, int RI>
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void gpmpc_pair_kernel_mfma(PairArgs A) {
     constexpr int NM = 1 + 2 * D;
     constexpr int GW = PairMfmaTraits<D, TB>::GW;        // doubles per G row (even, >= 2D+1)
     constexpr int GBUF = TB * 64 * GW;                   // one staging buffer
-    // all LDS in ONE dynamic array: [2][TB][64][GW] G | [4][TB][NM] reduction | [64] exp table
+    // all LDS in ONE dynamic array: [2][TB][64][GW] G | [4][TB][NM] reduction | [GPMPC_EXP_N] exp table
     extern __shared__ __attribute__((aligned(16))) double s_dyn[];
     double* const s_G0 = s_dyn;
     double* const s_red = s_dyn + PairMfmaTraits<D, TB>::GAREA;
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void gpmpc_pair_kernel_mfma(PairArgs A) {
     const int Np = A.Np;
     const int ibase = i0 + w * 16 * RI;                  // first row of this wave
     const bool active = ibase < Np;                      // wave-uniform; Np is a multiple of 64 and 16*RI divides 64, so a wave's rows are all inside or all outside
-    if (tid < 64) s_tab[tid] = gpmpc_exp2_table[tid];
+    gpmpc_exp_table_to_lds(s_tab);
 
     const double* __restrict__ prm[TB];
 #pragma unroll

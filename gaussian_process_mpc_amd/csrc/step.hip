@@ -387,7 +387,8 @@ struct RollPlan { int tiling, tb, waves, ntiles, nm, pps, sps, mfma; size_t off_
 
 static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag, RollPlan* r) {
     const int D = p->D;
-    r->tb = B >= 4 ? 4 : 1;
+    r->tb = B >= 2 ? 2 : 1;      // TB=2 (3-4 waves/SIMD) beats TB=4 (2 waves/SIMD) by 13 % on C3: profiles/r01
+    if (const char* ev = getenv("GPMPC_PAIR_TB")) { const int v = atoi(ev); if (v == 1 || v == 2 || v == 4) r->tb = v; }
     if (!diag && grad && r->tb > 2) r->tb = 2;
     const long groups = (B + r->tb - 1) / r->tb;
     // big workgroups once they already oversubscribe the 256 CUs; one-wave tiles otherwise
@@ -395,7 +396,8 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     // v2 (MFMA moment accumulation) for the rollout hot path when the grid is large enough for 256-thread tiles.
     // GPMPC_PAIR_VARIANT: -1 forces v1, 0/1/2 force a v2 shape (bench / A-B use).
     r->mfma = -1;
-    if (diag && grad && D <= 7 && r->tiling == 0) r->mfma = B >= 4 ? 0 : 2;
+    // (measured slower than v1/TB=2 because fp64 MFMA and fp64 VALU share the same issue capacity on MI355X:
+    //  profiles/r01/ubench_mfma_f64_overlap.txt -- so it is opt-in only)
     if (const char* ev = getenv("GPMPC_PAIR_VARIANT")) {
         const int v = atoi(ev);
         if (v < 0) r->mfma = -1;
@@ -458,7 +460,7 @@ extern "C" int gpmpc_rollout(const gpmpc_pack* p, int B, int H, const double* x0
 
     PairArgs P;
     P.M = p->M; P.XT = p->XT; P.pp = A.pp; P.part = A.part; P.tiles = p->tilings[r.tiling].tiles_dev;
-    P.Np = p->Np; P.ds = p->ds; P.B = B; P.ntiles = r.ntiles; P.pps = r.pps; P.nm = r.nm;
+    P.Np = p->Np; P.ds = p->ds; P.B = B; P.ntiles = r.ntiles; P.pps = r.pps; P.nm = r.nm; P.ns2 = p->ds;
 
     for (int t = 1; t <= H; ++t) {
         switch (p->D) {
