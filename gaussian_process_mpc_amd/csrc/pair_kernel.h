@@ -59,7 +59,20 @@ __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void gpmpc_pair_kernel(Pa
     __shared__ double s_tab[GPMPC_EXP_N];
     gpmpc_exp_table_to_lds(s_tab);                        // visible after the first barrier below
 
-    const int bg = blockIdx.x, tile = blockIdx.y, a = blockIdx.z;
+    // XCD-aware decode of the flat grid.  Workgroups are dealt round-robin over the 8 XCDs (each with its own
+    // L2), so the XCD label L % 8 picks the (tile, GP) unit and all trajectory groups of a unit run back to
+    // back on ONE XCD: every M tile is pulled through a single L2 instead of all eight.  Bijective for any
+    // unit count (the ragged tail falls back to the plain order).  Placement only affects speed.
+    int bg, tile, a;
+    {
+        const int groups = (A.B + TB - 1) / TB, units = A.ntiles * A.ds;
+        const int L = blockIdx.x, full = (units >> 3) << 3;
+        int u;
+        if (L < full * groups) { const int q = L >> 3; u = (q / groups) * 8 + (L & 7); bg = q % groups; }
+        else { const int Lt = L - full * groups; u = full + Lt / groups; bg = Lt % groups; }
+        a = u / A.ntiles;
+        tile = u - a * A.ntiles;
+    }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int i0 = A.tiles[tile * 3 + 0], j0 = A.tiles[tile * 3 + 1], j1 = A.tiles[tile * 3 + 2];
     const int Np = A.Np;
@@ -183,7 +196,7 @@ __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void gpmpc_pair_kernel(Pa
 
 template <int D, bool DIAG, bool GRAD, int TB, int WPS = 0, int NS2 = D>
 static int launch_pair_one(int waves, const PairArgs& a, hipStream_t s) {
-    dim3 grid((a.B + TB - 1) / TB, a.ntiles, a.ds), block(64 * waves);
+    dim3 grid(((a.B + TB - 1) / TB) * a.ntiles * a.ds), block(64 * waves);
     hipLaunchKernelGGL((gpmpc_pair_kernel<D, DIAG, GRAD, TB, WPS, NS2>), grid, block, 0, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { gpmpc_set_error("pair kernel launch", e); return GPMPC_E_LAUNCH; }
