@@ -1,0 +1,124 @@
+"""GPU parity at BASELINE.json's full sizes.
+
+A full reference/oracle run with gradients at these sizes needs 46 GiB (C3) or cannot run at all (C4), so the
+full-size checks are (i) the CPU oracle on a bounded slice of the same workload (first horizon step(s), a few
+trajectories) and (ii) size-independent properties of the whole H-step batch: agreement of the batched and the
+single-trajectory code paths (different tilings), bit reproducibility, invariance under a permutation of the
+training set, and a directional finite-difference check of the analytic gradient.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    import gaussian_process_mpc_amd as g
+    g.require_gpu()
+    return g
+
+
+@pytest.fixture(scope="module")
+def c3(G):
+    from oracle import gpmpc_oracle as O
+    from gaussian_process_mpc_amd.synth import CONFIGS, synth_problem
+    cfg = CONFIGS["C3"]
+    pb = synth_problem(3, cfg["N"], cfg["ds"], cfg["da"], cfg["H"], 8)
+    torch.set_num_threads(16)
+    gp = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"])     # CPU inverse, as the reference
+    pack = G.GPPack(pb["X"], pb["Y"], gp.Ky_inv.numpy(), pb["lambdas"], pb["sigma_f"])
+    return pb, gp, pack
+
+
+def test_c3_first_steps_against_oracle(G, c3):
+    """N=2048, ds=4, da=1: two horizon steps, objective AND gradient, against the O(N^2) oracle with autograd."""
+    from oracle import gpmpc_oracle as O
+    pb, gp, pack = c3
+    H = 2
+    cost = G.CostParams(-1.0, pb["Q"], pb["R"])
+    r = G.rollout(pack, pb["x0"][:2], pb["U"][:2, :H], cost)
+    for b in range(2):
+        o = O.objective_and_gradient(gp, H, pb["x0"][b], pb["U"][b, :H], pb["x_ref"], pb["u_ref"], pb["Q"], pb["R"],
+                                     -1.0, mode="o2")
+        np.testing.assert_allclose(r["means"][b].cpu().numpy(), o["means"], rtol=1e-5, atol=1e-9)     # north star
+        np.testing.assert_allclose(r["vars"][b].cpu().numpy(), o["vars"], rtol=1e-4, atol=1e-12)      # north star
+        np.testing.assert_allclose(r["cost"][b].item(), o["cost"], rtol=1e-6)
+        np.testing.assert_allclose(r["grad"][b].cpu().numpy(), o["grad"], rtol=1e-4, atol=1e-7)
+
+
+def test_c3_single_step_moment_match_against_faithful_oracle(G, c3):
+    """One (u, diagonal S) query at N=2048 against the FAITHFUL oracle (N^3 trace, reference op order)."""
+    from oracle import gpmpc_oracle as O
+    pb, gp, pack = c3
+    T = lambda a: torch.as_tensor(a, dtype=torch.float64)     # noqa: E731
+    u = np.concatenate((pb["x0"][0], pb["U"][0, 0]))
+    S = np.diag(np.concatenate((np.full(4, 1e-3), [O.ACTION_NOISE_VAR])))
+    r = G.moment_match(pack, u, S)
+    for a in range(4):
+        m, beta, _ = O.mean_prop(gp.Ky_inv[a], gp.lambdas[a], T(u), T(S), gp.X, gp.Y[:, a])
+        v = O.variance_prop(gp.Ky_inv[a], gp.lambdas[a], T(u), T(S), gp.X, m, beta, mode="faithful")
+        np.testing.assert_allclose(r["mean"][0, a].item(), m.item(), rtol=1e-5)
+        np.testing.assert_allclose(r["var"][0, a].item(), v.item(), rtol=1e-4)
+
+
+def test_c3_full_horizon_properties(G, c3):
+    pb, gp, pack = c3
+    cost = G.CostParams(-1.0, pb["Q"], pb["R"])
+    rb = G.rollout(pack, pb["x0"], pb["U"], cost)                     # B = 8, H = 20: 256-row tiles
+    assert all(torch.isfinite(v).all() for v in rb.values())
+    assert float(rb["vars"].min()) > 0
+    r1 = G.rollout(pack, pb["x0"][3], pb["U"][3], cost)               # B = 1: one-wave 64x64 tiles
+    np.testing.assert_allclose(r1["means"][0].cpu().numpy(), rb["means"][3].cpu().numpy(), rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(r1["vars"][0].cpu().numpy(), rb["vars"][3].cpu().numpy(), rtol=1e-6)
+    np.testing.assert_allclose(r1["cost"][0].item(), rb["cost"][3].item(), rtol=1e-8)
+    np.testing.assert_allclose(r1["grad"][0].cpu().numpy(), rb["grad"][3].cpu().numpy(), rtol=1e-5, atol=1e-9)
+    again = G.rollout(pack, pb["x0"], pb["U"], cost)
+    for k in rb:
+        assert torch.equal(rb[k], again[k]), k                        # fixed-order reductions
+    # directional derivative by central differences of the HIP objective
+    rng = np.random.default_rng(5)
+    d = rng.normal(size=pb["U"][0].shape)
+    d /= np.linalg.norm(d)
+    # the cost carries ~1e-7 of cancellation noise at N = 2048 (sum_|terms| / |var| ~ 1e9): a wide stencil
+    eps = 2e-3
+    cp = G.rollout(pack, pb["x0"][0], pb["U"][0] + eps * d, cost, want_grad=False)["cost"].item()
+    cm = G.rollout(pack, pb["x0"][0], pb["U"][0] - eps * d, cost, want_grad=False)["cost"].item()
+    g0 = float((rb["grad"][0].cpu().numpy() * d).sum())
+    assert abs((cp - cm) / (2 * eps) - g0) < 2e-4 * max(1.0, abs(g0)), ((cp - cm) / (2 * eps), g0)
+
+
+def test_c3_training_set_permutation_invariance(G, c3):
+    """The result is a sum over pairs: re-ordering the training points only re-orders the tiles."""
+    pb, gp, pack = c3
+    rng = np.random.default_rng(9)
+    perm = rng.permutation(pb["N"])
+    Ki = gp.Ky_inv.numpy()[:, perm][:, :, perm]
+    pack_p = G.GPPack(pb["X"][perm], pb["Y"][perm], Ki, pb["lambdas"], pb["sigma_f"])
+    cost = G.CostParams(-1.0, pb["Q"], pb["R"])
+    a = G.rollout(pack, pb["x0"][:2], pb["U"][:2, :5], cost)
+    b = G.rollout(pack_p, pb["x0"][:2], pb["U"][:2, :5], cost)
+    np.testing.assert_allclose(b["means"].cpu().numpy(), a["means"].cpu().numpy(), rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(b["vars"].cpu().numpy(), a["vars"].cpu().numpy(), rtol=1e-5)
+    np.testing.assert_allclose(b["grad"].cpu().numpy(), a["grad"].cpu().numpy(), rtol=1e-4, atol=1e-8)
+
+
+def test_c4_first_step_against_oracle(G):
+    """N=4096, ds=6, da=1 (config 4): first horizon step of two trajectories against the O(N^2) oracle."""
+    from oracle import gpmpc_oracle as O
+    from gaussian_process_mpc_amd.synth import CONFIGS, synth_problem
+    cfg = CONFIGS["C4"]
+    pb = synth_problem(4, cfg["N"], cfg["ds"], cfg["da"], 3, 2)
+    torch.set_num_threads(16)
+    gp = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"])
+    pack = G.GPPack(pb["X"], pb["Y"], gp.Ky_inv.numpy(), pb["lambdas"], pb["sigma_f"])
+    r = G.rollout(pack, pb["x0"], pb["U"][:, :1], G.CostParams(-1.0, pb["Q"], pb["R"]))
+    for b in range(2):
+        o = O.objective_and_gradient(gp, 1, pb["x0"][b], pb["U"][b, :1], pb["x_ref"], pb["u_ref"], pb["Q"], pb["R"],
+                                     -1.0, mode="o2")
+        np.testing.assert_allclose(r["means"][b].cpu().numpy(), o["means"], rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(r["vars"][b].cpu().numpy(), o["vars"], rtol=1e-4, atol=1e-12)
+        np.testing.assert_allclose(r["grad"][b].cpu().numpy(), o["grad"], rtol=1e-4, atol=1e-7)
+    del pack
+    torch.cuda.empty_cache()
