@@ -29,7 +29,7 @@ struct RollArgs {
     double* means; double* vars;
     // workspace
     double* pp;    // [B][ds][pps]   pair-kernel parameters of the current step
-    double* sp;    // [B][ds][sps]   per-GP scalars of the current step kept for the finish phase
+    double* sp;    // [2][B][ds][sps] per-GP scalars of step t at [t & 1], kept for the finish phase of the next head launch
     double* part;  // [B][ds][ntiles][nm]
     double* jac;   // [B][H][2ds][2ds+da] or null
     int pps, sps, ntiles, nm, grad;
@@ -41,8 +41,11 @@ struct RollArgs {
 // layout of sp (doubles): 0 c | 1 mu | 2 sf2 | 3 A[D] | 3+D scale[D] | 3+2D dmu_du[D] | 3+3D dmu_ds[D]
 __host__ __device__ static inline int sps_of(int D) { return 3 + 4 * D; }
 
-// Finish step t (>= 1) for trajectory b: reduce the pair-kernel partials, write mean/var of step t and its Jacobian.
-__device__ static void finish_step(const RollArgs& A, int b, int t, double* s_z /* [ds*nm] */) {
+// Finish step t (>= 1) for trajectory b: reduce the pair-kernel partials of ALL ds GPs (mean/var of step t land in
+// s_mu / s_var, LDS) and write to global memory the rows this workgroup owns: every GP if own < 0, else GP `own`
+// only (the head kernel runs one workgroup per (trajectory, GP); each recomputes the cheap reduction and owns one GP).
+__device__ static void finish_step(const RollArgs& A, int b, int t, int own, double* s_z /* [ds*nm] */,
+                                   double* s_mu, double* s_var) {
     const int ds = A.ds, D = A.D, nm = A.nm;
     for (int idx = threadIdx.x; idx < ds * nm; idx += blockDim.x) {
         const int a = idx / nm, m = idx - a * nm;
@@ -54,30 +57,34 @@ __device__ static void finish_step(const RollArgs& A, int b, int t, double* s_z 
     __syncthreads();
     if (threadIdx.x < ds) {
         const int a = threadIdx.x;
-        const double* sp = A.sp + ((size_t)b * ds + a) * A.sps;
+        const double* sp = A.sp + (((size_t)(t & 1) * A.B + b) * ds + a) * A.sps;
         const double* z = s_z + a * nm;
         const double c = sp[0], mu = sp[1], sf2 = sp[2];
         const double T = c * z[0];
         const double var = sf2 - T - mu * mu;
-        A.means[((size_t)b * (A.H + 1) + t) * ds + a] = mu;
-        A.vars[((size_t)b * (A.H + 1) + t) * ds + a] = var;
-        if (A.grad) {
-            const int nc = 2 * ds + A.da;
-            double* jm = A.jac + (((size_t)b * A.H + (t - 1)) * 2 * ds + a) * nc;        // row of mu_a
-            double* jv = A.jac + (((size_t)b * A.H + (t - 1)) * 2 * ds + ds + a) * nc;   // row of var_a
-            for (int k = 0; k < D; ++k) {
-                const double Ak = sp[3 + k], sc = sp[3 + D + k];
-                const double dmu_du = sp[3 + 2 * D + k], dmu_ds = sp[3 + 3 * D + k];
-                const double dT_du = -4.0 * sc * c * z[1 + k];
-                const double dT_ds = Ak * (c * z[1 + D + k] - 0.5 * T);
-                const double dv_du = -dT_du - 2.0 * mu * dmu_du;
-                const double dv_ds = -dT_ds - 2.0 * mu * dmu_ds;
-                if (k < ds) {
-                    jm[k] = dmu_du; jm[ds + k] = dmu_ds;
-                    jv[k] = dv_du;  jv[ds + k] = dv_ds;
-                } else {            // action input: its variance is a constant
-                    jm[2 * ds + (k - ds)] = dmu_du;
-                    jv[2 * ds + (k - ds)] = dv_du;
+        s_mu[a] = mu;
+        s_var[a] = var;
+        if (own < 0 || own == a) {
+            A.means[((size_t)b * (A.H + 1) + t) * ds + a] = mu;
+            A.vars[((size_t)b * (A.H + 1) + t) * ds + a] = var;
+            if (A.grad) {
+                const int nc = 2 * ds + A.da;
+                double* jm = A.jac + (((size_t)b * A.H + (t - 1)) * 2 * ds + a) * nc;        // row of mu_a
+                double* jv = A.jac + (((size_t)b * A.H + (t - 1)) * 2 * ds + ds + a) * nc;   // row of var_a
+                for (int k = 0; k < D; ++k) {
+                    const double Ak = sp[3 + k], sc = sp[3 + D + k];
+                    const double dmu_du = sp[3 + 2 * D + k], dmu_ds = sp[3 + 3 * D + k];
+                    const double dT_du = -4.0 * sc * c * z[1 + k];
+                    const double dT_ds = Ak * (c * z[1 + D + k] - 0.5 * T);
+                    const double dv_du = -dT_du - 2.0 * mu * dmu_du;
+                    const double dv_ds = -dT_ds - 2.0 * mu * dmu_ds;
+                    if (k < ds) {
+                        jm[k] = dmu_du; jm[ds + k] = dmu_ds;
+                        jv[k] = dv_du;  jv[ds + k] = dv_ds;
+                    } else {            // action input: its variance is a constant
+                        jm[2 * ds + (k - ds)] = dmu_du;
+                        jv[2 * ds + (k - ds)] = dv_du;
+                    }
                 }
             }
         }
@@ -85,82 +92,89 @@ __device__ static void finish_step(const RollArgs& A, int b, int t, double* s_z 
     __syncthreads();
 }
 
-// Prepare step t (>= 1): input moments from step t-1 and action t-1, the O(N) mean sums, pair parameters.
+// Prepare step t (>= 1) for GP a: input moments (mean/var of step t-1 in s_mu / s_var, action t-1), the O(N) mean
+// sums, the pair-kernel parameters.
 template <int D>
-__device__ static void prep_step(const RollArgs& A, int b, int t, double* s_u, double* s_s, double* s_scr, double* s_out) {
+__device__ static void prep_step(const RollArgs& A, int b, int t, int a, const double* s_mu, const double* s_var,
+                                 double* s_u, double* s_s, double* s_scr, double* s_out) {
     const int ds = A.ds;
     if (threadIdx.x < D) {
         const int k = threadIdx.x;
         if (k < ds) {
-            s_u[k] = A.means[((size_t)b * (A.H + 1) + (t - 1)) * ds + k];
-            s_s[k] = A.vars[((size_t)b * (A.H + 1) + (t - 1)) * ds + k];
+            s_u[k] = s_mu[k];
+            s_s[k] = s_var[k];
         } else {
             s_u[k] = A.U[((size_t)b * A.H + (t - 1)) * A.da + (k - ds)];
             s_s[k] = GPMPC_ACTION_VAR;
         }
     }
     __syncthreads();
-    for (int a = 0; a < ds; ++a) {
-        double u[D], Bk[D];
+    double u[D], Bk[D];
 #pragma unroll
-        for (int k = 0; k < D; ++k) { u[k] = s_u[k]; Bk[k] = 1.0 / (s_s[k] + A.lam[a * D + k]); }
-        double v[1 + 2 * D];
+    for (int k = 0; k < D; ++k) { u[k] = s_u[k]; Bk[k] = 1.0 / (s_s[k] + A.lam[a * D + k]); }
+    double v[1 + 2 * D];
 #pragma unroll
-        for (int m = 0; m < 1 + 2 * D; ++m) v[m] = 0.0;
-        for (int i = threadIdx.x; i < A.Np; i += blockDim.x) {
-            double d[D], q = 0.0;
+    for (int m = 0; m < 1 + 2 * D; ++m) v[m] = 0.0;
+    for (int i = threadIdx.x; i < A.Np; i += blockDim.x) {
+        double d[D], q = 0.0;
 #pragma unroll
-            for (int k = 0; k < D; ++k) { d[k] = u[k] - A.XT[(size_t)k * A.Np + i]; q = fma(Bk[k] * d[k], d[k], q); }
-            const double p = A.beta[(size_t)a * A.Np + i] * exp(-0.5 * q);
-            v[0] += p;
+        for (int k = 0; k < D; ++k) { d[k] = u[k] - A.XT[(size_t)k * A.Np + i]; q = fma(Bk[k] * d[k], d[k], q); }
+        const double p = A.beta[(size_t)a * A.Np + i] * exp(-0.5 * q);
+        v[0] += p;
 #pragma unroll
-            for (int k = 0; k < D; ++k) { v[1 + k] = fma(p, d[k], v[1 + k]); v[1 + D + k] = fma(p * d[k], d[k], v[1 + D + k]); }
+        for (int k = 0; k < D; ++k) { v[1 + k] = fma(p, d[k], v[1 + k]); v[1 + D + k] = fma(p * d[k], d[k], v[1 + D + k]); }
+    }
+    block_sum<1 + 2 * D>(v, s_scr, s_out);
+    if (threadIdx.x == 0) {
+        const double sf = A.sf[a], sf2 = sf * sf;
+        double detm = 1.0, detv = 1.0;
+        for (int k = 0; k < D; ++k) {
+            const double lam = A.lam[a * D + k];
+            detm *= s_s[k] / lam + 1.0;
+            detv *= 2.0 * s_s[k] / lam + 1.0;
         }
-        block_sum<1 + 2 * D>(v, s_scr, s_out);
-        if (threadIdx.x == 0) {
-            const double sf = A.sf[a], sf2 = sf * sf;
-            double detm = 1.0, detv = 1.0;
-            for (int k = 0; k < D; ++k) {
-                const double lam = A.lam[a * D + k];
-                detm *= s_s[k] / lam + 1.0;
-                detv *= 2.0 * s_s[k] / lam + 1.0;
-            }
-            const double cm = sf2 / sqrt(detm), c = 1.0 / sqrt(detv);
-            const double mu = cm * s_out[0];
-            double* sp = A.sp + ((size_t)b * ds + a) * A.sps;
-            double* pp = A.pp + ((size_t)b * ds + a) * A.pps;
-            sp[0] = c; sp[1] = mu; sp[2] = sf2;
-            for (int k = 0; k < D; ++k) {
-                const double lam = A.lam[a * D + k];
-                const double Ak = 1.0 / (0.5 * lam + s_s[k]);
-                const double sc = sqrt(0.125 * Ak);
-                sp[3 + k] = Ak; sp[3 + D + k] = sc;
-                sp[3 + 2 * D + k] = -Bk[k] * cm * s_out[1 + k];
-                sp[3 + 3 * D + k] = -0.5 * mu * Bk[k] + 0.5 * Bk[k] * Bk[k] * cm * s_out[1 + D + k];
-                pp[k] = sc * s_u[k];
-                pp[D + k] = sc;
-            }
+        const double cm = sf2 / sqrt(detm), c = 1.0 / sqrt(detv);
+        const double mu = cm * s_out[0];
+        double* sp = A.sp + (((size_t)(t & 1) * A.B + b) * ds + a) * A.sps;   // other parity than the finish phase reads
+        double* pp = A.pp + ((size_t)b * ds + a) * A.pps;
+        sp[0] = c; sp[1] = mu; sp[2] = sf2;
+        for (int k = 0; k < D; ++k) {
+            const double lam = A.lam[a * D + k];
+            const double Ak = 1.0 / (0.5 * lam + s_s[k]);
+            const double sc = sqrt(0.125 * Ak);
+            sp[3 + k] = Ak; sp[3 + D + k] = sc;
+            sp[3 + 2 * D + k] = -Bk[k] * cm * s_out[1 + k];
+            sp[3 + 3 * D + k] = -0.5 * mu * Bk[k] + 0.5 * Bk[k] * Bk[k] * cm * s_out[1 + D + k];
+            pp[k] = sc * s_u[k];
+            pp[D + k] = sc;
         }
-        __syncthreads();
     }
 }
 
+// One workgroup per (trajectory, GP).  The finish phase of step t-1 reads sp/pp/part written by the previous
+// launches and the prep phase overwrites sp/pp of ITS OWN GP only, so workgroups of one trajectory never race.
 template <int D>
 __global__ __launch_bounds__(256) void k_roll_head(RollArgs A, int t) {
     __shared__ double s_z[GPMPC_MAX_DS * (1 + 2 * GPMPC_MAX_D)];
+    __shared__ double s_mu[GPMPC_MAX_DS], s_var[GPMPC_MAX_DS];
     __shared__ double s_u[GPMPC_MAX_D], s_s[GPMPC_MAX_D];
     __shared__ double s_scr[16 * (1 + 2 * D)], s_out[1 + 2 * D];
-    const int b = blockIdx.x;
+    const int b = blockIdx.x, a = blockIdx.y;
     if (t == 1) {
         if (threadIdx.x < A.ds) {
-            A.means[((size_t)b * (A.H + 1)) * A.ds + threadIdx.x] = A.x0[(size_t)b * A.ds + threadIdx.x];
-            A.vars[((size_t)b * (A.H + 1)) * A.ds + threadIdx.x] = GPMPC_INIT_VAR;
+            const double x = A.x0[(size_t)b * A.ds + threadIdx.x];
+            s_mu[threadIdx.x] = x;
+            s_var[threadIdx.x] = GPMPC_INIT_VAR;
+            if (a == 0) {
+                A.means[((size_t)b * (A.H + 1)) * A.ds + threadIdx.x] = x;
+                A.vars[((size_t)b * (A.H + 1)) * A.ds + threadIdx.x] = GPMPC_INIT_VAR;
+            }
         }
         __syncthreads();
     } else {
-        finish_step(A, b, t - 1, s_z);
+        finish_step(A, b, t - 1, a, s_z, s_mu, s_var);
     }
-    prep_step<D>(A, b, t, s_u, s_s, s_scr, s_out);
+    prep_step<D>(A, b, t, a, s_mu, s_var, s_u, s_s, s_scr, s_out);
 }
 
 // ---------------------------------------------------------------------------
@@ -270,8 +284,9 @@ __device__ static double input_cost(int H, int da, const gpmpc_cost_params& C, c
 __global__ __launch_bounds__(64) void k_roll_tail(RollArgs A) {
     extern __shared__ double s_dyn[];
     __shared__ double s_z[GPMPC_MAX_DS * (1 + 2 * GPMPC_MAX_D)];
+    __shared__ double s_mu[GPMPC_MAX_DS], s_var[GPMPC_MAX_DS];
     const int b = blockIdx.x, ds = A.ds, da = A.da, H = A.H;
-    finish_step(A, b, H, s_z);
+    finish_step(A, b, H, -1, s_z, s_mu, s_var);
     double* s_lu = s_dyn;
     double* s_ct = s_dyn + GPMPC_TAIL_WORKERS * ds * 2 * ds;
     double* s_dl = s_ct + (H + 1);
@@ -414,7 +429,7 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     size_t off = 0;
     auto take = [&](size_t n) { size_t o = off; off += (n * sizeof(double) + 255) & ~(size_t)255; return o; };
     r->off_pp = take((size_t)B * p->ds * r->pps);
-    r->off_sp = take((size_t)B * p->ds * r->sps);
+    r->off_sp = take((size_t)2 * B * p->ds * r->sps);
     r->off_part = take((size_t)B * p->ds * r->ntiles * r->nm);
     r->off_jac = take(grad ? (size_t)B * H * 2 * p->ds * (2 * p->ds + p->da) : 0);
     r->off_means = take((size_t)B * (H + 1) * p->ds);
@@ -431,7 +446,7 @@ extern "C" size_t gpmpc_rollout_workspace_bytes(const gpmpc_pack* p, int B, int 
 
 template <int D>
 static void launch_head(const RollArgs& A, int t, hipStream_t s) {
-    hipLaunchKernelGGL(k_roll_head<D>, dim3(A.B), dim3(256), 0, s, A, t);
+    hipLaunchKernelGGL(k_roll_head<D>, dim3(A.B, A.ds), dim3(256), 0, s, A, t);
 }
 
 extern "C" int gpmpc_rollout(const gpmpc_pack* p, int B, int H, const double* x0, const double* U,
