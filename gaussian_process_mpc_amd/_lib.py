@@ -54,10 +54,11 @@ SIGNATURES = {
     "gpmpc_build_ky": (_i, [_i, _i, _vp, _dp, _d, _d, _vp, _vp, _vp]),
     "gpmpc_pack_build": (_i, [_vp, _vp, _vp, _vp, _dp, _dp, _vp]),
     "gpmpc_pack_build_beta": (_i, [_vp, _vp, _vp, _vp, _dp, _dp, _vp]),
+    "gpmpc_pack_enable_fullcov": (_i, [_vp, _vp]),
     "gpmpc_pack_dims": (_i, [_vp] + [ctypes.POINTER(_i)] * 4),
     "gpmpc_pack_export": (_i, [_vp, _vp, _vp, _vp]),
     "gpmpc_moment_match_workspace_bytes": (_sz, [_vp, _i]),
-    "gpmpc_moment_match": (_i, [_vp, _i, _vp, _vp, _u] + [_vp] * 8 + [_vp, _sz, _vp]),
+    "gpmpc_moment_match": (_i, [_vp, _i, _vp, _vp, _u] + [_vp] * 10 + [_vp, _sz, _vp]),
     "gpmpc_cost": (_i, [_i, _i, _i, _i, ctypes.POINTER(CostParamsC), _vp, _vp, _vp, _vp, _vp]),
     "gpmpc_rollout_workspace_bytes": (_sz, [_vp, _i, _i, _u]),
     "gpmpc_rollout": (_i, [_vp, _i, _i, _vp, _vp, ctypes.POINTER(CostParamsC), _u, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -13,26 +13,39 @@
 #define GPMPC_INIT_VAR   1e-3
 #define GPMPC_ACTION_VAR ((double)1e-3f)
 
-struct gpmpc_tiling {
+#define GPMPC_MAX_PAIRS (GPMPC_MAX_DS * (GPMPC_MAX_DS - 1) / 2)
+
+// A list of pair-kernel work items (unit, i0, j0, j1).  Units 0..ds-1 are the variance units (upper-triangular
+// tiles only), units ds.. are the cross-covariance units (a < b, all tiles).  Items of one unit are contiguous:
+// unit u owns items [ustart[u], ustart[u+1]).
+struct gpmpc_worklist {
     int it;         // rows per tile
-    int waves;      // waves per workgroup of the v1 kernel: it / 64
-    int jt;         // j-extent of a tile (multiple of 64)
-    int ntiles;
-    int* tiles_dev; // [ntiles][3] = {i0, j0, j1}
+    int waves;      // waves per workgroup: it / 64
+    int jt;         // column extent of a tile (multiple of 64)
+    int nunits, nwork;
+    int* work_dev;      // [nwork][4]
+    int* ustart_dev;    // [nunits + 1]
+    int ustart_host[GPMPC_MAX_DS + GPMPC_MAX_PAIRS + 1];
 };
 
 struct gpmpc_pack {
     int N, Np, ds, da, D;
     int built;
+    int npairs;     // ds (ds - 1) / 2 cross-covariance units (a < b, lexicographic)
+    int fullcov;    // cross-covariance weight matrices are allocated and kept up to date
+    int pair_a[GPMPC_MAX_PAIRS > 0 ? GPMPC_MAX_PAIRS : 1], pair_b[GPMPC_MAX_PAIRS > 0 ? GPMPC_MAX_PAIRS : 1];
+    int* pair_ab_dev;   // [npairs][2]
     double* X;      // dev [Np][D], rows >= N zero
     double* XT;     // dev [D][Np]
     double* beta;   // dev [ds][Np], zero padded
-    double* M;      // dev [ds][Np][Np]: element (i,j), i<=j, lives at [j*Np+i]; weight 2 off the diagonal
+    // dev [ds (+ npairs)][Np][Np].  Variance unit a: element (i,j), i<=j, at [j*Np+i], weight 2 off the diagonal, zero
+    // below.  Cross unit (a,b): element (i,j) at [j*Np+i] = beta_a[i] beta_b[j] sfa^2 sfb^2 exp(-1/2 d^2_{La+Lb}(x_i,x_j)).
+    double* M;
     double* lam;    // dev [ds][D]
     double* sf;     // dev [ds]
     double lam_host[GPMPC_MAX_DS][GPMPC_MAX_D];
     double sf_host[GPMPC_MAX_DS];
-    gpmpc_tiling tilings[3];   // [0] 256x256 (big batches), [1] 64x64 one-wave tiles (small batches), [2] 128x256 (v2, RI=2)
+    gpmpc_worklist wl[2][2];   // [0: variance units only | 1: + cross units][0: 256x256 tiles | 1: 64x64 one-wave tiles]
 };
 
 // Number of pair-kernel output moments per (trajectory, GP, tile).
@@ -42,21 +55,20 @@ static inline int gpmpc_num_moments(int D, bool diag, bool grad) {
 }
 
 struct PairArgs {
-    const double* M;
-    const double* XT;
-    const double* pp;     // [B][ds][pps]: cvec[D] then transform (diag: scale[D]; full: Cm[D][D] upper)
-    double* part;         // [B][ds][ntiles][nm]
-    const int* tiles;
-    int Np, ds, B, ntiles, pps, nm;
+    const double* M;      // [units][Np][Np]
+    const double* XT;     // [D][Np]
+    const double* pp;     // [B][nunits][pps]: row-side cvec[D] + transform, column side jside_off doubles further
+    double* part;         // [B][nwork][nm]
+    const int* work;      // [nwork][4] = {unit, i0, j0, j1}
+    int Np, B, nunits, nwork, pps, nm;
+    int jside_off;        // 0: columns use the row transform (symmetric units only)
+    int ntri;             // units < ntri are symmetric / upper-triangular
     int ns2;              // leading dims whose second moments are needed (diag+grad path); D = all
 };
 
 // Implemented in pair_d*.hip (one translation unit per D so the build parallelises).
 int gpmpc_launch_pair(int D, bool diag, bool grad, int tb, int waves, const PairArgs& a, hipStream_t s);
 template <int D> int gpmpc_launch_pair_D(bool diag, bool grad, int tb, int waves, const PairArgs& a, hipStream_t s);
-// v2 (MFMA moment accumulation; diagonal S, forward+gradient, D <= 7); variant: 0 = TB4/RI2, 1 = TB2/RI4, 2 = TB1/RI4
-int gpmpc_launch_pair_mfma(int D, int variant, const PairArgs& a, hipStream_t s);
-template <int D> int gpmpc_launch_pair_mfma_D(int variant, const PairArgs& a, hipStream_t s);
 
 void gpmpc_set_error(const char* what, hipError_t e);
 #define GPMPC_HIP(call)                                              \

@@ -10,20 +10,24 @@
 // with S1 = sum p_i v_i, S2 = sum p_i v_i v_i^T and Z* the pair-kernel moments in h-space.
 #include "gpmpc_internal.h"
 
-int gpmpc_timed_pair(int D, bool diag, bool grad, int tb, int waves, const PairArgs& a, hipStream_t s, int mfma_variant);
+int gpmpc_timed_pair(int D, bool diag, bool grad, int tb, int waves, const PairArgs& a, hipStream_t s);
 
 struct MomArgs {
     const double* XT; const double* beta; const double* lam; const double* sf;
     int N, Np, ds, D;
     const double* u; const double* S; int nq;
     double* pp; double* sp; double* part;
-    int pps, sps, ntiles, nm, grad;
+    int pps, sps, nwork, nunits, nm, grad;
+    const int* ustart;            // work items of unit u: [ustart[u], ustart[u+1])
+    const int* pair_ab; int npairs;   // cross units evaluated by the pair kernel (0: none)
     double* out_mean; double* out_var; double* out_cov; double* out_l;
-    double* dmean_du; double* dmean_dS; double* dvar_du; double* dvar_dS;
+    double* dmean_du; double* dmean_dS; double* dvar_du; double* dvar_dS; double* dcov_du; double* dcov_dS;
     unsigned flags;
 };
 
-// sp layout: 0 c | 1 mu | 2 sf2 | 3 Am[D*D] | 3+DD Cm[D*D] | 3+2DD dmu_du[D] | 3+2DD+D dmu_dS[D*D]
+// sp layout, variance unit a: 0 c | 1 mu | 2 sf2 | 3 Am[D*D] | 3+DD Cm[D*D] | 3+2DD dmu_du[D] | 3+2DD+D dmu_dS[D*D]
+//            cross unit (a,b): 0 c_ab | 1,2 unused | 3 Bab[D*D] | 3+DD Cm[D*D]
+// pp layout per unit: rows [cvec(D) | T(D*D)], columns the same D + D*D doubles further
 __host__ __device__ static inline int msps_of(int D) { return 3 + 3 * D * D + D; }
 
 // In-place inverse and determinant of a small general matrix (Gauss-Jordan, partial pivoting).
@@ -64,8 +68,8 @@ __global__ __launch_bounds__(256) void k_mom_prep(MomArgs A) {
     if (threadIdx.x < D * D) s_S[threadIdx.x] = A.S[(size_t)q * D * D + threadIdx.x];
     __syncthreads();
     for (int a = 0; a < ds; ++a) {
-        double* sp = A.sp + ((size_t)q * ds + a) * A.sps;
-        double* pp = A.pp + ((size_t)q * ds + a) * A.pps;
+        double* sp = A.sp + ((size_t)q * A.nunits + a) * A.sps;
+        double* pp = A.pp + ((size_t)q * A.nunits + a) * A.pps;
         if (threadIdx.x == 0) {
             const double* lam = A.lam + a * D;
             double detlam = 1.0;
@@ -98,9 +102,9 @@ __global__ __launch_bounds__(256) void k_mom_prep(MomArgs A) {
             for (int k = 0; k < D; ++k) {
                 double s = 0.0;
                 for (int l = k; l < D; ++l) s += Cm[k * D + l] * s_u[l];
-                pp[k] = s;
+                pp[k] = s; pp[D + D * D + k] = s;
             }
-            for (int e = 0; e < D * D; ++e) pp[D + e] = Cm[e];
+            for (int e = 0; e < D * D; ++e) { pp[D + e] = Cm[e]; pp[D + D * D + D + e] = Cm[e]; }
         }
         __syncthreads();
         double u[D], Bm[D * D];
@@ -161,53 +165,127 @@ __global__ __launch_bounds__(256) void k_mom_prep(MomArgs A) {
         }
         __syncthreads();
     }
+    // cross-covariance units (a < b): Gaussian-product form of covariance_prop_torch (:402-465)
+    //   Lab = (La^-1 + Lb^-1)^-1, w_a = Lab La^-1, w_b = Lab Lb^-1, Bab = (S + Lab)^-1, c = det(Lab^-1 S + I)^-1/2,
+    //   Cm^T Cm = Bab / 2, rows p_i = Cm (w_a o (u - x_i)), columns q_j = Cm (w_b o (u - x_j)).
+    for (int pr = threadIdx.x; pr < A.npairs; pr += blockDim.x) {
+        const int a = A.pair_ab[2 * pr], b = A.pair_ab[2 * pr + 1];
+        const double* la = A.lam + a * D; const double* lb = A.lam + b * D;
+        double* sp = A.sp + ((size_t)q * A.nunits + ds + pr) * A.sps;
+        double* pp = A.pp + ((size_t)q * A.nunits + ds + pr) * A.pps;
+        double Mt[D * D], Bab[D * D], L[D * D], wa[D], wb[D];
+        double detlab = 1.0;
+        for (int k = 0; k < D; ++k) {
+            const double lab = la[k] * lb[k] / (la[k] + lb[k]);
+            wa[k] = lb[k] / (la[k] + lb[k]); wb[k] = la[k] / (la[k] + lb[k]);
+            detlab *= lab;
+            for (int c = 0; c < D; ++c) Mt[k * D + c] = 0.5 * (s_S[k * D + c] + s_S[c * D + k]) + (k == c ? lab : 0.0);
+        }
+        const double det = small_inverse(D, Mt, Bab);
+        sp[0] = sqrt(detlab / det);
+        sp[1] = 0.0; sp[2] = 0.0;
+        for (int e = 0; e < D * D; ++e) { sp[3 + e] = Bab[e]; L[e] = 0.0; }
+        for (int r = 0; r < D; ++r)
+            for (int c = 0; c <= r; ++c) {
+                double s = 0.25 * (Bab[r * D + c] + Bab[c * D + r]);
+                for (int l = 0; l < c; ++l) s -= L[r * D + l] * L[c * D + l];
+                L[r * D + c] = (r == c) ? sqrt(s) : s / L[c * D + c];
+            }
+        double* Cm = sp + 3 + D * D;
+        for (int r = 0; r < D; ++r) for (int c = 0; c < D; ++c) Cm[r * D + c] = (c >= r) ? L[c * D + r] : 0.0;
+        double* pr_r = pp; double* pr_c = pp + D + D * D;
+        for (int k = 0; k < D; ++k) {
+            double sr = 0.0, sc = 0.0;
+            for (int l = 0; l < D; ++l) {
+                const double tr_ = Cm[k * D + l] * wa[l], tc_ = Cm[k * D + l] * wb[l];
+                pr_r[D + k * D + l] = tr_; pr_c[D + k * D + l] = tc_;
+                sr += tr_ * s_u[l]; sc += tc_ * s_u[l];
+            }
+            pr_r[k] = sr; pr_c[k] = sc;
+        }
+    }
 }
 
 template <int D>
 __global__ __launch_bounds__(64) void k_mom_finish(MomArgs A) {
-    __shared__ double s_z[GPMPC_MAX_DS * (1 + D + D * (D + 1) / 2)];
-    const int q = blockIdx.x, ds = A.ds, nm = A.nm;
-    for (int idx = threadIdx.x; idx < ds * nm; idx += blockDim.x) {
-        const int a = idx / nm, m = idx - a * nm;
-        const double* p = A.part + (((size_t)q * ds + a) * A.ntiles) * nm + m;
+    constexpr int NMX = 1 + D + D * (D + 1) / 2;
+    __shared__ double s_z[(GPMPC_MAX_DS + GPMPC_MAX_PAIRS) * NMX];
+    const int q = blockIdx.x, ds = A.ds, nm = A.nm, nunits = A.nunits;
+    for (int idx = threadIdx.x; idx < nunits * nm; idx += blockDim.x) {
+        const int u = idx / nm, m = idx - u * nm;
+        const double* p = A.part + (size_t)q * A.nwork * nm + m;
         double s = 0.0;
-        for (int tl = 0; tl < A.ntiles; ++tl) s += p[(size_t)tl * nm];
+        for (int wi = A.ustart[u]; wi < A.ustart[u + 1]; ++wi) s += p[(size_t)wi * nm];
         s_z[idx] = s;
     }
     __syncthreads();
-    if (threadIdx.x >= ds) return;
-    const int a = threadIdx.x;
-    const double* sp = A.sp + ((size_t)q * ds + a) * A.sps;
-    const double* z = s_z + a * nm;
-    const double c = sp[0], mu = sp[1], sf2 = sp[2];
-    const double T = c * z[0];
-    const double var = sf2 - T - mu * mu;
-    A.out_mean[(size_t)q * ds + a] = mu;
-    A.out_var[(size_t)q * ds + a] = var;
-    if (A.out_cov) A.out_cov[((size_t)q * ds + a) * ds + a] = var;
-    if (!A.grad) return;
-    const double* Am = sp + 3;
+    const int u = threadIdx.x;
+    if (u >= nunits) return;
+    const double* sp = A.sp + ((size_t)q * nunits + u) * A.sps;
+    const double* z = s_z + u * nm;
+    const double c = sp[0];
+    const double* Bm = sp + 3;                 // Am (variance unit) or Bab (cross unit)
     const double* Cm = sp + 3 + D * D;
-    const double* dmu_du = sp + 3 + 2 * D * D;
-    const double* dmu_dS = dmu_du + D;
-    double Z2[D * D];
-    int o = 1 + D;
-    for (int k = 0; k < D; ++k) for (int l = k; l < D; ++l) { Z2[k * D + l] = Z2[l * D + k] = z[o]; ++o; }
-    for (int k = 0; k < D; ++k) {
-        double s = 0.0;                                   // (Cm^T Z1)_k
-        for (int l = 0; l <= k; ++l) s += Cm[l * D + k] * z[1 + l];
-        const double dT_du = -4.0 * c * s;
-        A.dmean_du[((size_t)q * ds + a) * D + k] = dmu_du[k];
-        A.dvar_du[((size_t)q * ds + a) * D + k] = -dT_du - 2.0 * mu * dmu_du[k];
+    double Z2[D * D], CtZ1[D], CZC[D * D];
+    if (A.grad) {
+        int o = 1 + D;
+        for (int k = 0; k < D; ++k) for (int l = k; l < D; ++l) { Z2[k * D + l] = Z2[l * D + k] = z[o]; ++o; }
+        for (int k = 0; k < D; ++k) {
+            double s = 0.0;                                   // (Cm^T Z1)_k
+            for (int l = 0; l <= k; ++l) s += Cm[l * D + k] * z[1 + l];
+            CtZ1[k] = s;
+        }
+        double ZC[D * D];                                     // Z2 Cm
+        for (int r = 0; r < D; ++r) for (int cc = 0; cc < D; ++cc) { double s = 0.0; for (int l = 0; l <= cc; ++l) s += Z2[r * D + l] * Cm[l * D + cc]; ZC[r * D + cc] = s; }
+        for (int r = 0; r < D; ++r) for (int cc = 0; cc < D; ++cc) { double s = 0.0; for (int l = 0; l <= r; ++l) s += Cm[l * D + r] * ZC[l * D + cc]; CZC[r * D + cc] = s; }
     }
-    double ZC[D * D];                                     // Z2 Cm
-    for (int r = 0; r < D; ++r) for (int cc = 0; cc < D; ++cc) { double s = 0.0; for (int l = 0; l <= cc; ++l) s += Z2[r * D + l] * Cm[l * D + cc]; ZC[r * D + cc] = s; }
-    for (int r = 0; r < D; ++r) for (int cc = 0; cc < D; ++cc) {
-        double s = 0.0;                                   // (Cm^T Z2 Cm)_rc
-        for (int l = 0; l <= r; ++l) s += Cm[l * D + r] * ZC[l * D + cc];
-        const double dT_dS = -0.5 * T * Am[r * D + cc] + 8.0 * c * s;
-        A.dmean_dS[(((size_t)q * ds + a) * D + r) * D + cc] = dmu_dS[r * D + cc];
-        A.dvar_dS[(((size_t)q * ds + a) * D + r) * D + cc] = -dT_dS - 2.0 * mu * dmu_dS[r * D + cc];
+    if (u < ds) {                                             // variance unit
+        const int a = u;
+        const double mu = sp[1], sf2 = sp[2];
+        const double T = c * z[0];
+        const double var = sf2 - T - mu * mu;
+        A.out_mean[(size_t)q * ds + a] = mu;
+        A.out_var[(size_t)q * ds + a] = var;
+        if (A.out_cov) A.out_cov[((size_t)q * ds + a) * ds + a] = var;
+        if (!A.grad) return;
+        const double* dmu_du = sp + 3 + 2 * D * D;
+        const double* dmu_dS = dmu_du + D;
+        for (int k = 0; k < D; ++k) {
+            const double dT_du = -4.0 * c * CtZ1[k];
+            const double dv = -dT_du - 2.0 * mu * dmu_du[k];
+            A.dmean_du[((size_t)q * ds + a) * D + k] = dmu_du[k];
+            A.dvar_du[((size_t)q * ds + a) * D + k] = dv;
+            if (A.dcov_du) A.dcov_du[(((size_t)q * ds + a) * ds + a) * D + k] = dv;
+        }
+        for (int e = 0; e < D * D; ++e) {
+            const double dT_dS = -0.5 * T * Bm[e] + 8.0 * c * CZC[e];
+            const double dv = -dT_dS - 2.0 * mu * dmu_dS[e];
+            A.dmean_dS[((size_t)q * ds + a) * D * D + e] = dmu_dS[e];
+            A.dvar_dS[((size_t)q * ds + a) * D * D + e] = dv;
+            if (A.dcov_dS) A.dcov_dS[(((size_t)q * ds + a) * ds + a) * D * D + e] = dv;
+        }
+    } else {                                                  // cross unit (a, b): F = c Z0, Cov = F - mu_a mu_b
+        const int pr = u - ds, a = A.pair_ab[2 * pr], b = A.pair_ab[2 * pr + 1];
+        const double* spa = A.sp + ((size_t)q * nunits + a) * A.sps;
+        const double* spb = A.sp + ((size_t)q * nunits + b) * A.sps;
+        const double mua = spa[1], mub = spb[1];
+        const double F = c * z[0];
+        const double cov = F - mua * mub;
+        A.out_cov[((size_t)q * ds + a) * ds + b] = cov;
+        A.out_cov[((size_t)q * ds + b) * ds + a] = cov;
+        if (!A.grad || !A.dcov_du) return;
+        const double* da_du = spa + 3 + 2 * D * D; const double* da_dS = da_du + D;
+        const double* db_du = spb + 3 + 2 * D * D; const double* db_dS = db_du + D;
+        for (int k = 0; k < D; ++k) {
+            const double d = -2.0 * c * CtZ1[k] - mub * da_du[k] - mua * db_du[k];
+            A.dcov_du[(((size_t)q * ds + a) * ds + b) * D + k] = d;
+            A.dcov_du[(((size_t)q * ds + b) * ds + a) * D + k] = d;
+        }
+        for (int e = 0; e < D * D; ++e) {
+            const double d = -0.5 * F * Bm[e] + 2.0 * c * CZC[e] - mub * da_dS[e] - mua * db_dS[e];
+            A.dcov_dS[(((size_t)q * ds + a) * ds + b) * D * D + e] = d;
+            A.dcov_dS[(((size_t)q * ds + b) * ds + a) * D * D + e] = d;
+        }
     }
 }
 
@@ -308,45 +386,51 @@ __global__ __launch_bounds__(256) void k_cross_cov(MomArgs A, const int* __restr
     }
 }
 
-struct MomPlan { int tiling, tb, waves, ntiles, nm, pps, sps; size_t off_pp, off_sp, off_part, off_pairs, total; };
+struct MomPlan { int mode, tiling, tb, waves, nwork, nunits, nm, pps, sps; size_t off_pp, off_sp, off_part, off_pairs, total; };
 
-static void plan_mom(const gpmpc_pack* p, int nq, bool grad, MomPlan* r) {
+static void plan_mom(const gpmpc_pack* p, int nq, bool grad, bool pair_cov, MomPlan* r) {
     const int D = p->D;
-    r->tb = nq >= 4 ? (grad ? 2 : 4) : 1;
+    r->mode = pair_cov ? 1 : 0;
+    r->tb = nq >= 2 ? 2 : 1;
     const long groups = (nq + r->tb - 1) / r->tb;
-    r->tiling = (groups * p->tilings[0].ntiles * p->ds >= 1024) ? 0 : 1;
-    r->waves = p->tilings[r->tiling].waves;
-    r->ntiles = p->tilings[r->tiling].ntiles;
+    r->tiling = (groups * p->wl[r->mode][0].nwork >= 1024) ? 0 : 1;
+    const gpmpc_worklist& w = p->wl[r->mode][r->tiling];
+    r->waves = w.waves; r->nwork = w.nwork; r->nunits = w.nunits;
     r->nm = gpmpc_num_moments(D, false, grad);
-    r->pps = D + D * D;
+    r->pps = 2 * (D + D * D);
     r->sps = msps_of(D);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    r->off_pp = take(sizeof(double) * (size_t)nq * p->ds * r->pps);
-    r->off_sp = take(sizeof(double) * (size_t)nq * p->ds * r->sps);
-    r->off_part = take(sizeof(double) * (size_t)nq * p->ds * r->ntiles * r->nm);
+    r->off_pp = take(sizeof(double) * (size_t)nq * r->nunits * r->pps);
+    r->off_sp = take(sizeof(double) * (size_t)nq * r->nunits * r->sps);
+    r->off_part = take(sizeof(double) * (size_t)nq * r->nwork * r->nm);
     r->off_pairs = take(sizeof(int) * 2 * GPMPC_MAX_DS * GPMPC_MAX_DS);
     r->total = off;
 }
 
 extern "C" size_t gpmpc_moment_match_workspace_bytes(const gpmpc_pack* p, int nq) {
     if (!p || nq < 1) return 0;
-    MomPlan a, b;
-    plan_mom(p, nq, true, &a);
-    plan_mom(p, nq, false, &b);
-    return a.total > b.total ? a.total : b.total;
+    size_t best = 0;
+    for (int g = 0; g < 2; ++g)
+        for (int pc = 0; pc < 2; ++pc) {
+            MomPlan r;
+            plan_mom(p, nq, g != 0, pc != 0, &r);
+            if (r.total > best) best = r.total;
+        }
+    return best;
 }
 
 template <int D>
 static int run_mom(const gpmpc_pack* p, MomArgs& A, const MomPlan& r, bool grad, hipStream_t s, int* pairs_dev) {
     hipLaunchKernelGGL(k_mom_prep<D>, dim3(A.nq), dim3(256), 0, s, A);
     PairArgs P;
-    P.M = p->M; P.XT = p->XT; P.pp = A.pp; P.part = A.part; P.tiles = p->tilings[r.tiling].tiles_dev;
-    P.Np = p->Np; P.ds = p->ds; P.B = A.nq; P.ntiles = r.ntiles; P.pps = r.pps; P.nm = r.nm; P.ns2 = D;
-    int rc = gpmpc_timed_pair(D, false, grad, r.tb, r.waves, P, s, -1);
+    P.M = p->M; P.XT = p->XT; P.pp = A.pp; P.part = A.part; P.work = p->wl[r.mode][r.tiling].work_dev;
+    P.Np = p->Np; P.B = A.nq; P.nunits = r.nunits; P.nwork = r.nwork; P.pps = r.pps; P.nm = r.nm;
+    P.jside_off = D + D * D; P.ntri = p->ds; P.ns2 = D;
+    int rc = gpmpc_timed_pair(D, false, grad, r.tb, r.waves, P, s);
     if (rc != GPMPC_OK) return rc;
     hipLaunchKernelGGL(k_mom_finish<D>, dim3(A.nq), dim3(64), 0, s, A);
-    if (A.out_cov && p->ds > 1) {
+    if (A.out_cov && p->ds > 1 && A.npairs == 0) {          // direct N^2 kernel (also the bug-compatible form)
         int h[2 * GPMPC_MAX_DS * GPMPC_MAX_DS], n = 0;
         const bool bug = (A.flags & GPMPC_COV_BUG_COMPAT) != 0;
         for (int a = 0; a < p->ds; ++a)
@@ -363,14 +447,19 @@ static int run_mom(const gpmpc_pack* p, MomArgs& A, const MomPlan& r, bool grad,
 
 extern "C" int gpmpc_moment_match(const gpmpc_pack* p, int nq, const double* u, const double* S, unsigned flags,
                                   double* out_mean, double* out_var, double* out_cov, double* out_l, double* dmean_du,
-                                  double* dmean_dS, double* dvar_du, double* dvar_dS, void* workspace,
-                                  size_t workspace_bytes, void* stream) {
+                                  double* dmean_dS, double* dvar_du, double* dvar_dS, double* dcov_du, double* dcov_dS,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
     if (!p || !u || !S || !out_mean || !out_var || !workspace || nq < 1) return GPMPC_E_ARG;
     if (!p->built) return GPMPC_E_STATE;
     const bool grad = (flags & GPMPC_WANT_GRAD) != 0;
+    const bool bug = (flags & GPMPC_COV_BUG_COMPAT) != 0;
     if (grad && (!dmean_du || !dmean_dS || !dvar_du || !dvar_dS)) return GPMPC_E_ARG;
+    if ((dcov_du == nullptr) != (dcov_dS == nullptr)) return GPMPC_E_ARG;
+    // cross-covariances through the pair kernel (with Jacobians) need the cross weight matrices of the pack
+    const bool pair_cov = out_cov && !bug && p->fullcov && p->npairs > 0;
+    if (dcov_du && (!grad || !out_cov || bug || (p->npairs > 0 && !p->fullcov))) return GPMPC_E_STATE;
     MomPlan r;
-    plan_mom(p, nq, grad, &r);
+    plan_mom(p, nq, grad, pair_cov, &r);
     if (workspace_bytes < r.total) return GPMPC_E_WORKSPACE;
     char* ws = (char*)workspace;
     MomArgs A;
@@ -379,9 +468,12 @@ extern "C" int gpmpc_moment_match(const gpmpc_pack* p, int nq, const double* u, 
     A.N = p->N; A.Np = p->Np; A.ds = p->ds; A.D = p->D;
     A.u = u; A.S = S; A.nq = nq;
     A.pp = (double*)(ws + r.off_pp); A.sp = (double*)(ws + r.off_sp); A.part = (double*)(ws + r.off_part);
-    A.pps = r.pps; A.sps = r.sps; A.ntiles = r.ntiles; A.nm = r.nm; A.grad = grad ? 1 : 0;
+    A.pps = r.pps; A.sps = r.sps; A.nwork = r.nwork; A.nunits = r.nunits; A.nm = r.nm; A.grad = grad ? 1 : 0;
+    A.ustart = p->wl[r.mode][r.tiling].ustart_dev;
+    A.pair_ab = p->pair_ab_dev; A.npairs = pair_cov ? p->npairs : 0;
     A.out_mean = out_mean; A.out_var = out_var; A.out_cov = out_cov; A.out_l = out_l;
     A.dmean_du = dmean_du; A.dmean_dS = dmean_dS; A.dvar_du = dvar_du; A.dvar_dS = dvar_dS;
+    A.dcov_du = dcov_du; A.dcov_dS = dcov_dS;
     A.flags = flags;
     hipStream_t s = (hipStream_t)stream;
     int* pairs_dev = (int*)(ws + r.off_pairs);

@@ -94,19 +94,51 @@ __global__ void k_build_ky(const double* __restrict__ X, int n, int D, const dou
     Ky[(size_t)i * n + j] = kf + (i == j ? noise_var : 0.0);
 }
 
-static void build_tiling(int Np, int it, int jt, gpmpc_tiling* t, int** host_out) {
-    const int waves = it / 64 > 0 ? it / 64 : 1;
-    int cap = ((Np + it - 1) / it) * ((Np + jt - 1) / jt);
-    int* h = (int*)malloc(sizeof(int) * 3 * (size_t)cap);
-    int n = 0;
-    for (int i0 = 0; i0 < Np; i0 += it)
-        for (int j0 = 0; j0 < Np; j0 += jt) {
-            int j1 = j0 + jt < Np ? j0 + jt : Np;
-            if (j1 <= i0) continue;                          // wholly below the diagonal
-            h[3 * n] = i0; h[3 * n + 1] = j0; h[3 * n + 2] = j1; ++n;
+// Cross-covariance weights of the GP pair (a, b), a < b:  element (i,j) at [j*Np + i]
+//   beta_a[i] beta_b[j] sfa^2 sfb^2 exp(-1/2 sum_k (x_ik - x_jk)^2 / (lambda_ak + lambda_bk))
+// (the x-independent factor of k_a(x,x_i) k_b(x,x_j), src/tools/uncertainty_prop.py:448-460 as a Gaussian product).
+__global__ void k_pack_cross(const double* __restrict__ beta, const double* __restrict__ XT, const double* __restrict__ lam,
+                             const double* __restrict__ sf, const int* __restrict__ pair_ab, int N, int Np, int D, int ds,
+                             double* __restrict__ Mx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, pr = blockIdx.z;
+    if (i >= Np) return;
+    const int a = pair_ab[2 * pr], b = pair_ab[2 * pr + 1];
+    double out = 0.0;
+    if (i < N && j < N) {
+        double d2 = 0.0;
+        for (int k = 0; k < D; ++k) {
+            const double d = XT[(size_t)k * Np + i] - XT[(size_t)k * Np + j];
+            d2 = fma(d * d, 1.0 / (lam[a * D + k] + lam[b * D + k]), d2);
         }
-    t->it = it; t->waves = waves; t->jt = jt; t->ntiles = n;
-    *host_out = h;
+        const double s2 = sf[a] * sf[a] * sf[b] * sf[b];
+        out = beta[(size_t)a * Np + i] * beta[(size_t)b * Np + j] * s2 * exp(-0.5 * d2);
+    }
+    Mx[((size_t)pr * Np + j) * Np + i] = out;
+}
+
+static int build_worklist(int Np, int it, int jt, int ds, int npairs, gpmpc_worklist* w) {
+    const int ti = (Np + it - 1) / it, tj = (Np + jt - 1) / jt;
+    const size_t cap = (size_t)ti * tj * (ds + npairs);
+    int* h = (int*)malloc(sizeof(int) * 4 * cap);
+    if (!h) return -1;
+    int n = 0;
+    for (int u = 0; u < ds + npairs; ++u) {
+        w->ustart_host[u] = n;
+        for (int i0 = 0; i0 < Np; i0 += it)
+            for (int j0 = 0; j0 < Np; j0 += jt) {
+                const int j1 = j0 + jt < Np ? j0 + jt : Np;
+                if (u < ds && j1 <= i0) continue;            // variance unit: tile wholly below the diagonal
+                h[4 * n] = u; h[4 * n + 1] = i0; h[4 * n + 2] = j0; h[4 * n + 3] = j1; ++n;
+            }
+    }
+    w->ustart_host[ds + npairs] = n;
+    w->it = it; w->waves = it / 64 > 0 ? it / 64 : 1; w->jt = jt; w->nunits = ds + npairs; w->nwork = n;
+    hipError_t e = hipMalloc(&w->work_dev, sizeof(int) * 4 * (size_t)n);
+    if (e == hipSuccess) e = hipMemcpy(w->work_dev, h, sizeof(int) * 4 * (size_t)n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&w->ustart_dev, sizeof(int) * (ds + npairs + 1));
+    if (e == hipSuccess) e = hipMemcpy(w->ustart_dev, w->ustart_host, sizeof(int) * (ds + npairs + 1), hipMemcpyHostToDevice);
+    free(h);
+    return e == hipSuccess ? 0 : -1;
 }
 
 extern "C" int gpmpc_pack_create(gpmpc_pack** out, int n_train, int state_dim, int action_dim) {
@@ -116,6 +148,8 @@ extern "C" int gpmpc_pack_create(gpmpc_pack** out, int n_train, int state_dim, i
     gpmpc_pack* p = (gpmpc_pack*)calloc(1, sizeof(gpmpc_pack));
     if (!p) return GPMPC_E_ALLOC;
     p->N = n_train; p->Np = ((n_train + 63) / 64) * 64; p->ds = state_dim; p->da = action_dim; p->D = D;
+    for (int a = 0; a < state_dim; ++a)
+        for (int b = a + 1; b < state_dim; ++b) { p->pair_a[p->npairs] = a; p->pair_b[p->npairs] = b; ++p->npairs; }
     const size_t Np = p->Np;
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = hipMalloc(&p->X, sizeof(double) * Np * D);
@@ -124,16 +158,18 @@ extern "C" int gpmpc_pack_create(gpmpc_pack** out, int n_train, int state_dim, i
     if (e == hipSuccess) e = hipMalloc(&p->M, sizeof(double) * Np * Np * state_dim);
     if (e == hipSuccess) e = hipMalloc(&p->lam, sizeof(double) * state_dim * D);
     if (e == hipSuccess) e = hipMalloc(&p->sf, sizeof(double) * state_dim);
-    const int cfg[3][2] = {{256, 256}, {64, 64}, {128, 256}};
-    for (int k = 0; k < 3 && e == hipSuccess; ++k) {
-        int* h = nullptr;
-        build_tiling(p->Np, cfg[k][0], cfg[k][1], &p->tilings[k], &h);
-        e = hipMalloc(&p->tilings[k].tiles_dev, sizeof(int) * 3 * (size_t)p->tilings[k].ntiles);
-        if (e == hipSuccess)
-            e = hipMemcpy(p->tilings[k].tiles_dev, h, sizeof(int) * 3 * (size_t)p->tilings[k].ntiles, hipMemcpyHostToDevice);
-        free(h);
+    if (e == hipSuccess && p->npairs > 0) {
+        int hab[2 * GPMPC_MAX_PAIRS];
+        for (int k = 0; k < p->npairs; ++k) { hab[2 * k] = p->pair_a[k]; hab[2 * k + 1] = p->pair_b[k]; }
+        e = hipMalloc(&p->pair_ab_dev, sizeof(int) * 2 * p->npairs);
+        if (e == hipSuccess) e = hipMemcpy(p->pair_ab_dev, hab, sizeof(int) * 2 * p->npairs, hipMemcpyHostToDevice);
     }
-    if (e != hipSuccess) { gpmpc_set_error("gpmpc_pack_create", e); gpmpc_pack_destroy(p); return GPMPC_E_ALLOC; }
+    bool ok = e == hipSuccess;
+    const int cfg[2][2] = {{256, 256}, {64, 64}};
+    for (int mode = 0; mode < 2 && ok; ++mode)
+        for (int k = 0; k < 2 && ok; ++k)
+            ok = build_worklist(p->Np, cfg[k][0], cfg[k][1], state_dim, mode ? p->npairs : 0, &p->wl[mode][k]) == 0;
+    if (!ok) { gpmpc_set_error("gpmpc_pack_create", e); gpmpc_pack_destroy(p); return GPMPC_E_ALLOC; }
     *out = p;
     return GPMPC_OK;
 }
@@ -146,7 +182,12 @@ extern "C" int gpmpc_pack_destroy(gpmpc_pack* p) {
     if (p->M) (void)hipFree(p->M);
     if (p->lam) (void)hipFree(p->lam);
     if (p->sf) (void)hipFree(p->sf);
-    for (int k = 0; k < 3; ++k) if (p->tilings[k].tiles_dev) (void)hipFree(p->tilings[k].tiles_dev);
+    if (p->pair_ab_dev) (void)hipFree(p->pair_ab_dev);
+    for (int mode = 0; mode < 2; ++mode)
+        for (int k = 0; k < 2; ++k) {
+            if (p->wl[mode][k].work_dev) (void)hipFree(p->wl[mode][k].work_dev);
+            if (p->wl[mode][k].ustart_dev) (void)hipFree(p->wl[mode][k].ustart_dev);
+        }
     free(p);
     return GPMPC_OK;
 }
@@ -183,8 +224,33 @@ static int pack_build_impl(gpmpc_pack* p, const double* X_dev, const double* Y_d
                            Ky_inv_dev, p->beta, p->XT, p->lam, p->sf, p->N, p->Np, p->D, p->M);
     else
         GPMPC_HIP(hipMemsetAsync(p->M, 0, sizeof(double) * (size_t)p->Np * p->Np * p->ds, s));
+    if (p->fullcov && p->npairs > 0)
+        hipLaunchKernelGGL(k_pack_cross, dim3((p->Np + 255) / 256, p->Np, p->npairs), dim3(256), 0, s, p->beta, p->XT, p->lam,
+                           p->sf, p->pair_ab_dev, p->N, p->Np, p->D, p->ds, p->M + (size_t)p->ds * p->Np * p->Np);
     GPMPC_HIP(hipGetLastError());
     p->built = 1;
+    return GPMPC_OK;
+}
+
+// Allocate and fill the cross-covariance weight matrices (needed by the full-covariance rollout and by the
+// analytic cross-covariance Jacobians of gpmpc_moment_match).  Later gpmpc_pack_build* calls keep them current.
+extern "C" int gpmpc_pack_enable_fullcov(gpmpc_pack* p, void* stream) {
+    if (!p) return GPMPC_E_ARG;
+    if (p->fullcov || p->npairs == 0) { p->fullcov = 1; return GPMPC_OK; }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t mat = sizeof(double) * (size_t)p->Np * p->Np;
+    double* Mnew = nullptr;
+    if (hipMalloc(&Mnew, mat * (p->ds + p->npairs)) != hipSuccess) return GPMPC_E_ALLOC;
+    GPMPC_HIP(hipMemcpyAsync(Mnew, p->M, mat * p->ds, hipMemcpyDeviceToDevice, s));
+    GPMPC_HIP(hipStreamSynchronize(s));
+    (void)hipFree(p->M);
+    p->M = Mnew;
+    p->fullcov = 1;
+    if (p->built) {
+        hipLaunchKernelGGL(k_pack_cross, dim3((p->Np + 255) / 256, p->Np, p->npairs), dim3(256), 0, s, p->beta, p->XT, p->lam,
+                           p->sf, p->pair_ab_dev, p->N, p->Np, p->D, p->ds, p->M + (size_t)p->ds * p->Np * p->Np);
+        GPMPC_HIP(hipGetLastError());
+    }
     return GPMPC_OK;
 }
 
@@ -212,7 +278,7 @@ extern "C" int gpmpc_pack_export(const gpmpc_pack* p, double* beta_out, double* 
     hipStream_t s = (hipStream_t)stream;
     const size_t Np = p->Np;
     if (beta_out) GPMPC_HIP(hipMemcpyAsync(beta_out, p->beta, sizeof(double) * Np * p->ds, hipMemcpyDeviceToDevice, s));
-    if (weights_out) GPMPC_HIP(hipMemcpyAsync(weights_out, p->M, sizeof(double) * Np * Np * p->ds, hipMemcpyDeviceToDevice, s));
+    if (weights_out) GPMPC_HIP(hipMemcpyAsync(weights_out, p->M, sizeof(double) * Np * Np * p->ds, hipMemcpyDeviceToDevice, s));   // variance units only
     return GPMPC_OK;
 }
 

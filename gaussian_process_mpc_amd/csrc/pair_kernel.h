@@ -1,28 +1,31 @@
 // The O(N^2) pair kernel: the dominant kernel of the rollout.
 //
-// For one (trajectory b, GP a) the variance term of exact moment matching is
-//     T = c * sum_{i,j} M_ij * exp(-|h_i + h_j|^2),      h_i = Cm (u - x_i),  Cm^T Cm = (Lambda/2 + S)^-1 / 8
-// which restates  trace((Ky_inv - beta beta^T) @ L)  of the reference
-// (src/tools/uncertainty_prop.py:372-399) as an elementwise sum: M folds every factor that
-// does not depend on (u, S) (built once per data update, pack.hip) and
-// exp(-1/8 (G_ii + 2 G_ij + G_jj)) = exp(-|h_i + h_j|^2)  (:389).
+// For one (trajectory b, unit) it evaluates
+//     Z0 = sum_{i,j} M_ij exp(-|p_i + q_j|^2),      p_i = cvec_r - T_r x_i (rows),  q_j = cvec_c - T_c x_j (columns)
+// and, for the input-gradients, the moments  Z1_k = sum P m_k,  Z2_kl = sum P m_k m_l  with  m = p_i + q_j,
+// P = M_ij exp(-|m|^2).  Two kinds of unit share the code:
+//   * variance unit a (unit < ntri): the trace term of variance_prop_torch (src/tools/uncertainty_prop.py:372-399),
+//       T = c Z0,  M = sym(Ky_inv - beta beta^T) o exp(-1/4 d^2_Lambda) sf^4 (pack.hip),  rows and columns use the same
+//       transform h = Cm (u - x), Cm^T Cm = (Lambda/2 + S)^-1 / 8, so exp(-1/8 (G_ii + 2 G_ij + G_jj)) = exp(-|h_i + h_j|^2)
+//       (:389).  M is stored upper-triangular with weight 2 off the diagonal: only i <= j is visited.
+//   * cross-covariance unit (a, b) (unit >= ntri): beta_a^T Qt beta_b of covariance_prop_torch (:402-465) written as a
+//       Gaussian product, M = beta_a beta_b^T o exp(-1/2 d^2_{La+Lb}) sfa^2 sfb^2, rows use Cm diag(w_a), columns
+//       Cm diag(w_b) with Cm^T Cm = (S + Lab)^-1 / 2; all N^2 ordered pairs are visited.
+// step.hip / moment.hip turn (Z0, Z1, Z2) into values and Jacobians, so forward value and gradient come out of ONE
+// pass and nothing N x N is ever stored per call.
 //
-// With m = h_i + h_j the input-gradients of T need only the moments
-//     Z0 = sum P,  Z1_k = sum P m_k,  Z2_kl = sum P m_k m_l,   P = M_ij exp(-|m|^2)
-// (step.hip turns them into dT/du, dT/dS), so forward value and gradient come out of ONE pass,
-// nothing N x N is ever stored, and only the upper triangle i <= j is visited
-// (M carries weight 2 off the diagonal).
-//
-// Mapping (CDNA4, wave64): lane = row i; a workgroup of W waves owns 64*W rows and walks its
-// j-range in chunks of 64 columns whose transformed points h_j (for TB trajectories) are staged
-// in LDS and read back wave-uniformly (broadcast, conflict-free).  M_ij is read as [j][i], i.e.
-// 512 contiguous bytes per wave and j.  TB trajectories share every M_ij load.  All accumulation
-// is per-lane fp64; the cross-lane reduction happens once per workgroup, in a fixed order, and the
-// per-tile partials are written (not atomically added) so results are bit-reproducible.
+// Mapping (CDNA4, wave64): lane = row i; a workgroup of W waves owns 64*W rows and walks its j-range in chunks of 64
+// columns whose transformed points q_j (for TB trajectories) are staged in LDS and read back wave-uniformly
+// (broadcast, conflict-free).  M_ij is read as [j][i], i.e. 512 contiguous bytes per wave and j; TB trajectories
+// share every M_ij load.  All accumulation is per-lane fp64; the cross-lane reduction happens once per workgroup in a
+// fixed order and per-tile partials are written (not atomically added): results are bit-reproducible.
+// The kernel is fp64-VALU-issue bound (exp = 10 of ~35 fp64 instructions per pair): fp64 MFMA was measured NOT to
+// overlap with fp64 VALU work on MI355X and is not cheaper per FMA (profiles/r01/ubench_mfma_f64_overlap.txt), so the
+// moment accumulation stays on the VALU; occupancy (TB = 2 -> 3+ waves/SIMD) matters more than reuse (TB = 4).
 #pragma once
+#include <cstdlib>
 #include "gpmpc_internal.h"
 #include "fast_exp.h"
-#include <cstdlib>
 
 template <int D, bool DIAG, bool GRAD>
 struct PairTraits {
@@ -32,7 +35,7 @@ struct PairTraits {
 
 template <int D, bool DIAG>
 __device__ __forceinline__ void pair_transform(const double* __restrict__ prm, const double (&x)[D], double (&h)[D]) {
-    // h = cvec - Cm x
+    // h = cvec - T x   (DIAG: T = diag(prm[D..2D)); otherwise T upper-triangular, row-major at prm[D..D+D*D))
     if (DIAG) {
 #pragma unroll
         for (int k = 0; k < D; ++k) h[k] = fma(-prm[D + k], x[k], prm[k]);
@@ -47,11 +50,10 @@ __device__ __forceinline__ void pair_transform(const double* __restrict__ prm, c
     }
 }
 
-// WPS: minimum waves per SIMD the register allocator must leave room for (launch bound); 0 = compiler's choice.
 // NS2: second moments are accumulated for the first NS2 dimensions only (DIAG && GRAD).  In the rollout the
 //      input variance of the action dimensions is a constant, so dT/ds_k is not needed for k >= state_dim.
-template <int D, bool DIAG, bool GRAD, int TB, int WPS = 0, int NS2 = D>
-__global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void gpmpc_pair_kernel(PairArgs A) {
+template <int D, bool DIAG, bool GRAD, int TB, int NS2 = D>
+__global__ __launch_bounds__(256) void gpmpc_pair_kernel(PairArgs A) {
     using TR = PairTraits<D, DIAG, GRAD>;
     constexpr int DP = TR::DP, NM = TR::NM;
     __shared__ __attribute__((aligned(16))) double s_hj[TB * 64 * DP];
@@ -60,32 +62,30 @@ __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void gpmpc_pair_kernel(Pa
     gpmpc_exp_table_to_lds(s_tab);                        // visible after the first barrier below
 
     // XCD-aware decode of the flat grid.  Workgroups are dealt round-robin over the 8 XCDs (each with its own
-    // L2), so the XCD label L % 8 picks the (tile, GP) unit and all trajectory groups of a unit run back to
+    // L2), so the XCD label L % 8 picks the work item (unit, tile) and all trajectory groups of an item run back to
     // back on ONE XCD: every M tile is pulled through a single L2 instead of all eight.  Bijective for any
-    // unit count (the ragged tail falls back to the plain order).  Placement only affects speed.
-    int bg, tile, a;
+    // item count (the ragged tail falls back to the plain order).  Placement only affects speed.
+    int bg, wi;
     {
-        const int groups = (A.B + TB - 1) / TB, units = A.ntiles * A.ds;
-        const int L = blockIdx.x, full = (units >> 3) << 3;
-        int u;
-        if (L < full * groups) { const int q = L >> 3; u = (q / groups) * 8 + (L & 7); bg = q % groups; }
-        else { const int Lt = L - full * groups; u = full + Lt / groups; bg = Lt % groups; }
-        a = u / A.ntiles;
-        tile = u - a * A.ntiles;
+        const int groups = (A.B + TB - 1) / TB, items = A.nwork;
+        const int L = blockIdx.x, full = (items >> 3) << 3;
+        if (L < full * groups) { const int q = L >> 3; wi = (q / groups) * 8 + (L & 7); bg = q % groups; }
+        else { const int Lt = L - full * groups; wi = full + Lt / groups; bg = Lt % groups; }
     }
+    const int unit = A.work[wi * 4 + 0], i0 = A.work[wi * 4 + 1], j0 = A.work[wi * 4 + 2], j1 = A.work[wi * 4 + 3];
+    const bool tri = unit < A.ntri;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int i0 = A.tiles[tile * 3 + 0], j0 = A.tiles[tile * 3 + 1], j1 = A.tiles[tile * 3 + 2];
     const int Np = A.Np;
     const int iw0 = i0 + w * 64;            // first row of this wave
     const bool active = iw0 < Np;           // wave-uniform (Np is a multiple of 64)
     const int i = iw0 + lane;
 
-    const double* __restrict__ prm[TB];
+    const double* __restrict__ prm[TB];     // row-side parameters; the column side sits jside_off doubles further
 #pragma unroll
     for (int tb = 0; tb < TB; ++tb) {
         int b = bg * TB + tb;
         b = b < A.B ? b : A.B - 1;          // pad the last group with a duplicate (its result is not written)
-        prm[tb] = A.pp + ((size_t)b * A.ds + a) * A.pps;
+        prm[tb] = A.pp + ((size_t)b * A.nunits + unit) * A.pps;
     }
 
     double hi[TB][D];
@@ -108,11 +108,11 @@ __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void gpmpc_pair_kernel(Pa
 #pragma unroll
         for (int m = 0; m < NM; ++m) acc[tb][m] = 0.0;
 
-    const double* __restrict__ Ma = A.M + (size_t)a * Np * Np;
+    const double* __restrict__ Ma = A.M + (size_t)unit * Np * Np;
 
     for (int jc = j0; jc < j1; jc += 64) {
         __syncthreads();
-        // stage h_j for this chunk: 64 columns x TB trajectories
+        // stage q_j for this chunk: 64 columns x TB trajectories
         for (int idx = tid; idx < 64 * TB; idx += blockDim.x) {
             const int jj = idx & 63, tb = idx >> 6;
             double x[D], h[D];
@@ -122,13 +122,13 @@ __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void gpmpc_pair_kernel(Pa
             const double* p = prm[0];
 #pragma unroll
             for (int t2 = 1; t2 < TB; ++t2) p = (tb == t2) ? prm[t2] : p;
-            pair_transform<D, DIAG>(p, x, h);
+            pair_transform<D, DIAG>(p + A.jside_off, x, h);
 #pragma unroll
             for (int k = 0; k < D; ++k) s_hj[(tb * 64 + jj) * DP + k] = h[k];
         }
         __syncthreads();
-        // rows of this wave all below the chunk's columns -> every M_ij of the chunk is zero
-        if (!active || jc + 63 < iw0) continue;
+        // symmetric unit: rows of this wave all below the chunk's columns -> every M_ij of the chunk is zero
+        if (!active || (tri && jc + 63 < iw0)) continue;
 
         const double* __restrict__ Mc = Ma + (size_t)jc * Np + i;
 #pragma unroll 1
@@ -189,15 +189,15 @@ __global__ __launch_bounds__(256, (WPS > 0 ? WPS : 1)) void gpmpc_pair_kernel(Pa
         if (b < A.B) {
             double s = 0.0;
             for (int ww = 0; ww < nw; ++ww) s += s_red[(ww * TB + tb) * NM + m];
-            A.part[(((size_t)b * A.ds + a) * A.ntiles + tile) * A.nm + m] = s;
+            A.part[((size_t)b * A.nwork + wi) * A.nm + m] = s;
         }
     }
 }
 
-template <int D, bool DIAG, bool GRAD, int TB, int WPS = 0, int NS2 = D>
+template <int D, bool DIAG, bool GRAD, int TB, int NS2 = D>
 static int launch_pair_one(int waves, const PairArgs& a, hipStream_t s) {
-    dim3 grid(((a.B + TB - 1) / TB) * a.ntiles * a.ds), block(64 * waves);
-    hipLaunchKernelGGL((gpmpc_pair_kernel<D, DIAG, GRAD, TB, WPS, NS2>), grid, block, 0, s, a);
+    dim3 grid(((a.B + TB - 1) / TB) * a.nwork), block(64 * waves);
+    hipLaunchKernelGGL((gpmpc_pair_kernel<D, DIAG, GRAD, TB, NS2>), grid, block, 0, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { gpmpc_set_error("pair kernel launch", e); return GPMPC_E_LAUNCH; }
     return GPMPC_OK;
@@ -207,8 +207,8 @@ template <int D>
 int gpmpc_launch_pair_D(bool diag, bool grad, int tb, int waves, const PairArgs& a, hipStream_t s) {
     if (a.nm != gpmpc_num_moments(D, diag, grad)) return GPMPC_E_ARG;
     if (diag && grad && tb == 2 && a.ns2 < D) {   // the rollout hot path: skip the action dims' second moments
-        if (D >= 2 && a.ns2 == D - 1) return launch_pair_one<D, true, true, 2, 0, (D >= 2 ? D - 1 : D)>(waves, a, s);
-        if (D >= 3 && a.ns2 == D - 2) return launch_pair_one<D, true, true, 2, 0, (D >= 3 ? D - 2 : D)>(waves, a, s);
+        if (D >= 2 && a.ns2 == D - 1) return launch_pair_one<D, true, true, 2, (D >= 2 ? D - 1 : D)>(waves, a, s);
+        if (D >= 3 && a.ns2 == D - 2) return launch_pair_one<D, true, true, 2, (D >= 3 ? D - 2 : D)>(waves, a, s);
     }
 #define GPMPC_PAIR_CASE(DG, GR)                                                  \
     if (diag == DG && grad == GR) {                                              \

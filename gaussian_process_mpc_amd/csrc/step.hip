@@ -30,9 +30,10 @@ struct RollArgs {
     // workspace
     double* pp;    // [B][ds][pps]   pair-kernel parameters of the current step
     double* sp;    // [2][B][ds][sps] per-GP scalars of step t at [t & 1], kept for the finish phase of the next head launch
-    double* part;  // [B][ds][ntiles][nm]
+    double* part;  // [B][nwork][nm]; work items of GP a are [ustart[a], ustart[a+1])
+    const int* ustart;
     double* jac;   // [B][H][2ds][2ds+da] or null
-    int pps, sps, ntiles, nm, grad;
+    int pps, sps, nwork, nm, grad;
     // outputs of the tail
     double* out_cost; double* out_grad;
     gpmpc_cost_params cost;
@@ -49,9 +50,9 @@ __device__ static void finish_step(const RollArgs& A, int b, int t, int own, dou
     const int ds = A.ds, D = A.D, nm = A.nm;
     for (int idx = threadIdx.x; idx < ds * nm; idx += blockDim.x) {
         const int a = idx / nm, m = idx - a * nm;
-        const double* p = A.part + (((size_t)b * ds + a) * A.ntiles) * nm + m;
+        const double* p = A.part + (size_t)b * A.nwork * nm + m;
         double s = 0.0;
-        for (int tl = 0; tl < A.ntiles; ++tl) s += p[(size_t)tl * nm];
+        for (int wi = A.ustart[a]; wi < A.ustart[a + 1]; ++wi) s += p[(size_t)wi * nm];
         s_z[idx] = s;
     }
     __syncthreads();
@@ -379,26 +380,20 @@ extern "C" int gpmpc_pair_kernel_time(double* total_ms, long long* launches, int
     return GPMPC_OK;
 }
 
-// mfma_variant >= 0 selects the v2 kernel (pair_kernel_mfma.h), otherwise v1 (pair_kernel.h)
-static int launch_any_pair(int D, bool diag, bool grad, int tb, int waves, int mfma_variant, const PairArgs& a, hipStream_t s) {
-    if (mfma_variant >= 0) return gpmpc_launch_pair_mfma(D, mfma_variant, a, s);
-    return gpmpc_launch_pair(D, diag, grad, tb, waves, a, s);
-}
-
-int gpmpc_timed_pair(int D, bool diag, bool grad, int tb, int waves, const PairArgs& a, hipStream_t s, int mfma_variant) {
-    if (!g_timing) return launch_any_pair(D, diag, grad, tb, waves, mfma_variant, a, s);
+int gpmpc_timed_pair(int D, bool diag, bool grad, int tb, int waves, const PairArgs& a, hipStream_t s) {
+    if (!g_timing) return gpmpc_launch_pair(D, diag, grad, tb, waves, a, s);
     if (g_npending == 4096) drain_events();
     EvPair ev;
     GPMPC_HIP(hipEventCreate(&ev.a));
     GPMPC_HIP(hipEventCreate(&ev.b));
     GPMPC_HIP(hipEventRecord(ev.a, s));
-    int rc = launch_any_pair(D, diag, grad, tb, waves, mfma_variant, a, s);
+    int rc = gpmpc_launch_pair(D, diag, grad, tb, waves, a, s);
     GPMPC_HIP(hipEventRecord(ev.b, s));
     g_pending[g_npending++] = ev;
     return rc;
 }
 
-struct RollPlan { int tiling, tb, waves, ntiles, nm, pps, sps, mfma; size_t off_pp, off_sp, off_part, off_jac, off_means, off_vars, total; };
+struct RollPlan { int tiling, tb, waves, nwork, nm, pps, sps; size_t off_pp, off_sp, off_part, off_jac, off_means, off_vars, total; };
 
 static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag, RollPlan* r) {
     const int D = p->D;
@@ -407,22 +402,9 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     if (!diag && grad && r->tb > 2) r->tb = 2;
     const long groups = (B + r->tb - 1) / r->tb;
     // big workgroups once they already oversubscribe the 256 CUs; one-wave tiles otherwise
-    r->tiling = (groups * p->tilings[0].ntiles * p->ds >= 1024) ? 0 : 1;
-    // v2 (MFMA moment accumulation) for the rollout hot path when the grid is large enough for 256-thread tiles.
-    // GPMPC_PAIR_VARIANT: -1 forces v1, 0/1/2 force a v2 shape (bench / A-B use).
-    r->mfma = -1;
-    // (measured slower than v1/TB=2 because fp64 MFMA and fp64 VALU share the same issue capacity on MI355X:
-    //  profiles/r01/ubench_mfma_f64_overlap.txt -- so it is opt-in only)
-    if (const char* ev = getenv("GPMPC_PAIR_VARIANT")) {
-        const int v = atoi(ev);
-        if (v < 0) r->mfma = -1;
-        else if (diag && grad && D <= 7 && v <= 2) r->mfma = v;
-    }
-    if (r->mfma == 0) { r->tb = 4; r->tiling = 2; }
-    if (r->mfma == 1) { r->tb = 2; r->tiling = 0; }
-    if (r->mfma == 2) { r->tb = 1; r->tiling = 0; }
-    r->waves = p->tilings[r->tiling].waves;
-    r->ntiles = p->tilings[r->tiling].ntiles;
+    r->tiling = (groups * p->wl[0][0].nwork >= 1024) ? 0 : 1;
+    r->waves = p->wl[0][r->tiling].waves;
+    r->nwork = p->wl[0][r->tiling].nwork;
     r->nm = gpmpc_num_moments(D, diag, grad);
     r->pps = D + D * D;
     r->sps = sps_of(D);
@@ -430,7 +412,7 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     auto take = [&](size_t n) { size_t o = off; off += (n * sizeof(double) + 255) & ~(size_t)255; return o; };
     r->off_pp = take((size_t)B * p->ds * r->pps);
     r->off_sp = take((size_t)2 * B * p->ds * r->sps);
-    r->off_part = take((size_t)B * p->ds * r->ntiles * r->nm);
+    r->off_part = take((size_t)B * r->nwork * r->nm);
     r->off_jac = take(grad ? (size_t)B * H * 2 * p->ds * (2 * p->ds + p->da) : 0);
     r->off_means = take((size_t)B * (H + 1) * p->ds);
     r->off_vars = take((size_t)B * (H + 1) * p->ds);
@@ -470,12 +452,14 @@ extern "C" int gpmpc_rollout(const gpmpc_pack* p, int B, int H, const double* x0
     A.vars = out_vars ? out_vars : (double*)(ws + r.off_vars);
     A.pp = (double*)(ws + r.off_pp); A.sp = (double*)(ws + r.off_sp); A.part = (double*)(ws + r.off_part);
     A.jac = grad ? (double*)(ws + r.off_jac) : nullptr;
-    A.pps = r.pps; A.sps = r.sps; A.ntiles = r.ntiles; A.nm = r.nm; A.grad = grad ? 1 : 0;
+    A.pps = r.pps; A.sps = r.sps; A.nwork = r.nwork; A.nm = r.nm; A.grad = grad ? 1 : 0;
+    A.ustart = p->wl[0][r.tiling].ustart_dev;
     A.out_cost = out_cost; A.out_grad = out_grad; A.cost = *cost;
 
     PairArgs P;
-    P.M = p->M; P.XT = p->XT; P.pp = A.pp; P.part = A.part; P.tiles = p->tilings[r.tiling].tiles_dev;
-    P.Np = p->Np; P.ds = p->ds; P.B = B; P.ntiles = r.ntiles; P.pps = r.pps; P.nm = r.nm; P.ns2 = p->ds;
+    P.M = p->M; P.XT = p->XT; P.pp = A.pp; P.part = A.part; P.work = p->wl[0][r.tiling].work_dev;
+    P.Np = p->Np; P.B = B; P.nunits = p->ds; P.nwork = r.nwork; P.pps = r.pps; P.nm = r.nm;
+    P.jside_off = 0; P.ntri = p->ds; P.ns2 = p->ds;
 
     for (int t = 1; t <= H; ++t) {
         switch (p->D) {
@@ -489,7 +473,7 @@ extern "C" int gpmpc_rollout(const gpmpc_pack* p, int B, int H, const double* x0
             case 8: launch_head<8>(A, t, s); break;
             default: return GPMPC_E_ARG;
         }
-        int rc = gpmpc_timed_pair(p->D, true, grad, r.tb, r.waves, P, s, r.mfma);
+        int rc = gpmpc_timed_pair(p->D, true, grad, r.tb, r.waves, P, s);
         if (rc != GPMPC_OK) return rc;
     }
     const size_t lds = sizeof(double) * ((size_t)GPMPC_TAIL_WORKERS * p->ds * 2 * p->ds + (size_t)(H + 1) * (1 + 2 * p->ds));

@@ -78,6 +78,7 @@ class GPPack:
         lib().gpmpc_pack_dims(self._h, ctypes.byref(n), ctypes.byref(npad), ctypes.byref(ds), ctypes.byref(da))
         self.Np = npad.value
         self._ws = None
+        self.fullcov = False
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -88,6 +89,14 @@ class GPPack:
             except Exception:
                 pass
             self._h = None
+
+    def enable_fullcov(self):
+        """Allocate the cross-covariance weight matrices (one N x N per GP pair): full-covariance rollout and
+        analytic cross-covariance Jacobians."""
+        with torch.cuda.device(self.device):
+            check(lib().gpmpc_pack_enable_fullcov(self._h, stream_ptr()), "gpmpc_pack_enable_fullcov")
+        self.fullcov = True
+        return self
 
     @property
     def handle(self):
@@ -161,12 +170,15 @@ def moment_match(pack, u, S, want_cov=False, want_grad=False, bug_compatible=Fal
         out["l"] = e(nq, ds, pack.N)
     if want_grad:
         out.update(dmean_du=e(nq, ds, D), dmean_dS=e(nq, ds, D, D), dvar_du=e(nq, ds, D), dvar_dS=e(nq, ds, D, D))
+        if want_cov and pack.fullcov and not bug_compatible:
+            out.update(dcov_du=e(nq, ds, ds, D), dcov_dS=e(nq, ds, ds, D, D))
     nbytes = lib().gpmpc_moment_match_workspace_bytes(pack.handle, nq)
     ws = pack.workspace(nbytes)
     with torch.cuda.device(dev):
         check(lib().gpmpc_moment_match(pack.handle, nq, ptr(u), ptr(S), flags, ptr(out["mean"]), ptr(out["var"]),
                                        ptr(out.get("cov")), ptr(out.get("l")), ptr(out.get("dmean_du")), ptr(out.get("dmean_dS")),
                                        ptr(out.get("dvar_du")), ptr(out.get("dvar_dS")),
+                                       ptr(out.get("dcov_du")), ptr(out.get("dcov_dS")),
                                        ctypes.c_void_p(ws.data_ptr()), ws.numel(), stream_ptr()), "gpmpc_moment_match")
     return out
 

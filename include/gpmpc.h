@@ -88,6 +88,11 @@ int gpmpc_pack_build_beta(gpmpc_pack* pack, const double* X_dev, const double* b
                           const double* Ky_inv_dev, const double* lambdas_host,
                           const double* sigma_f_host, void* stream);
 
+/* Allocate and maintain the cross-covariance weight matrices (one N x N matrix per GP pair a < b): needed by
+ * gpmpc_rollout_fullcov and by the analytic cross-covariance Jacobians of gpmpc_moment_match.  Without it
+ * cross-covariances are evaluated by a direct N^2 kernel, forward only. */
+int gpmpc_pack_enable_fullcov(gpmpc_pack* pack, void* stream);
+
 /* Inspection for tests / bindings.  gpmpc_pack_export copies into caller buffers (either may be NULL):
  * beta_out dev [ds][n_padded] (beta_a = Ky_inv_a y_a, zero padded); weights_out dev
  * [ds][n_padded][n_padded], element (i <= j) of M_a at [a][j][i], zero elsewhere. */
@@ -106,14 +111,17 @@ int gpmpc_pack_export(const gpmpc_pack* pack, double* beta_out, double* weights_
  *            reference's transposed cross term)
  *   out_l    dev [nq][ds][N] or NULL: the vector l of mean_prop_torch's second return value
  *            (l_i = c_m exp(-1/2 v_i^T B v_i), src/tools/uncertainty_prop.py:335-336)
- *   with GPMPC_WANT_GRAD (all four non-NULL):
+ *   with GPMPC_WANT_GRAD (the first four non-NULL):
  *     dmean_du dev [nq][ds][D], dmean_dS dev [nq][ds][D][D] (symmetrised),
- *     dvar_du  dev [nq][ds][D], dvar_dS  dev [nq][ds][D][D] (symmetrised)
+ *     dvar_du  dev [nq][ds][D], dvar_dS  dev [nq][ds][D][D] (symmetrised),
+ *     dcov_du  dev [nq][ds][ds][D], dcov_dS dev [nq][ds][ds][D][D] or both NULL: Jacobians of the full covariance
+ *              (consistent form only; needs gpmpc_pack_enable_fullcov, else GPMPC_E_STATE)
  * ------------------------------------------------------------------------- */
 size_t gpmpc_moment_match_workspace_bytes(const gpmpc_pack* pack, int nq);
 int gpmpc_moment_match(const gpmpc_pack* pack, int nq, const double* u_dev, const double* S_dev,
                        unsigned flags, double* out_mean, double* out_var, double* out_cov, double* out_l,
                        double* dmean_du, double* dmean_dS, double* dvar_du, double* dvar_dS,
+                       double* dcov_du, double* dcov_dS,
                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------

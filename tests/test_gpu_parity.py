@@ -207,3 +207,35 @@ def test_gradient_finite_difference(G):
         fd = (G.rollout(pack, pb["x0"], Up, cost, want_grad=False)["cost"].item() -
               G.rollout(pack, pb["x0"], Um, cost, want_grad=False)["cost"].item()) / (2 * eps)
         assert abs(fd - g[j, 0]) < 1e-5 * max(1.0, abs(fd)), (j, fd, g[j, 0])
+
+
+@pytest.mark.parametrize("k", range(6))
+def test_cross_covariance_pair_kernel_and_jacobians(G, golden, k):
+    """Consistent-form cross-covariance through the pair kernel (Gaussian-product weights) equals the direct N^2
+    kernel and the reference's numpy loop; its analytic Jacobians equal autograd of the corrected oracle."""
+    from oracle import gpmpc_oracle as O
+    z = golden("g2_adversarial.npz")
+    p = f"c{k}_"
+    packu = G.GPPack(z[p + "X"], np.stack([z[p + "y1"], z[p + "y1"]], axis=1),
+                     np.stack([z[p + "unit_Kinv1"], z[p + "unit_Kinv2"]]),
+                     np.stack([z[p + "lam1"], z[p + "lam2"]]), np.ones(2))
+    direct = G.moment_match(packu, z[p + "u"], z[p + "S"], want_cov=True)["cov"][0].cpu().numpy()
+    packu.enable_fullcov()
+    r = G.moment_match(packu, z[p + "u"], z[p + "S"], want_cov=True, want_grad=True)
+    cov = r["cov"][0].cpu().numpy()
+    np.testing.assert_allclose(cov[0, 1], z[p + "unit_cov_numpy"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(cov, direct, rtol=1e-7, atol=1e-10)
+    assert cov[0, 1] == cov[1, 0]
+    # Jacobians of Cov[f1, f2] against autograd through the oracle's corrected covariance_prop
+    T = lambda a: torch.as_tensor(a, dtype=torch.float64)          # noqa: E731
+    u = T(z[p + "u"]).requires_grad_(True)
+    S = T(z[p + "S"]).requires_grad_(True)
+    X, y = T(z[p + "X"]), T(z[p + "y1"])
+    m1, b1, _ = O.mean_prop(T(z[p + "unit_Kinv1"]), T(z[p + "lam1"]), u, S, X, y)
+    m2, b2, _ = O.mean_prop(T(z[p + "unit_Kinv2"]), T(z[p + "lam2"]), u, S, X, y)
+    c = O.covariance_prop(T(z[p + "lam1"]), T(z[p + "lam2"]), u, S, X, m1, m2, b1, b2, bug_compatible=False)
+    dc_du, dc_dS = torch.autograd.grad(c, (u, S))
+    sym = lambda A: 0.5 * (A + A.T)                                 # noqa: E731
+    np.testing.assert_allclose(r["dcov_du"][0, 0, 1].cpu().numpy(), dc_du.numpy(), rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(r["dcov_dS"][0, 0, 1].cpu().numpy(), sym(dc_dS.numpy()), rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(r["dcov_du"][0, 0, 0].cpu().numpy(), r["dvar_du"][0, 0].cpu().numpy(), rtol=0, atol=0)

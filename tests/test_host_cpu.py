@@ -73,7 +73,7 @@ def test_abi_argument_validation_without_device(built):
     assert lib.gpmpc_pack_create(None, 10, 2, 1) == -1
     assert lib.gpmpc_pack_destroy(None) == 0
     assert lib.gpmpc_rollout(None, 1, 1, None, None, None, 0, None, None, None, None, None, 0, None) == -1
-    assert lib.gpmpc_moment_match(None, 1, None, None, 0, *([None] * 8), None, 0, None) == -1
+    assert lib.gpmpc_moment_match(None, 1, None, None, 0, *([None] * 10), None, 0, None) == -1
     assert lib.gpmpc_rollout_workspace_bytes(None, 1, 1, 0) == 0
     assert lib.gpmpc_predict_workspace_bytes(100, 3, 7) >= 2 * 7 * 100 * 8
     assert lib.gpmpc_matvec(0, 1, None, None, None, None) == -1
