@@ -62,6 +62,8 @@ SIGNATURES = {
     "gpmpc_cost": (_i, [_i, _i, _i, _i, ctypes.POINTER(CostParamsC), _vp, _vp, _vp, _vp, _vp]),
     "gpmpc_rollout_workspace_bytes": (_sz, [_vp, _i, _i, _u]),
     "gpmpc_rollout": (_i, [_vp, _i, _i, _vp, _vp, ctypes.POINTER(CostParamsC), _u, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "gpmpc_rollout_fullcov_workspace_bytes": (_sz, [_vp, _i, _i, _u]),
+    "gpmpc_rollout_fullcov": (_i, [_vp, _i, _i, _vp, _vp, ctypes.POINTER(CostParamsC), _u, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gpmpc_timing_enable": (_i, [_i]),
     "gpmpc_pair_kernel_time": (_i, [_dp, ctypes.POINTER(ctypes.c_longlong), _i]),
     "gpmpc_matvec": (_i, [_i, _i, _vp, _vp, _vp, _vp]),

@@ -153,6 +153,36 @@ def rollout(pack, x0, U, cost, want_grad=True, want_traj=True):
     return out
 
 
+def rollout_fullcov(pack, x0, U, cost, want_grad=True):
+    """Like :func:`rollout` but propagating the FULL state covariance (C ABI ``gpmpc_rollout_fullcov``;
+    BASELINE config 5).  Returns cost (B,), grad (B,H,da), means (B,H+1,ds), covs (B,H+1,ds,ds)."""
+    dev = pack.device
+    if not pack.fullcov:
+        pack.enable_fullcov()
+    U = _dev(U, dev)
+    if U.dim() == 2:
+        U = U.unsqueeze(0)
+    B, H, da = U.shape
+    x0 = _dev(x0, dev).reshape(-1, pack.ds)
+    if x0.shape[0] == 1 and B > 1:
+        x0 = x0.expand(B, pack.ds).contiguous()
+    if da != pack.da or x0.shape[0] != B or cost.ds != pack.ds or cost.da != pack.da:
+        raise ValueError("shape mismatch between pack, x0, U and cost parameters")
+    flags = _lib.WANT_GRAD if want_grad else 0
+    e = lambda *shape: torch.empty(shape, dtype=torch.float64, device=dev)  # noqa: E731
+    out = {"cost": e(B), "means": e(B, H + 1, pack.ds), "covs": e(B, H + 1, pack.ds, pack.ds)}
+    if want_grad:
+        out["grad"] = e(B, H, da)
+    nbytes = lib().gpmpc_rollout_fullcov_workspace_bytes(pack.handle, B, H, flags)
+    ws = pack.workspace(nbytes)
+    with torch.cuda.device(dev):
+        check(lib().gpmpc_rollout_fullcov(pack.handle, B, H, ptr(x0), ptr(U), ctypes.byref(cost.c), flags,
+                                          ptr(out["means"]), ptr(out["covs"]), ptr(out["cost"]), ptr(out.get("grad")),
+                                          ctypes.c_void_p(ws.data_ptr()), ws.numel(), stream_ptr()),
+              "gpmpc_rollout_fullcov")
+    return out
+
+
 def moment_match(pack, u, S, want_cov=False, want_grad=False, bug_compatible=False, want_l=False):
     """Exact moment matching of all ds GPs for nq Gaussian inputs N(u, S) with full S
     (C ABI ``gpmpc_moment_match``).  u: (nq, D) or (D,); S: (nq, D, D) or (D, D)."""

@@ -167,6 +167,21 @@ int gpmpc_rollout(const gpmpc_pack* pack, int B, int H, const double* x0_dev, co
                   double* out_means, double* out_vars, double* out_cost, double* out_grad,
                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Full-covariance form of the hot path (BASELINE config 5): the state distribution carries the whole ds x ds
+ * covariance; off-diagonal terms are the exact cross-covariances Cov[f_a, f_b] (covariance_prop_torch,
+ * src/tools/uncertainty_prop.py:402-465, consistent form).  The reference's rollout propagates variances only
+ * (src/dynamics.py:184-189 TODO); this is its extension to full Sigma with the same cost (src/mpc.py:156-200) and an
+ * analytic gradient.  Needs gpmpc_pack_enable_fullcov (GPMPC_E_STATE otherwise).
+ *   out_means dev [B][H+1][ds]; out_covs dev [B][H+1][ds][ds] (both required);
+ *   out_cost dev [B]; out_grad dev [B][H][da] (with GPMPC_WANT_GRAD).
+ * ------------------------------------------------------------------------- */
+size_t gpmpc_rollout_fullcov_workspace_bytes(const gpmpc_pack* pack, int B, int H, unsigned flags);
+int gpmpc_rollout_fullcov(const gpmpc_pack* pack, int B, int H, const double* x0_dev, const double* U_dev,
+                          const gpmpc_cost_params* cost_host, unsigned flags,
+                          double* out_means, double* out_covs, double* out_cost, double* out_grad,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
 /* Kernel-level timing of the dominant (pair) kernel for bench.py: when enabled, every
  * gpmpc_rollout brackets its pair-kernel launches with HIP events on the launch stream.
  * gpmpc_pair_kernel_time returns accumulated milliseconds and launch count since the last reset

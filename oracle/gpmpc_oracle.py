@@ -256,6 +256,52 @@ def forward_propagate(gp: GPBundle, horizon, x0, U, mode="faithful"):
     return means, covs
 
 
+def forward_propagate_fullcov(gp: GPBundle, horizon, x0, U, mode="o2"):
+    """Extension oracle for BASELINE config 5: the rollout of forward_propagate (src/dynamics.py:126-191) with the
+    off-diagonal covariances the reference leaves as a TODO (:184), filled in with covariance_prop_torch in its
+    consistent form (src/tools/uncertainty_prop.py:402-465; the reference's own numpy covariance_prop :187-237)."""
+    means = [_t(x0)]
+    covs = [INIT_STATE_VAR * torch.eye(gp.ds, dtype=F64)]
+    for t in range(1, horizon + 1):
+        u = torch.cat((means[t - 1], U[t - 1, :]))
+        S = torch.zeros((gp.D, gp.D), dtype=F64)
+        S[:gp.ds, :gp.ds] = covs[t - 1]
+        S = S + torch.diag(torch.cat((torch.zeros(gp.ds, dtype=F64), torch.full((gp.da,), ACTION_NOISE_VAR, dtype=F64))))
+        mu_t, beta_t = [], []
+        rows = [[None] * gp.ds for _ in range(gp.ds)]
+        for a in range(gp.ds):
+            m, beta, _ = mean_prop(gp.Ky_inv[a], gp.lambdas[a], u, S, gp.X, gp.Y[:, a], gp.sigma_f[a])
+            rows[a][a] = variance_prop(gp.Ky_inv[a], gp.lambdas[a], u, S, gp.X, m, beta, gp.sigma_f[a], mode)
+            mu_t.append(m)
+            beta_t.append(beta)
+        for a in range(gp.ds):
+            for b in range(a + 1, gp.ds):
+                c = covariance_prop(gp.lambdas[a], gp.lambdas[b], u, S, gp.X, mu_t[a], mu_t[b], beta_t[a], beta_t[b],
+                                    gp.sigma_f[a], gp.sigma_f[b], bug_compatible=False)
+                rows[a][b] = c
+                rows[b][a] = c
+        means.append(torch.stack(mu_t))
+        covs.append(torch.stack([torch.stack(r) for r in rows]))
+    return means, covs
+
+
+def objective_and_gradient_fullcov(gp, horizon, x0, U, x_ref, u_ref, Q, R, gamma, R_delta=None, last_u=None,
+                                   mode="o2", want_grad=True):
+    """cost_torch (src/mpc.py:156-200) on the full-covariance rollout, gradient by autograd."""
+    Ut = _t(U).clone().reshape(horizon, -1).requires_grad_(want_grad)
+    means, covs = forward_propagate_fullcov(gp, horizon, x0, Ut, mode)
+    if gamma == 0:
+        c = cost_risk_neutral(means, Ut, covs, _t(x_ref), _t(u_ref), Q, R, R_delta, last_u)
+    else:
+        c = cost(means, Ut, covs, _t(x_ref), _t(u_ref), Q, R, gamma, R_delta, last_u)
+    out = {"cost": float(c.item()), "means": torch.stack([m.detach() for m in means]).numpy(),
+           "covs": torch.stack([s.detach() for s in covs]).numpy()}
+    if want_grad:
+        c.backward()
+        out["grad"] = Ut.grad.detach().numpy().copy()
+    return out
+
+
 def cost(means, U, covs, x_ref, u_ref, Q, R, gamma, R_delta=None, last_u=None):
     """RiskSensitiveMPC.cost_torch (src/mpc.py:156-200).  gamma != 0."""
     Q, R = _t(Q), _t(R)
