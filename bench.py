@@ -52,7 +52,7 @@ def build_kinv(g, pb, device):
     return out
 
 
-def cpu_baseline(pb, H_sample, reps=2):
+def cpu_baseline(pb, H_sample, reps=2, fullcov=False):
     """The reference CPU path (faithful-op restatement in oracle/, checked against the reference by
     tests/test_oracle_golden.py) timed on this box's host cores on a bounded sample: ONE trajectory,
     H_sample of the H steps, objective + gradient; scaled linearly to H steps (per-step cost is constant)."""
@@ -64,8 +64,8 @@ def cpu_baseline(pb, H_sample, reps=2):
         best = float("inf")
         for r in range(reps + 1):
             t0 = time.perf_counter()
-            O.objective_and_gradient(gp, H_sample, pb["x0"][0], pb["U"][0][:H_sample], pb["x_ref"], pb["u_ref"],
-                                     pb["Q"], pb["R"], -1.0, mode=mode)
+            fn = O.objective_and_gradient_fullcov if fullcov else O.objective_and_gradient
+            fn(gp, H_sample, pb["x0"][0], pb["U"][0][:H_sample], pb["x_ref"], pb["u_ref"], pb["Q"], pb["R"], -1.0, mode=mode)
             dt = time.perf_counter() - t0
             if r > 0:
                 best = min(best, dt)
@@ -128,8 +128,15 @@ def main():
     cost = g.CostParams(cfg["gamma"], pb["Q"], pb["R"])
     want_grad = not args.forward_only
 
+    fullcov = args.config == "C5"          # config 5: full covariance propagation
+    if fullcov:
+        pack.enable_fullcov()
+
     def step():
-        r = g.rollout(pack, x0, U, cost, want_grad=want_grad, want_traj=False)
+        if fullcov:
+            r = g.rollout_fullcov(pack, x0, U, cost, want_grad=want_grad)
+        else:
+            r = g.rollout(pack, x0, U, cost, want_grad=want_grad, want_traj=False)
         if world > 1:
             return gather_results(r["cost"], r.get("grad"), dist)
         return r["cost"], r.get("grad")
@@ -165,9 +172,13 @@ def main():
         rollouts = B * world * args.steps
         value = rollouts / elapsed
         pairs_per_launch = B * ds * N * (N + 1) / 2                 # one horizon step, all trajectories and GPs
+        if fullcov:                                                 # + ds(ds-1)/2 cross units over all N^2 ordered pairs
+            pairs_per_launch += B * (ds * (ds - 1) / 2) * N * N
         fl, slots = pair_flops(D)
         if not want_grad:
             fl, slots = 2 * D + 37, D + 22
+        if fullcov and want_grad:          # full second moments: D(D+1)/2 instead of D accumulations per pair
+            fl, slots = 4 * D + 37 + D * (D - 1), 2 * D + 23 + D * (D - 1) // 2
         launch_s = (ms.value / max(nl.value, 1)) * 1e-3
         achieved = pairs_per_launch * fl / launch_s / 1e12
         out = {
@@ -187,13 +198,13 @@ def main():
                 "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
                 # HBM bytes per launch from the PMC passes of the same command (FETCH_SIZE x 2 + WRITE_SIZE,
                 # gfx950 correction): profiles/r01/pmc_c3_v1c.txt.  Only measured for the default C3 workload.
-                "traffic": 7.6e7 if (args.config == "C3" and B == 256 and want_grad) else None,
+                "traffic": 7.6e7 if (args.config == "C3" and B == 256 and want_grad and not fullcov) else None,
                 "traffic_source": "profiles/r01/pmc_c3_v1c.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, x2 read correction)",
                 "algorithmic_flops_per_pair": fl, "algorithmic_slots_per_pair": slots,
                 "valu_slot_frac": pairs_per_launch * slots / launch_s / 39.3e12,
                 "pairs_per_launch": pairs_per_launch, "avg_launch_ms": launch_s * 1e3, "launches": nl.value,
-                "hbm_algorithmic_GBs": (8 * ds * N * (N + 1) / 2) / launch_s / 1e9,
-                "hbm_frac": (8 * ds * N * (N + 1) / 2) / launch_s / 1e9 / HBM_PEAK_GBS,
+                "hbm_algorithmic_GBs": (8 * (ds * N * (N + 1) / 2 + (ds * (ds - 1) / 2 * N * N if fullcov else 0))) / launch_s / 1e9,
+                "hbm_frac": (8 * (ds * N * (N + 1) / 2 + (ds * (ds - 1) / 2 * N * N if fullcov else 0))) / launch_s / 1e9 / HBM_PEAK_GBS,
             },
             "pack_build_ms": pack_ms,
         }
@@ -202,7 +213,7 @@ def main():
             # the GPU box exposes every host core but grants a 16-core share per GPU: more threads than
             # that only oversubscribe (measured: 256 threads are >100x slower than 16)
             torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
-            res, _ = cpu_baseline(pb, H_s, reps=1)
+            res, _ = cpu_baseline(pb, H_s, reps=1, fullcov=fullcov)
             out["cpu_baseline"] = {
                 "value": res["faithful"], "unit": "rollouts/s", "cores": torch.get_num_threads(), "kind": "port",
                 "sample": f"1 trajectory, {H_s} of {H} horizon steps, objective+gradient, faithful-op restatement "

@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from .gpr import GaussianProcessRegression
-from .rollout import CostParams, GPPack, rollout
+from .rollout import CostParams, GPPack, rollout, rollout_fullcov
 
 
 class Dynamics(object):
@@ -61,11 +61,13 @@ class Dynamics(object):
         return self._pack
 
     # -- rollout ---------------------------------------------------------------------------
-    def rollout(self, curr_state, actions, cost=None, want_grad=False):
+    def rollout(self, curr_state, actions, cost=None, want_grad=False, full_covariance=False):
         """Batched rollout: curr_state (ds,) or (B, ds); actions (H, da) or (B, H, da).
-        Returns the dict of gaussian_process_mpc_amd.rollout.rollout."""
+        Returns the dict of gaussian_process_mpc_amd.rollout.rollout (or rollout_fullcov: 'covs' instead of 'vars')."""
         if cost is None:     # propagation only: a zero cost keeps the fused tail trivial
             cost = CostParams(0.0, np.zeros((self.state_dim, self.state_dim)), np.zeros((self.action_dim, self.action_dim)))
+        if full_covariance:
+            return rollout_fullcov(self.pack(), curr_state, actions, cost, want_grad=want_grad)
         return rollout(self.pack(), curr_state, actions, cost, want_grad=want_grad, want_traj=True)
 
     def forward_propagate_torch(self, horizon, curr_state, actions):

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from .dynamics import Dynamics
-from .rollout import CostParams, cost_full, rollout
+from .rollout import CostParams, cost_full, rollout, rollout_fullcov
 
 try:                                    # the solver binding is optional (not installed in the build image)
     import cyipopt                      # noqa: F401
@@ -26,7 +26,10 @@ except Exception:                       # pragma: no cover
 
 
 class RiskSensitiveMPC:
-    def __init__(self, gamma, horizon, state_dim, input_dim, Q, R, R_delta=None):
+    def __init__(self, gamma, horizon, state_dim, input_dim, Q, R, R_delta=None, full_covariance=False):
+        # full_covariance=True propagates the whole state covariance (off-diagonal terms from the exact
+        # cross-covariances): the extension the reference leaves as a TODO (src/dynamics.py:184), BASELINE config 5.
+        self.full_covariance = full_covariance
         self.gamma = gamma
         self.horizon = horizon
         self.state_dim = state_dim
@@ -113,8 +116,12 @@ class RiskSensitiveMPC:
         x = np.array(x, dtype=np.float64, copy=True).reshape(-1)
         key = (x.tobytes(), None if self.curr_state is None else self.curr_state.detach().cpu().numpy().tobytes())
         if key != self._cache_key:
-            r = rollout(self.dynamics.pack(), self.curr_state, x.reshape(self.horizon, self.input_dim),
-                        self._cost_params(), want_grad=True, want_traj=False)
+            if self.full_covariance:
+                r = rollout_fullcov(self.dynamics.pack(), self.curr_state, x.reshape(self.horizon, self.input_dim),
+                                    self._cost_params(), want_grad=True)
+            else:
+                r = rollout(self.dynamics.pack(), self.curr_state, x.reshape(self.horizon, self.input_dim),
+                            self._cost_params(), want_grad=True, want_traj=False)
             self.curr_cost = float(r["cost"][0].item())
             self.curr_grad = r["grad"][0].cpu().numpy()
             self.curr_u = x.reshape(self.horizon, self.input_dim)
@@ -140,6 +147,8 @@ class RiskSensitiveMPC:
         """U: (B, H, da) candidates from one (ds,) or per-candidate (B, ds) start state.
         Returns the rollout dict (device tensors: cost (B,), grad (B,H,da), means, vars)."""
         cs = self.curr_state if curr_state is None else curr_state
+        if self.full_covariance:
+            return rollout_fullcov(self.dynamics.pack(), cs, U, self._cost_params(), want_grad=want_grad)
         return rollout(self.dynamics.pack(), cs, U, self._cost_params(), want_grad=want_grad, want_traj=True)
 
     def objective_batch(self, U, curr_state=None):
