@@ -17,6 +17,21 @@ int gpmpc_launch_pair(int D, bool diag, bool grad, int tb, int waves, const Pair
     return GPMPC_E_ARG;
 }
 
+int gpmpc_launch_pair_sb(int D, bool grad, int tb, int ns2, int waves, const PairSbArgs& a, hipStream_t s) {
+    if (waves < 1 || waves > 4) return GPMPC_E_ARG;
+    switch (D) {
+        case 1: return gpmpc_launch_pair_sb_D<1>(grad, tb, ns2, waves, a, s);
+        case 2: return gpmpc_launch_pair_sb_D<2>(grad, tb, ns2, waves, a, s);
+        case 3: return gpmpc_launch_pair_sb_D<3>(grad, tb, ns2, waves, a, s);
+        case 4: return gpmpc_launch_pair_sb_D<4>(grad, tb, ns2, waves, a, s);
+        case 5: return gpmpc_launch_pair_sb_D<5>(grad, tb, ns2, waves, a, s);
+        case 6: return gpmpc_launch_pair_sb_D<6>(grad, tb, ns2, waves, a, s);
+        case 7: return gpmpc_launch_pair_sb_D<7>(grad, tb, ns2, waves, a, s);
+        case 8: return gpmpc_launch_pair_sb_D<8>(grad, tb, ns2, waves, a, s);
+    }
+    return GPMPC_E_ARG;
+}
+
 // K*[r][i] = sf^2 exp(-1/2 sum_k (xp_rk - x_ik)^2 / lambda_k)      (src/gpr.py:266-283)
 __global__ void k_cross_kernel(const double* __restrict__ Xp, int p, const double* __restrict__ X, int N, int D,
                                const double* __restrict__ lam, double sf2, double* __restrict__ K) {

@@ -66,6 +66,20 @@ struct PairArgs {
     int ns2;              // leading dims whose second moments are needed (diag+grad path); D = all
 };
 
+// Arguments of the scalar-broadcast pair kernel (pair_kernel_sb.h): rollout hot path, variance units only.
+struct PairSbArgs {
+    const double* M;      // [ds][Np][Np] upper-triangular, weight 2 off the diagonal (pack.hip)
+    const double* XT;     // [D][Np]
+    const double* pp;     // [B][ds][pps]: cvec[D] = sc o u, sc[D]
+    const double* G;      // [B][ds][Np][GW] column rows [h_j (D) | q_j | h_j^2 (NS2) | pad]
+    double* part;         // [B][nwork][nm]
+    const int* work;      // [nwork][4] = {unit, i0, j0, j1}
+    int Np, B, ds, nwork, pps, nm;
+};
+static inline int gpmpc_sb_gw(int D, int ns2) { return (D + 1 + ns2 + 1) & ~1; }
+int gpmpc_launch_pair_sb(int D, bool grad, int tb, int ns2, int waves, const PairSbArgs& a, hipStream_t s);
+template <int D> int gpmpc_launch_pair_sb_D(bool grad, int tb, int ns2, int waves, const PairSbArgs& a, hipStream_t s);
+
 // Implemented in pair_d*.hip (one translation unit per D so the build parallelises).
 int gpmpc_launch_pair(int D, bool diag, bool grad, int tb, int waves, const PairArgs& a, hipStream_t s);
 template <int D> int gpmpc_launch_pair_D(bool diag, bool grad, int tb, int waves, const PairArgs& a, hipStream_t s);

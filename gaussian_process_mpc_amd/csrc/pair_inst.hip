@@ -1,7 +1,9 @@
 // One translation unit per input dimension D (compiled with -DGPMPC_PAIR_D=<D>) so that the
 // template instantiations of the pair kernel build in parallel.
 #include "pair_kernel.h"
+#include "pair_kernel_sb.h"
 #ifndef GPMPC_PAIR_D
 #error "compile with -DGPMPC_PAIR_D=<D>"
 #endif
 template int gpmpc_launch_pair_D<GPMPC_PAIR_D>(bool, bool, int, int, const PairArgs&, hipStream_t);
+template int gpmpc_launch_pair_sb_D<GPMPC_PAIR_D>(bool, int, int, int, const PairSbArgs&, hipStream_t);

