@@ -197,3 +197,24 @@ def test_batch_matches_loop_and_pack_refresh(G, golden):
     assert p1 is not p0 and p1.N == p0.N + 1
     c2, _ = mpc.objective_batch(z["U"], z["x0"])
     assert np.all(np.isfinite(c2)) and not np.allclose(c2, cost, rtol=1e-12)
+
+
+def test_closed_loop_simulator(G):
+    """Simulator.run semantics (reference src/simulator.py:37-60) on the dependency-free pendulum plant:
+    solve, step, append one observation (pack refresh) per iteration."""
+    rng = np.random.default_rng(3)
+    plant = G.PendulumPlant(init_state=(0.3, 0.0))
+    S = np.stack((rng.uniform(-1, 1, 40), rng.uniform(-2, 2, 40)), axis=1)
+    A = rng.uniform(-2, 2, (40, 1))
+    nxt = np.array([G.PendulumPlant(init_state=s).step(a)[0] for s, a in zip(S, A)])
+    mpc = G.RiskSensitiveMPC(-1.0, 5, 2, 1, 0.5 * np.eye(2), 0.01 * np.eye(1))
+    for g in mpc.dynamics.gpr_err:
+        g.set_lambdas(np.array([1.0, 4.0, 4.0]))
+        g.set_sigma_n(np.array(1e-2))
+    mpc.dynamics.append_train_data(S, A, nxt)
+    mpc.set_lb([-2.0]); mpc.set_ub([2.0])
+    sim = G.Simulator(mpc, plant, num_iters=3)
+    hist = sim.run()
+    assert len(hist) == 3 and hist[0][1].shape == (1,)
+    assert mpc.dynamics.gpr_err[0].num_train == 43 and mpc.dynamics.pack().N == 43
+    assert all(np.isfinite(h[2]) for h in hist) and all(abs(h[1][0]) <= 2.0 + 1e-9 for h in hist)
