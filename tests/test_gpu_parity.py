@@ -268,3 +268,61 @@ def test_rollout_fullcov_vs_oracle(G, N, ds, da, H, B, gamma):
     np.testing.assert_allclose(rd["means"][:, 1].cpu().numpy(), r["means"][:, 1].cpu().numpy(), rtol=1e-9)
     np.testing.assert_allclose(rd["vars"][:, 1].cpu().numpy(),
                                torch.diagonal(r["covs"][:, 1], dim1=1, dim2=2).cpu().numpy(), rtol=1e-6)
+
+
+@pytest.mark.parametrize("N,ds,da,H,B", [(1, 2, 1, 2, 1), (2, 1, 1, 3, 2), (63, 2, 1, 2, 2), (64, 3, 1, 1, 3),
+                                         (65, 7, 1, 2, 2), (70, 6, 2, 2, 3), (257, 2, 2, 2, 600)])
+def test_rollout_edge_shapes(G, N, ds, da, H, B):
+    """Edge cases: a single training point (the reference special-cases 0-D y, uncertainty_prop.py:324), N around the
+    64-row padding boundary, the largest supported input dimension D = 8, H = 1, and a batch large enough to take the
+    256-row tiles / scalar-broadcast kernel at small N (ragged last tile)."""
+    from oracle import gpmpc_oracle as O
+    from gaussian_process_mpc_amd.synth import synth_problem
+    pb = synth_problem(21, N, ds, da, H, B, sigma_n=0.05)
+    gp = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"])
+    pack = G.GPPack(pb["X"], pb["Y"], gp.Ky_inv.numpy(), pb["lambdas"], pb["sigma_f"])
+    assert pack.Np % 64 == 0 and pack.Np >= N
+    r = G.rollout(pack, pb["x0"], pb["U"], G.CostParams(-1.0, pb["Q"], pb["R"]))
+    for b in sorted(set([0, B // 2, B - 1])):
+        o = O.objective_and_gradient(gp, H, pb["x0"][b], pb["U"][b], pb["x_ref"], pb["u_ref"], pb["Q"], pb["R"], -1.0)
+        np.testing.assert_allclose(r["means"][b].cpu().numpy(), o["means"], rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(r["vars"][b].cpu().numpy(), o["vars"], rtol=1e-4, atol=1e-12)
+        np.testing.assert_allclose(r["cost"][b].item(), o["cost"], rtol=1e-6)
+        np.testing.assert_allclose(r["grad"][b].cpu().numpy(), o["grad"], rtol=1e-4, atol=1e-7)
+
+
+def test_abi_error_codes_on_device(G, golden):
+    import ctypes
+    from gaussian_process_mpc_amd import _lib
+    z = golden("g3_rollout_c1.npz")
+    lib = G.lib()
+    h = ctypes.c_void_p()
+    assert lib.gpmpc_pack_create(ctypes.byref(h), 100, 2, 2) == 0
+    x0 = torch.zeros((1, 2), dtype=torch.float64, device="cuda")
+    U = torch.zeros((1, 10, 2), dtype=torch.float64, device="cuda")
+    out = torch.zeros(64, dtype=torch.float64, device="cuda")
+    ws = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")
+    c = _cost_from(G, z, -1.0)
+    args = (h, 1, 10, _lib.ptr(x0), _lib.ptr(U), ctypes.byref(c.c), 1, None, None, _lib.ptr(out), _lib.ptr(out))
+    assert lib.gpmpc_rollout(*args, ctypes.c_void_p(ws.data_ptr()), ws.numel(), None) == -5      # pack not built
+    assert lib.gpmpc_pack_destroy(h) == 0
+    pack = _pack_from(G, z)
+    need = lib.gpmpc_rollout_workspace_bytes(pack.handle, 1, 10, 1)
+    assert need > 1024
+    args = (pack.handle,) + args[1:]
+    assert lib.gpmpc_rollout(*args, ctypes.c_void_p(ws.data_ptr()), 1024, None) == -4              # workspace too small
+    assert lib.gpmpc_rollout(*args[:10], None, ctypes.c_void_p(ws.data_ptr()), ws.numel(), None) == -1   # grad wanted, no buffer
+    assert lib.gpmpc_rollout_fullcov(pack.handle, 1, 10, _lib.ptr(x0), _lib.ptr(U), ctypes.byref(c.c), 0, _lib.ptr(out),
+                                     _lib.ptr(out), _lib.ptr(out), None, ctypes.c_void_p(ws.data_ptr()), ws.numel(), None) == -5
+    torch.cuda.synchronize()
+
+
+def test_nan_passthrough(G, golden):
+    """A negative input variance makes the reference produce NaN (sqrt / log of a negative number); the HIP path must
+    pass NaN through, not clamp (keep NaN semantics)."""
+    z = golden("g3_rollout_c1.npz")
+    pack = _pack_from(G, z)
+    D = 4
+    S = np.diag([-50.0, 1e-3, 1e-3, 1e-3])
+    r = G.moment_match(pack, np.zeros(D), S)
+    assert torch.isnan(r["var"]).any() or torch.isnan(r["mean"]).any()
