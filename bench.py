@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="trajectories per GPU (default: the config's B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--forward-only", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay each rollout as one hipGraph (small batches)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -136,7 +137,7 @@ def main():
         if fullcov:
             r = g.rollout_fullcov(pack, x0, U, cost, want_grad=want_grad)
         else:
-            r = g.rollout(pack, x0, U, cost, want_grad=want_grad, want_traj=False)
+            r = g.rollout(pack, x0, U, cost, want_grad=want_grad, want_traj=False, graph=args.graph)
         if world > 1:
             return gather_results(r["cost"], r.get("grad"), dist)
         return r["cost"], r.get("grad")
@@ -147,7 +148,7 @@ def main():
     if not torch.isfinite(c).all() or (gr is not None and not torch.isfinite(gr).all()):
         raise SystemExit("non-finite rollout outputs")
 
-    lib().gpmpc_timing_enable(1)
+    lib().gpmpc_timing_enable(0 if args.graph else 1)     # per-kernel events and graph replay exclude each other
     import ctypes
     ms, nl = ctypes.c_double(), ctypes.c_longlong()
     lib().gpmpc_pair_kernel_time(ctypes.byref(ms), ctypes.byref(nl), 1)
@@ -179,7 +180,7 @@ def main():
             fl, slots = 2 * D + 37, D + 22
         if fullcov and want_grad:          # full second moments: D(D+1)/2 instead of D accumulations per pair
             fl, slots = 4 * D + 37 + D * (D - 1), 2 * D + 23 + D * (D - 1) // 2
-        launch_s = (ms.value / max(nl.value, 1)) * 1e-3
+        launch_s = (ms.value / max(nl.value, 1)) * 1e-3 if nl.value else float('nan')
         achieved = pairs_per_launch * fl / launch_s / 1e12
         out = {
             "metric": "GP-MPC rollouts/sec (N train pts x H horizon x d dims)",

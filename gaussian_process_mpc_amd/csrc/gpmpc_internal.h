@@ -45,6 +45,7 @@ struct gpmpc_pack {
     double* sf;     // dev [ds]
     double lam_host[GPMPC_MAX_DS][GPMPC_MAX_D];
     double sf_host[GPMPC_MAX_DS];
+    void* graph_cache;         // captured rollout (GPMPC_USE_GRAPH), owned by step.hip
     gpmpc_worklist wl[2][2];   // [0: variance units only | 1: + cross units][0: 256x256 tiles | 1: 64x64 one-wave tiles]
 };
 
@@ -64,6 +65,7 @@ struct PairArgs {
     int jside_off;        // 0: columns use the row transform (symmetric units only)
     int ntri;             // units < ntri are symmetric / upper-triangular
     int ns2;              // leading dims whose second moments are needed (diag+grad path); D = all
+    int colsplit;         // 64-row tiles run by 4 waves that split the columns (small batches)
 };
 
 // Arguments of the scalar-broadcast pair kernel (pair_kernel_sb.h): rollout hot path, variance units only.
@@ -85,6 +87,7 @@ int gpmpc_launch_pair(int D, bool diag, bool grad, int tb, int waves, const Pair
 template <int D> int gpmpc_launch_pair_D(bool diag, bool grad, int tb, int waves, const PairArgs& a, hipStream_t s);
 
 void gpmpc_set_error(const char* what, hipError_t e);
+void gpmpc_graph_cache_free(void* cache);
 #define GPMPC_HIP(call)                                              \
     do {                                                             \
         hipError_t e_ = (call);                                      \

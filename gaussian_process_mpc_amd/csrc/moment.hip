@@ -426,8 +426,8 @@ static int run_mom(const gpmpc_pack* p, MomArgs& A, const MomPlan& r, bool grad,
     PairArgs P;
     P.M = p->M; P.XT = p->XT; P.pp = A.pp; P.part = A.part; P.work = p->wl[r.mode][r.tiling].work_dev;
     P.Np = p->Np; P.B = A.nq; P.nunits = r.nunits; P.nwork = r.nwork; P.pps = r.pps; P.nm = r.nm;
-    P.jside_off = D + D * D; P.ntri = p->ds; P.ns2 = D;
-    int rc = gpmpc_timed_pair(D, false, grad, r.tb, r.waves, P, s);
+    P.jside_off = D + D * D; P.ntri = p->ds; P.ns2 = D; P.colsplit = (r.tiling == 1) ? 1 : 0;
+    int rc = gpmpc_timed_pair(D, false, grad, r.tb, P.colsplit ? 4 : r.waves, P, s);
     if (rc != GPMPC_OK) return rc;
     hipLaunchKernelGGL(k_mom_finish<D>, dim3(A.nq), dim3(64), 0, s, A);
     if (A.out_cov && p->ds > 1 && A.npairs == 0) {          // direct N^2 kernel (also the bug-compatible form)

@@ -76,7 +76,9 @@ __global__ __launch_bounds__(256) void gpmpc_pair_kernel(PairArgs A) {
     const bool tri = unit < A.ntri;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int Np = A.Np;
-    const int iw0 = i0 + w * 64;            // first row of this wave
+    // colsplit (small batches, 64-row tiles run by 4 waves): all waves share the 64 rows and each takes a quarter of
+    // every 64-column chunk, so a tile's latency is a quarter of a one-wave tile's
+    const int iw0 = A.colsplit ? i0 : i0 + w * 64;            // first row of this wave
     const bool active = iw0 < Np;           // wave-uniform (Np is a multiple of 64)
     const int i = iw0 + lane;
 
@@ -131,8 +133,9 @@ __global__ __launch_bounds__(256) void gpmpc_pair_kernel(PairArgs A) {
         if (!active || (tri && jc + 63 < iw0)) continue;
 
         const double* __restrict__ Mc = Ma + (size_t)jc * Np + i;
+        const int jb0 = A.colsplit ? w * 16 : 0, jb1 = A.colsplit ? w * 16 + 16 : 64;
 #pragma unroll 1
-        for (int jb = 0; jb < 64; jb += 8) {
+        for (int jb = jb0; jb < jb1; jb += 8) {
             double mij[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) mij[q] = Mc[(size_t)(jb + q) * Np];

@@ -47,15 +47,31 @@ __host__ __device__ static inline int sps_of(int D) { return 3 + 4 * D; }
 // Finish step t (>= 1) for trajectory b: reduce the pair-kernel partials of ALL ds GPs (mean/var of step t land in
 // s_mu / s_var, LDS) and write to global memory the rows this workgroup owns: every GP if own < 0, else GP `own`
 // only (the head kernel runs one workgroup per (trajectory, GP); each recomputes the cheap reduction and owns one GP).
+#define GPMPC_RED_CH 8
 __device__ static void finish_step(const RollArgs& A, int b, int t, int own, double* s_z /* [ds*nm] */,
-                                   double* s_mu, double* s_var) {
+                                   double* s_red /* [ds*nm*GPMPC_RED_CH] */, double* s_mu, double* s_var) {
     const int ds = A.ds, D = A.D, nm = A.nm;
-    for (int idx = threadIdx.x; idx < ds * nm; idx += blockDim.x) {
-        const int a = idx / nm, m = idx - a * nm;
-        const double* p = A.part + (size_t)b * A.nwork * nm + m;
-        double s = 0.0;
-        for (int wi = A.ustart[a]; wi < A.ustart[a + 1]; ++wi) s += p[(size_t)wi * nm];
-        s_z[idx] = s;
+    // Sum the per-tile partials of every (GP, moment) output.  GPMPC_RED_CH threads share one output (each a strided
+    // subset of the work items, so the global loads of a pass are independent), then a fixed-order combine: the
+    // summation order depends only on the shapes, never on timing.
+    {
+        const int nout = ds * nm, ch = threadIdx.x % GPMPC_RED_CH, per_pass = blockDim.x / GPMPC_RED_CH;
+        for (int o0 = 0; o0 < nout; o0 += per_pass) {
+            const int o = o0 + threadIdx.x / GPMPC_RED_CH;
+            if (o < nout) {
+                const int a = o / nm, m = o - a * nm;
+                const double* p = A.part + (size_t)b * A.nwork * nm + m;
+                double s = 0.0;
+                for (int wi = A.ustart[a] + ch; wi < A.ustart[a + 1]; wi += GPMPC_RED_CH) s += p[(size_t)wi * nm];
+                s_red[o * GPMPC_RED_CH + ch] = s;
+            }
+        }
+        __syncthreads();
+        for (int o = threadIdx.x; o < nout; o += blockDim.x) {
+            double s = 0.0;
+            for (int c = 0; c < GPMPC_RED_CH; ++c) s += s_red[o * GPMPC_RED_CH + c];
+            s_z[o] = s;
+        }
     }
     __syncthreads();
     if (threadIdx.x < ds) {
@@ -177,6 +193,7 @@ __device__ static void prep_step(const RollArgs& A, int b, int t, int a, const d
 template <int D>
 __global__ __launch_bounds__(256) void k_roll_head(RollArgs A, int t) {
     __shared__ double s_z[GPMPC_MAX_DS * (1 + 2 * GPMPC_MAX_D)];
+    __shared__ double s_zred[GPMPC_MAX_DS * (1 + 2 * GPMPC_MAX_D) * GPMPC_RED_CH];
     __shared__ double s_mu[GPMPC_MAX_DS], s_var[GPMPC_MAX_DS];
     __shared__ double s_u[GPMPC_MAX_D], s_s[GPMPC_MAX_D];
     __shared__ double s_scr[16 * (1 + 2 * D)], s_out[1 + 2 * D];
@@ -193,7 +210,7 @@ __global__ __launch_bounds__(256) void k_roll_head(RollArgs A, int t) {
         }
         __syncthreads();
     } else {
-        finish_step(A, b, t - 1, a, s_z, s_mu, s_var);
+        finish_step(A, b, t - 1, a, s_z, s_zred, s_mu, s_var);
     }
     prep_step<D>(A, b, t, a, s_mu, s_var, s_u, s_s, s_scr, s_out);
 }
@@ -298,51 +315,64 @@ __device__ static double input_cost(int H, int da, const gpmpc_cost_params& C, c
     return c;
 }
 
-// Tail: finish step H, cost, adjoint sweep.  One workgroup (64 threads) per trajectory; the first
-// GPMPC_TAIL_WORKERS threads evaluate the per-step cost terms (each needs an LU scratch in LDS).
-// dynamic LDS: [WORKERS][ds*2ds] LU scratch | [H+1] cost terms | [H+1][2ds] local derivatives
+// Tail: finish step H, cost, adjoint sweep.  One workgroup (256 threads) per trajectory; the first
+// GPMPC_TAIL_WORKERS threads evaluate the per-step cost terms (each needs an LU scratch in LDS), then the reverse
+// sweep runs one step per iteration with the (2ds) x (2ds+da) Jacobian of the next step prefetched into registers.
+// dynamic LDS: [WORKERS][ds*2ds] LU scratch | [H+1] cost terms | [H+1][2ds] local derivatives | [H*da] grad | [nz*nc] J
 #define GPMPC_TAIL_WORKERS 32
-__global__ __launch_bounds__(64) void k_roll_tail(RollArgs A) {
+__global__ __launch_bounds__(256) void k_roll_tail(RollArgs A) {
     extern __shared__ double s_dyn[];
     __shared__ double s_z[GPMPC_MAX_DS * (1 + 2 * GPMPC_MAX_D)];
+    __shared__ double s_zred[GPMPC_MAX_DS * (1 + 2 * GPMPC_MAX_D) * GPMPC_RED_CH];
     __shared__ double s_mu[GPMPC_MAX_DS], s_var[GPMPC_MAX_DS];
-    const int b = blockIdx.x, ds = A.ds, da = A.da, H = A.H;
-    finish_step(A, b, H, -1, s_z, s_mu, s_var);
+    __shared__ double s_adj[2][2 * GPMPC_MAX_DS];
+    const int b = blockIdx.x, ds = A.ds, da = A.da, H = A.H, tid = threadIdx.x;
+    const int nz = 2 * ds, nc = 2 * ds + da;
+    finish_step(A, b, H, -1, s_z, s_zred, s_mu, s_var);
     double* s_lu = s_dyn;
     double* s_ct = s_dyn + GPMPC_TAIL_WORKERS * ds * 2 * ds;
     double* s_dl = s_ct + (H + 1);
+    double* s_gU = s_dl + (size_t)(H + 1) * nz;
+    double* s_J = s_gU + H * da;
     const double* mu = A.means + (size_t)b * (H + 1) * ds;
     const double* var = A.vars + (size_t)b * (H + 1) * ds;
-    for (int i = threadIdx.x; i <= H && threadIdx.x < GPMPC_TAIL_WORKERS; i += GPMPC_TAIL_WORKERS)
-        s_ct[i] = state_cost(ds, A.cost, mu + i * ds, var + i * ds, 0, true, s_lu + threadIdx.x * ds * 2 * ds,
-                             A.grad ? s_dl + i * 2 * ds : nullptr, A.grad ? s_dl + i * 2 * ds + ds : nullptr);
+    for (int i = tid; i <= H && tid < GPMPC_TAIL_WORKERS; i += GPMPC_TAIL_WORKERS)
+        s_ct[i] = state_cost(ds, A.cost, mu + i * ds, var + i * ds, 0, true, s_lu + tid * ds * 2 * ds,
+                             A.grad ? s_dl + i * nz : nullptr, A.grad ? s_dl + i * nz + ds : nullptr);
+    for (int q = tid; q < H * da; q += blockDim.x) s_gU[q] = 0.0;
+    // Jacobian of step H into registers while the cost terms are finished (nz*nc <= 288 doubles: <= 2 per thread)
+    const double* Jg = A.grad ? A.jac + ((size_t)b * H + (H - 1)) * nz * nc : nullptr;
+    double j0 = (Jg && tid < nz * nc) ? Jg[tid] : 0.0, j1 = (Jg && tid + 256 < nz * nc) ? Jg[tid + 256] : 0.0;
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    const double* U = A.U + (size_t)b * H * da;
-    double* gU = A.grad ? A.out_grad + (size_t)b * H * da : nullptr;
-    if (gU) for (int q = 0; q < H * da; ++q) gU[q] = 0.0;
-    double total = 0.0;
-    for (int i = 0; i <= H; ++i) total += s_ct[i];
-    total += input_cost(H, da, A.cost, U, gU);
-    A.out_cost[b] = total;
-    if (!A.grad) return;
-    const int nz = 2 * ds, nc = 2 * ds + da;
-    double adj[2 * GPMPC_MAX_DS], nxt[2 * GPMPC_MAX_DS];
-    for (int r = 0; r < nz; ++r) adj[r] = s_dl[H * nz + r];
-    for (int t = H; t >= 1; --t) {
-        const double* J = A.jac + ((size_t)b * H + (t - 1)) * nz * nc;
-        for (int k = 0; k < da; ++k) {
-            double s = 0.0;
-            for (int r = 0; r < nz; ++r) s = fma(J[r * nc + nz + k], adj[r], s);
-            gU[(t - 1) * da + k] += s;
-        }
-        for (int cidx = 0; cidx < nz; ++cidx) {
-            double s = s_dl[(t - 1) * nz + cidx];
-            for (int r = 0; r < nz; ++r) s = fma(J[r * nc + cidx], adj[r], s);
-            nxt[cidx] = s;
-        }
-        for (int r = 0; r < nz; ++r) adj[r] = nxt[r];
+    if (tid == 0) {
+        const double* U = A.U + (size_t)b * H * da;
+        double total = 0.0;
+        for (int i = 0; i <= H; ++i) total += s_ct[i];
+        total += input_cost(H, da, A.cost, U, A.grad ? s_gU : nullptr);
+        A.out_cost[b] = total;
     }
+    if (!A.grad) return;
+    if (tid < nz) s_adj[0][tid] = s_dl[H * nz + tid];
+    int cur = 0;
+    for (int t = H; t >= 1; --t) {
+        if (tid < nz * nc) s_J[tid] = j0;
+        if (tid + 256 < nz * nc) s_J[tid + 256] = j1;
+        __syncthreads();                                  // J of step t and adj of step t are in LDS
+        if (t > 1) {                                      // prefetch the Jacobian of step t-1
+            const double* Jn = A.jac + ((size_t)b * H + (t - 2)) * nz * nc;
+            j0 = tid < nz * nc ? Jn[tid] : 0.0;
+            j1 = tid + 256 < nz * nc ? Jn[tid + 256] : 0.0;
+        }
+        if (tid < nc) {
+            double s = 0.0;
+            for (int r = 0; r < nz; ++r) s = fma(s_J[r * nc + tid], s_adj[cur][r], s);
+            if (tid < nz) s_adj[cur ^ 1][tid] = s_dl[(t - 1) * nz + tid] + s;
+            else s_gU[(t - 1) * da + (tid - nz)] += s;     // thread 0 finished input_cost before the first barrier above
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    for (int q = tid; q < H * da; q += blockDim.x) A.out_grad[(size_t)b * H * da + q] = s_gU[q];
 }
 
 // Stand-alone cost for given means / FULL covariances (cost_torch parity, src/mpc.py:156-200).
@@ -471,9 +501,9 @@ static void launch_head(const RollArgs& A, int t, hipStream_t s) {
     hipLaunchKernelGGL(k_roll_head<D>, dim3(A.B, A.ds), dim3(256), 0, s, A, t);
 }
 
-extern "C" int gpmpc_rollout(const gpmpc_pack* p, int B, int H, const double* x0, const double* U,
-                             const gpmpc_cost_params* cost, unsigned flags, double* out_means, double* out_vars,
-                             double* out_cost, double* out_grad, void* workspace, size_t workspace_bytes, void* stream) {
+static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, const double* U,
+                           const gpmpc_cost_params* cost, unsigned flags, double* out_means, double* out_vars,
+                           double* out_cost, double* out_grad, void* workspace, size_t workspace_bytes, void* stream) {
     if (!p || !x0 || !U || !cost || !out_cost || !workspace || B < 1 || H < 1) return GPMPC_E_ARG;
     if (!p->built) return GPMPC_E_STATE;
     const bool grad = (flags & GPMPC_WANT_GRAD) != 0;
@@ -500,7 +530,7 @@ extern "C" int gpmpc_rollout(const gpmpc_pack* p, int B, int H, const double* x0
     PairArgs P;
     P.M = p->M; P.XT = p->XT; P.pp = A.pp; P.part = A.part; P.work = p->wl[0][r.tiling].work_dev;
     P.Np = p->Np; P.B = B; P.nunits = p->ds; P.nwork = r.nwork; P.pps = r.pps; P.nm = r.nm;
-    P.jside_off = 0; P.ntri = p->ds; P.ns2 = p->ds;
+    P.jside_off = 0; P.ntri = p->ds; P.ns2 = p->ds; P.colsplit = (r.tiling == 1) ? 1 : 0;
 
     for (int t = 1; t <= H; ++t) {
         switch (p->D) {
@@ -521,15 +551,90 @@ extern "C" int gpmpc_rollout(const gpmpc_pack* p, int B, int H, const double* x0
             Q.Np = p->Np; Q.B = B; Q.ds = p->ds; Q.nwork = r.nwork; Q.pps = r.pps; Q.nm = r.nm;
             rc = gpmpc_timed_pair_sb(p->D, grad, r.tb, p->ds, r.waves, Q, s);
         } else {
-            rc = gpmpc_timed_pair(p->D, true, grad, r.tb, r.waves, P, s);
+            rc = gpmpc_timed_pair(p->D, true, grad, r.tb, P.colsplit ? 4 : r.waves, P, s);
         }
         if (rc != GPMPC_OK) return rc;
     }
-    const size_t lds = sizeof(double) * ((size_t)GPMPC_TAIL_WORKERS * p->ds * 2 * p->ds + (size_t)(H + 1) * (1 + 2 * p->ds));
-    if (lds > 60 * 1024) return GPMPC_E_ARG;   // horizon too long for the tail kernel's LDS budget
-    hipLaunchKernelGGL(k_roll_tail, dim3(B), dim3(64), lds, s, A);
+    const size_t nzc = (size_t)2 * p->ds * (2 * p->ds + p->da);
+    const size_t lds = sizeof(double) * ((size_t)GPMPC_TAIL_WORKERS * p->ds * 2 * p->ds + (size_t)(H + 1) * (1 + 2 * p->ds) +
+                                         (size_t)H * p->da + nzc);
+    if (lds > 48 * 1024) return GPMPC_E_ARG;   // horizon too long for the tail kernel's LDS budget
+    hipLaunchKernelGGL(k_roll_tail, dim3(B), dim3(256), lds, s, A);
     GPMPC_HIP(hipGetLastError());
     return GPMPC_OK;
+}
+
+
+// Key of a captured rollout: everything the launch sequence depends on besides device memory contents.
+struct gpmpc_graph_key {
+    int B, H; unsigned flags;
+    const void *x0, *U, *means, *vars, *cost_out, *grad, *ws; size_t ws_bytes;
+    gpmpc_cost_params cost;
+};
+struct gpmpc_graph_cache {
+    hipStream_t stream; hipEvent_t ev_in, ev_out; hipGraphExec_t exec; int valid; gpmpc_graph_key key;
+};
+
+void gpmpc_graph_cache_free(void* c) {
+    gpmpc_graph_cache* g = (gpmpc_graph_cache*)c;
+    if (!g) return;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->ev_in) (void)hipEventDestroy(g->ev_in);
+    if (g->ev_out) (void)hipEventDestroy(g->ev_out);
+    if (g->stream) (void)hipStreamDestroy(g->stream);
+    free(g);
+}
+
+// Replay the 2H+1 launches of a rollout as ONE hipGraph on a stream owned by the pack (the caller's stream may be the
+// legacy default stream, which cannot be captured); ordered against the caller's stream with two events.
+static int graph_rollout(gpmpc_pack* p, int B, int H, const double* x0, const double* U, const gpmpc_cost_params* cost,
+                         unsigned flags, double* out_means, double* out_vars, double* out_cost, double* out_grad,
+                         void* workspace, size_t workspace_bytes, hipStream_t user) {
+    gpmpc_graph_cache* g = (gpmpc_graph_cache*)p->graph_cache;
+    if (!g) {
+        g = (gpmpc_graph_cache*)calloc(1, sizeof(gpmpc_graph_cache));
+        if (!g) return GPMPC_E_ALLOC;
+        GPMPC_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+        GPMPC_HIP(hipEventCreateWithFlags(&g->ev_in, hipEventDisableTiming));
+        GPMPC_HIP(hipEventCreateWithFlags(&g->ev_out, hipEventDisableTiming));
+        p->graph_cache = g;
+    }
+    gpmpc_graph_key k;
+    memset(&k, 0, sizeof(k));
+    k.B = B; k.H = H; k.flags = flags; k.x0 = x0; k.U = U; k.means = out_means; k.vars = out_vars; k.cost_out = out_cost;
+    k.grad = out_grad; k.ws = workspace; k.ws_bytes = workspace_bytes; k.cost = *cost;
+    if (!g->valid || memcmp(&k, &g->key, sizeof(k)) != 0) {
+        if (g->exec) { (void)hipGraphExecDestroy(g->exec); g->exec = nullptr; }
+        g->valid = 0;
+        hipGraph_t graph = nullptr;
+        GPMPC_HIP(hipStreamBeginCapture(g->stream, hipStreamCaptureModeThreadLocal));
+        int rc = enqueue_rollout(p, B, H, x0, U, cost, flags, out_means, out_vars, out_cost, out_grad, workspace,
+                                 workspace_bytes, g->stream);
+        hipError_t e = hipStreamEndCapture(g->stream, &graph);
+        if (rc != GPMPC_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (e != hipSuccess) { gpmpc_set_error("hipStreamEndCapture", e); return GPMPC_E_LAUNCH; }
+        e = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) { gpmpc_set_error("hipGraphInstantiate", e); return GPMPC_E_LAUNCH; }
+        g->key = k; g->valid = 1;
+    }
+    GPMPC_HIP(hipEventRecord(g->ev_in, user));
+    GPMPC_HIP(hipStreamWaitEvent(g->stream, g->ev_in, 0));
+    GPMPC_HIP(hipGraphLaunch(g->exec, g->stream));
+    GPMPC_HIP(hipEventRecord(g->ev_out, g->stream));
+    GPMPC_HIP(hipStreamWaitEvent(user, g->ev_out, 0));
+    return GPMPC_OK;
+}
+
+extern "C" int gpmpc_rollout(const gpmpc_pack* p, int B, int H, const double* x0, const double* U,
+                             const gpmpc_cost_params* cost, unsigned flags, double* out_means, double* out_vars,
+                             double* out_cost, double* out_grad, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!p || !cost) return GPMPC_E_ARG;
+    if ((flags & GPMPC_USE_GRAPH) && !g_timing && p->built && x0 && U && out_cost && workspace && B >= 1 && H >= 1)
+        return graph_rollout(const_cast<gpmpc_pack*>(p), B, H, x0, U, cost, flags, out_means, out_vars, out_cost, out_grad,
+                             workspace, workspace_bytes, (hipStream_t)stream);
+    return enqueue_rollout(p, B, H, x0, U, cost, flags, out_means, out_vars, out_cost, out_grad, workspace,
+                           workspace_bytes, stream);
 }
 
 extern "C" int gpmpc_cost(int B, int H, int ds, int da, const gpmpc_cost_params* cost, const double* means,

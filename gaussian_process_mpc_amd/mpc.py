@@ -120,8 +120,9 @@ class RiskSensitiveMPC:
                 r = rollout_fullcov(self.dynamics.pack(), self.curr_state, x.reshape(self.horizon, self.input_dim),
                                     self._cost_params(), want_grad=True)
             else:
+                # B = 1 is launch-latency bound: replay the 2H+1 launches as one hipGraph
                 r = rollout(self.dynamics.pack(), self.curr_state, x.reshape(self.horizon, self.input_dim),
-                            self._cost_params(), want_grad=True, want_traj=False)
+                            self._cost_params(), want_grad=True, want_traj=False, graph=True)
             self.curr_cost = float(r["cost"][0].item())
             self.curr_grad = r["grad"][0].cpu().numpy()
             self.curr_u = x.reshape(self.horizon, self.input_dim)

@@ -78,6 +78,7 @@ class GPPack:
         lib().gpmpc_pack_dims(self._h, ctypes.byref(n), ctypes.byref(npad), ctypes.byref(ds), ctypes.byref(da))
         self.Np = npad.value
         self._ws = None
+        self._graph_bufs = {}
         self.fullcov = False
 
     def __del__(self):
@@ -122,11 +123,15 @@ class GPPack:
         return out
 
 
-def rollout(pack, x0, U, cost, want_grad=True, want_traj=True):
+def rollout(pack, x0, U, cost, want_grad=True, want_traj=True, graph=False):
     """B shooting rollouts + cost (+ gradient) in one call (C ABI ``gpmpc_rollout``).
 
     x0: (B, ds) or (ds,); U: (B, H, da) or (H, da).  Returns a dict of CUDA tensors:
-    cost (B,), grad (B, H, da), means (B, H+1, ds), vars (B, H+1, ds)."""
+    cost (B,), grad (B, H, da), means (B, H+1, ds), vars (B, H+1, ds).
+
+    graph=True replays the 2H+1 kernel launches as one hipGraph (for launch-latency-bound small batches, e.g. the
+    B = 1 callbacks of a solver loop): inputs are copied into buffers owned by the pack and the returned tensors are
+    views of buffers that the NEXT graph call with the same shape overwrites."""
     dev = pack.device
     U = _dev(U, dev)
     if U.dim() == 2:
@@ -137,15 +142,31 @@ def rollout(pack, x0, U, cost, want_grad=True, want_traj=True):
         x0 = x0.expand(B, pack.ds).contiguous()
     if da != pack.da or x0.shape[0] != B or cost.ds != pack.ds or cost.da != pack.da:
         raise ValueError("shape mismatch between pack, x0, U and cost parameters")
-    flags = _lib.WANT_GRAD if want_grad else 0
-    out = {"cost": torch.empty(B, dtype=torch.float64, device=dev)}
-    if want_grad:
-        out["grad"] = torch.empty((B, H, da), dtype=torch.float64, device=dev)
-    if want_traj:
-        out["means"] = torch.empty((B, H + 1, pack.ds), dtype=torch.float64, device=dev)
-        out["vars"] = torch.empty((B, H + 1, pack.ds), dtype=torch.float64, device=dev)
+    flags = (_lib.WANT_GRAD if want_grad else 0) | (_lib.USE_GRAPH if graph else 0)
     nbytes = lib().gpmpc_rollout_workspace_bytes(pack.handle, B, H, flags)
-    ws = pack.workspace(nbytes)
+    e = lambda *shape: torch.empty(shape, dtype=torch.float64, device=dev)  # noqa: E731
+    if graph:
+        key = (B, H, bool(want_grad), bool(want_traj))
+        buf = pack._graph_bufs.get(key)
+        if buf is None:
+            buf = {"x0": e(B, pack.ds), "U": e(B, H, da), "cost": e(B),
+                   "ws": torch.empty(int(nbytes), dtype=torch.uint8, device=dev)}
+            if want_grad:
+                buf["grad"] = e(B, H, da)
+            if want_traj:
+                buf["means"], buf["vars"] = e(B, H + 1, pack.ds), e(B, H + 1, pack.ds)
+            pack._graph_bufs = {key: buf}                    # one captured shape at a time
+        buf["x0"].copy_(x0)
+        buf["U"].copy_(U)
+        x0, U, ws = buf["x0"], buf["U"], buf["ws"]
+        out = {k: buf[k] for k in ("cost", "grad", "means", "vars") if k in buf}
+    else:
+        out = {"cost": e(B)}
+        if want_grad:
+            out["grad"] = e(B, H, da)
+        if want_traj:
+            out["means"], out["vars"] = e(B, H + 1, pack.ds), e(B, H + 1, pack.ds)
+        ws = pack.workspace(nbytes)
     with torch.cuda.device(dev):
         check(lib().gpmpc_rollout(pack.handle, B, H, ptr(x0), ptr(U), ctypes.byref(cost.c), flags,
                                   ptr(out.get("means")), ptr(out.get("vars")), ptr(out["cost"]), ptr(out.get("grad")),

@@ -42,6 +42,10 @@ extern "C" {
 
 /* flags for gpmpc_rollout / gpmpc_moment_match */
 #define GPMPC_WANT_GRAD      1u   /* also produce d cost / d U (rollout) or input Jacobians (moment_match) */
+#define GPMPC_USE_GRAPH      4u   /* gpmpc_rollout: replay the 2H+1 launches as one hipGraph.  The caller promises that
+                                     all pointer arguments (inputs, outputs, workspace) are the same buffers on every
+                                     call with this flag; a changed argument re-captures.  For launch-latency-bound
+                                     small batches (B = 1 solver loops). */
 #define GPMPC_COV_BUG_COMPAT 2u   /* cross-covariance with the reference's transposed cross term
                                      (src/tools/uncertainty_prop.py:446) instead of the consistent one */
 

@@ -326,3 +326,21 @@ def test_nan_passthrough(G, golden):
     S = np.diag([-50.0, 1e-3, 1e-3, 1e-3])
     r = G.moment_match(pack, np.zeros(D), S)
     assert torch.isnan(r["var"]).any() or torch.isnan(r["mean"]).any()
+
+
+def test_graph_replay_matches_eager(G, golden):
+    """GPMPC_USE_GRAPH: the captured launch sequence gives bit-identical results, survives new input values,
+    a changed cost (re-capture) and interleaving with eager calls."""
+    z = golden("g4_rollout_c2.npz")
+    pack = _pack_from(G, z)
+    cost = _cost_from(G, z, -1.0)
+    for rep in range(3):
+        for b in range(2):
+            e = G.rollout(pack, z["x0"][b], z["U"][b] * (1 + 0.1 * rep), cost)
+            g = G.rollout(pack, z["x0"][b], z["U"][b] * (1 + 0.1 * rep), cost, graph=True)
+            for k in e:
+                assert torch.equal(e[k], g[k]), (rep, b, k)
+    cost2 = _cost_from(G, z, 1e-5)
+    e = G.rollout(pack, z["x0"][0], z["U"][0], cost2)
+    g = G.rollout(pack, z["x0"][0], z["U"][0], cost2, graph=True)
+    assert torch.equal(e["cost"], g["cost"]) and torch.equal(e["grad"], g["grad"])
