@@ -23,6 +23,7 @@ struct gpmpc_worklist {
     int waves;      // waves per workgroup: it / 64
     int jt;         // column extent of a tile (multiple of 64)
     int nunits, nwork;
+    int contiguous;     // items of a unit are contiguous (ustart valid); 0: XCD-sorted order, look the unit up per item
     int* work_dev;      // [nwork][4]
     int* ustart_dev;    // [nunits + 1]
     int ustart_host[GPMPC_MAX_DS + GPMPC_MAX_PAIRS + 1];

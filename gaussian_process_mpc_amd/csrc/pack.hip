@@ -3,6 +3,7 @@
 // (src/tools/uncertainty_prop.py:324-327 beta, :392-394 Lambda_part, :399 Ky_inv - beta beta^T;
 // src/gpr.py:163-170 Kf / Ky).
 #include "gpmpc_internal.h"
+#include <cstdlib>
 
 // X [N][D] -> Xp [Np][D] (zero rows appended) and XT [D][Np]
 __global__ void k_pack_points(const double* __restrict__ X, int N, int Np, int D,
@@ -116,7 +117,7 @@ __global__ void k_pack_cross(const double* __restrict__ beta, const double* __re
     Mx[((size_t)pr * Np + j) * Np + i] = out;
 }
 
-static int build_worklist(int Np, int it, int jt, int ds, int npairs, gpmpc_worklist* w) {
+static int build_worklist(int Np, int it, int jt, int ds, int npairs, bool xcd_sort, gpmpc_worklist* w) {
     const int ti = (Np + it - 1) / it, tj = (Np + jt - 1) / jt;
     const size_t cap = (size_t)ti * tj * (ds + npairs);
     int* h = (int*)malloc(sizeof(int) * 4 * cap);
@@ -132,6 +133,30 @@ static int build_worklist(int Np, int it, int jt, int ds, int npairs, gpmpc_work
             }
     }
     w->ustart_host[ds + npairs] = n;
+    w->contiguous = 1;
+    if (xcd_sort && n >= 16) {
+        // Re-order so that the list position p (the pair kernel maps p % 8 to an XCD) groups tiles that share a COLUMN
+        // range: they read the same G rows and, per unit, the same column block of M.  Odd units use the mirrored
+        // column index so that the triangular tile counts (1..T per column block) balance across the 8 XCDs.
+        int* q[8]; int cnt[8] = {0}, pos[8] = {0};
+        for (int x = 0; x < 8; ++x) q[x] = (int*)malloc(sizeof(int) * 4 * (size_t)n);
+        for (int k = 0; k < n; ++k) {
+            const int u = h[4 * k], tjx = h[4 * k + 2] / jt;
+            const int x = ((u & 1) ? (tj - 1 - tjx) : tjx) & 7;
+            memcpy(q[x] + 4 * cnt[x]++, h + 4 * k, sizeof(int) * 4);
+        }
+        for (int p = 0; p < n; ++p) {
+            int x = p & 7;
+            if (pos[x] >= cnt[x]) {                             // this XCD's queue ran dry: take from the fullest one
+                int best = 0;
+                for (int y = 1; y < 8; ++y) if (cnt[y] - pos[y] > cnt[best] - pos[best]) best = y;
+                x = best;
+            }
+            memcpy(h + 4 * p, q[x] + 4 * pos[x]++, sizeof(int) * 4);
+        }
+        for (int x = 0; x < 8; ++x) free(q[x]);
+        w->contiguous = 0;
+    }
     w->it = it; w->waves = it / 64 > 0 ? it / 64 : 1; w->jt = jt; w->nunits = ds + npairs; w->nwork = n;
     hipError_t e = hipMalloc(&w->work_dev, sizeof(int) * 4 * (size_t)n);
     if (e == hipSuccess) e = hipMemcpy(w->work_dev, h, sizeof(int) * 4 * (size_t)n, hipMemcpyHostToDevice);
@@ -168,7 +193,7 @@ extern "C" int gpmpc_pack_create(gpmpc_pack** out, int n_train, int state_dim, i
     const int cfg[2][2] = {{256, 256}, {64, 64}};
     for (int mode = 0; mode < 2 && ok; ++mode)
         for (int k = 0; k < 2 && ok; ++k)
-            ok = build_worklist(p->Np, cfg[k][0], cfg[k][1], state_dim, mode ? p->npairs : 0, &p->wl[mode][k]) == 0;
+            ok = build_worklist(p->Np, cfg[k][0], cfg[k][1], state_dim, mode ? p->npairs : 0, mode == 0 && k == 0 && !getenv("GPMPC_NO_XCD_SORT"), &p->wl[mode][k]) == 0;
     if (!ok) { gpmpc_set_error("gpmpc_pack_create", e); gpmpc_pack_destroy(p); return GPMPC_E_ALLOC; }
     *out = p;
     return GPMPC_OK;

@@ -32,6 +32,7 @@ struct RollArgs {
     double* sp;    // [2][B][ds][sps] per-GP scalars of step t at [t & 1], kept for the finish phase of the next head launch
     double* part;  // [B][nwork][nm]; work items of GP a are [ustart[a], ustart[a+1])
     const int* ustart;
+    const int* work;   // [nwork][4] when the items of a unit are NOT contiguous (XCD-sorted list), else null
     double* jac;   // [B][H][2ds][2ds+da] or null
     double* G;     // [B][ds][Np][gw] column rows of the scalar-broadcast pair kernel, or null
     int gw;
@@ -62,7 +63,11 @@ __device__ static void finish_step(const RollArgs& A, int b, int t, int own, dou
                 const int a = o / nm, m = o - a * nm;
                 const double* p = A.part + (size_t)b * A.nwork * nm + m;
                 double s = 0.0;
-                for (int wi = A.ustart[a] + ch; wi < A.ustart[a + 1]; wi += GPMPC_RED_CH) s += p[(size_t)wi * nm];
+                if (A.work) {
+                    for (int wi = ch; wi < A.nwork; wi += GPMPC_RED_CH) if (A.work[4 * wi] == a) s += p[(size_t)wi * nm];
+                } else {
+                    for (int wi = A.ustart[a] + ch; wi < A.ustart[a + 1]; wi += GPMPC_RED_CH) s += p[(size_t)wi * nm];
+                }
                 s_red[o * GPMPC_RED_CH + ch] = s;
             }
         }
@@ -525,6 +530,7 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
     A.G = r.sb ? (double*)(ws + r.off_G) : nullptr; A.gw = r.gw;
     A.pps = r.pps; A.sps = r.sps; A.nwork = r.nwork; A.nm = r.nm; A.grad = grad ? 1 : 0;
     A.ustart = p->wl[0][r.tiling].ustart_dev;
+    A.work = p->wl[0][r.tiling].contiguous ? nullptr : p->wl[0][r.tiling].work_dev;
     A.out_cost = out_cost; A.out_grad = out_grad; A.cost = *cost;
 
     PairArgs P;
