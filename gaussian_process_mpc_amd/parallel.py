@@ -42,7 +42,7 @@ def gather_results(cost, grad, dist, sizes=None):
         flat = torch.cat((flat, flat.new_zeros(bmax - b, width)), dim=0)
     flat = flat.contiguous()
     out = flat.new_empty((world * bmax, width))
-    if flat.is_cuda:
+    if flat.is_cuda and dist.get_backend() == "nccl":
         dist.all_gather_into_tensor(out, flat)
     else:                                   # gloo: list form
         parts = [flat.new_empty((bmax, width)) for _ in range(world)]
