@@ -32,6 +32,21 @@ int gpmpc_launch_pair_sb(int D, bool grad, int tb, int ns2, int waves, const Pai
     return GPMPC_E_ARG;
 }
 
+int gpmpc_launch_pair_sbf(int D, bool grad, int ns2, int waves, const PairSbfArgs& a, hipStream_t s) {
+    if (waves < 1 || waves > 4) return GPMPC_E_ARG;
+    switch (D) {
+        case 1: return gpmpc_launch_pair_sbf_D<1>(grad, ns2, waves, a, s);
+        case 2: return gpmpc_launch_pair_sbf_D<2>(grad, ns2, waves, a, s);
+        case 3: return gpmpc_launch_pair_sbf_D<3>(grad, ns2, waves, a, s);
+        case 4: return gpmpc_launch_pair_sbf_D<4>(grad, ns2, waves, a, s);
+        case 5: return gpmpc_launch_pair_sbf_D<5>(grad, ns2, waves, a, s);
+        case 6: return gpmpc_launch_pair_sbf_D<6>(grad, ns2, waves, a, s);
+        case 7: return gpmpc_launch_pair_sbf_D<7>(grad, ns2, waves, a, s);
+        case 8: return gpmpc_launch_pair_sbf_D<8>(grad, ns2, waves, a, s);
+    }
+    return GPMPC_E_ARG;
+}
+
 // K*[r][i] = sf^2 exp(-1/2 sum_k (xp_rk - x_ik)^2 / lambda_k)      (src/gpr.py:266-283)
 __global__ void k_cross_kernel(const double* __restrict__ Xp, int p, const double* __restrict__ X, int N, int D,
                                const double* __restrict__ lam, double sf2, double* __restrict__ K) {

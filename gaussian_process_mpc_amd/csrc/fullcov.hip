@@ -11,6 +11,11 @@
 // risk-sensitive cost with full Sigma (src/mpc.py:179-198) and runs the reverse sweep.
 #include "gpmpc_internal.h"
 
+int gpmpc_moment_match_ex(const gpmpc_pack* p, int nq, const double* u, const double* S, unsigned flags,
+                          double* out_mean, double* out_var, double* out_cov, double* out_l, double* dmean_du,
+                          double* dmean_dS, double* dvar_du, double* dvar_dS, double* dcov_du, double* dcov_dS,
+                          void* workspace, size_t workspace_bytes, void* stream, int ns2);
+
 struct FcArgs {
     int B, H, ds, da, D, grad;
     const double* x0; const double* U;
@@ -243,11 +248,11 @@ extern "C" int gpmpc_rollout_fullcov(const gpmpc_pack* p, int B, int H, const do
     for (int t = 1; t <= H; ++t) {
         hipLaunchKernelGGL(k_fc_assemble, gb, tb, 0, s, A, t);
         const size_t sl = grad ? (size_t)(t - 1) * B : 0;
-        int rc = gpmpc_moment_match(p, B, A.u, A.S, grad ? GPMPC_WANT_GRAD : 0u, A.mean, var, A.cov, nullptr,
+        int rc = gpmpc_moment_match_ex(p, B, A.u, A.S, grad ? GPMPC_WANT_GRAD : 0u, A.mean, var, A.cov, nullptr,
                                     grad ? A.dmean_du + sl * ds * D : nullptr, grad ? A.dmean_dS + sl * ds * D * D : nullptr,
                                     grad ? dvu : nullptr, grad ? dvS : nullptr,
                                     grad ? A.dcov_du + sl * ds * ds * D : nullptr, grad ? A.dcov_dS + sl * ds * ds * D * D : nullptr,
-                                    ws + r.off_mm, r.mm_bytes, stream);
+                                    ws + r.off_mm, r.mm_bytes, stream, p->ds);
         if (rc != GPMPC_OK) return rc;
     }
     hipLaunchKernelGGL(k_fc_assemble, gb, tb, 0, s, A, H + 1);      // records step H

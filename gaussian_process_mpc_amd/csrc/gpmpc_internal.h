@@ -83,6 +83,20 @@ static inline int gpmpc_sb_gw(int D, int ns2) { return (D + 1 + ns2 + 1) & ~1; }
 int gpmpc_launch_pair_sb(int D, bool grad, int tb, int ns2, int waves, const PairSbArgs& a, hipStream_t s);
 template <int D> int gpmpc_launch_pair_sb_D(bool grad, int tb, int ns2, int waves, const PairSbArgs& a, hipStream_t s);
 
+// Arguments of the general scalar-broadcast pair kernel (pair_kernel_sbf.h): full S, variance + cross units.
+struct PairSbfArgs {
+    const double* M;      // [units][Np][Np]
+    const double* XT;     // [D][Np]
+    const double* pp;     // [B][nunits][pps]: row-side cvec[D] + T[D][D] (upper triangular)
+    const double* G;      // [B][nunits][Np][GW] column rows [q_j (D) | |q_j|^2 | q_jk q_jl (k <= l < ns2) | pad]
+    double* part;         // [B][nwork][nm]
+    const int* work;      // [nwork][4] = {unit, i0, j0, j1}
+    int Np, B, nunits, nwork, pps, nm, ntri;
+};
+static inline int gpmpc_sbf_gw(int D, int ns2) { return (D + 1 + ns2 * (ns2 + 1) / 2 + 1) & ~1; }
+int gpmpc_launch_pair_sbf(int D, bool grad, int ns2, int waves, const PairSbfArgs& a, hipStream_t s);
+template <int D> int gpmpc_launch_pair_sbf_D(bool grad, int ns2, int waves, const PairSbfArgs& a, hipStream_t s);
+
 // Implemented in pair_d*.hip (one translation unit per D so the build parallelises).
 int gpmpc_launch_pair(int D, bool diag, bool grad, int tb, int waves, const PairArgs& a, hipStream_t s);
 template <int D> int gpmpc_launch_pair_D(bool diag, bool grad, int tb, int waves, const PairArgs& a, hipStream_t s);

@@ -9,8 +9,10 @@
 //   dT/du  = -4 c Cm^T Z1,         dT/dS  = -1/2 T A + 8 c Cm^T Z2 Cm        (since A Cm^-1 = 8 Cm^T)
 // with S1 = sum p_i v_i, S2 = sum p_i v_i v_i^T and Z* the pair-kernel moments in h-space.
 #include "gpmpc_internal.h"
+#include <cstdlib>
 
 int gpmpc_timed_pair(int D, bool diag, bool grad, int tb, int waves, const PairArgs& a, hipStream_t s);
+int gpmpc_timed_pair_sbf(int D, bool grad, int ns2, int waves, const PairSbfArgs& a, hipStream_t s);
 
 struct MomArgs {
     const double* XT; const double* beta; const double* lam; const double* sf;
@@ -20,6 +22,7 @@ struct MomArgs {
     int pps, sps, nwork, nunits, nm, grad;
     const int* ustart;            // work items of unit u: [ustart[u], ustart[u+1])
     const int* pair_ab; int npairs;   // cross units evaluated by the pair kernel (0: none)
+    double* G; int gw, ns2;           // column rows of the scalar-broadcast kernel (pair_kernel_sbf.h), or null
     double* out_mean; double* out_var; double* out_cov; double* out_l;
     double* dmean_du; double* dmean_dS; double* dvar_du; double* dvar_dS; double* dcov_du; double* dcov_dS;
     unsigned flags;
@@ -204,6 +207,41 @@ __global__ __launch_bounds__(256) void k_mom_prep(MomArgs A) {
             pr_r[k] = sr; pr_c[k] = sc;
         }
     }
+    if (!A.G) return;
+    // Column rows of every unit for the scalar-broadcast pair kernel: [q_j (D) | |q_j|^2 | q_jk q_jl (k <= l < ns2) | pad]
+    // with q_j = cvec_c - T_c x_j, the unit's COLUMN-side transform written above by this workgroup.
+    __syncthreads();
+    for (int u = 0; u < A.nunits; ++u) {
+        const double* prc = A.pp + ((size_t)q * A.nunits + u) * A.pps + D + D * D;
+        double* Gu = A.G + ((size_t)q * A.nunits + u) * A.Np * A.gw;
+        double cv[D], T[D * D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) cv[k] = prc[k];
+#pragma unroll
+        for (int e = 0; e < D * D; ++e) T[e] = prc[D + e];
+        for (int i = threadIdx.x; i < A.Np; i += blockDim.x) {
+            double x[D], qv[D], qq = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) x[k] = A.XT[(size_t)k * A.Np + i];
+            double* g = Gu + (size_t)i * A.gw;
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                double sacc = cv[k];
+#pragma unroll
+                for (int l = k; l < D; ++l) sacc = fma(-T[k * D + l], x[l], sacc);
+                qv[k] = sacc; g[k] = sacc;
+                qq = fma(sacc, sacc, qq);
+            }
+            g[D] = qq;
+            int o = D + 1;
+#pragma unroll
+            for (int k = 0; k < D; ++k)
+#pragma unroll
+                for (int l = k; l < D; ++l)
+                    if (k < A.ns2 && l < A.ns2) { g[o] = qv[k] * qv[l]; ++o; }
+            for (; o < A.gw; ++o) g[o] = 0.0;
+        }
+    }
 }
 
 template <int D>
@@ -386,14 +424,18 @@ __global__ __launch_bounds__(256) void k_cross_cov(MomArgs A, const int* __restr
     }
 }
 
-struct MomPlan { int mode, tiling, tb, waves, nwork, nunits, nm, pps, sps; size_t off_pp, off_sp, off_part, off_pairs, total; };
+struct MomPlan { int mode, tiling, tb, waves, nwork, nunits, nm, pps, sps, sbf, gw; size_t off_pp, off_sp, off_part, off_pairs, off_G, total; };
 
-static void plan_mom(const gpmpc_pack* p, int nq, bool grad, bool pair_cov, MomPlan* r) {
+static void plan_mom(const gpmpc_pack* p, int nq, bool grad, bool pair_cov, int ns2, MomPlan* r) {
     const int D = p->D;
     r->mode = pair_cov ? 1 : 0;
     r->tb = nq >= 2 ? 2 : 1;
     const long groups = (nq + r->tb - 1) / r->tb;
     r->tiling = (groups * p->wl[r->mode][0].nwork >= 1024) ? 0 : 1;
+    // scalar-broadcast kernel (pair_kernel_sbf.h) once the grid fills the chip; GPMPC_PAIR_SB=0 keeps the staged kernel
+    r->sbf = (r->tiling == 0 && D - ns2 <= 2) ? 1 : 0;
+    if (const char* ev = getenv("GPMPC_PAIR_SB")) if (atoi(ev) == 0) r->sbf = 0;
+    r->gw = gpmpc_sbf_gw(D, ns2);
     const gpmpc_worklist& w = p->wl[r->mode][r->tiling];
     r->waves = w.waves; r->nwork = w.nwork; r->nunits = w.nunits;
     r->nm = gpmpc_num_moments(D, false, grad);
@@ -405,6 +447,7 @@ static void plan_mom(const gpmpc_pack* p, int nq, bool grad, bool pair_cov, MomP
     r->off_sp = take(sizeof(double) * (size_t)nq * r->nunits * r->sps);
     r->off_part = take(sizeof(double) * (size_t)nq * r->nwork * r->nm);
     r->off_pairs = take(sizeof(int) * 2 * GPMPC_MAX_DS * GPMPC_MAX_DS);
+    r->off_G = take(r->sbf ? sizeof(double) * (size_t)nq * r->nunits * p->Np * r->gw : 0);
     r->total = off;
 }
 
@@ -413,9 +456,11 @@ extern "C" size_t gpmpc_moment_match_workspace_bytes(const gpmpc_pack* p, int nq
     size_t best = 0;
     for (int g = 0; g < 2; ++g)
         for (int pc = 0; pc < 2; ++pc) {
-            MomPlan r;
-            plan_mom(p, nq, g != 0, pc != 0, &r);
-            if (r.total > best) best = r.total;
+            for (int ns2 = p->ds; ns2 <= p->D; ns2 += (p->D > p->ds ? p->D - p->ds : 1)) {
+                MomPlan r;
+                plan_mom(p, nq, g != 0, pc != 0, ns2, &r);
+                if (r.total > best) best = r.total;
+            }
         }
     return best;
 }
@@ -427,7 +472,15 @@ static int run_mom(const gpmpc_pack* p, MomArgs& A, const MomPlan& r, bool grad,
     P.M = p->M; P.XT = p->XT; P.pp = A.pp; P.part = A.part; P.work = p->wl[r.mode][r.tiling].work_dev;
     P.Np = p->Np; P.B = A.nq; P.nunits = r.nunits; P.nwork = r.nwork; P.pps = r.pps; P.nm = r.nm;
     P.jside_off = D + D * D; P.ntri = p->ds; P.ns2 = D; P.colsplit = (r.tiling == 1) ? 1 : 0;
-    int rc = gpmpc_timed_pair(D, false, grad, r.tb, P.colsplit ? 4 : r.waves, P, s);
+    int rc;
+    if (r.sbf) {
+        PairSbfArgs Q;
+        Q.M = p->M; Q.XT = p->XT; Q.pp = A.pp; Q.G = A.G; Q.part = A.part; Q.work = P.work;
+        Q.Np = p->Np; Q.B = A.nq; Q.nunits = r.nunits; Q.nwork = r.nwork; Q.pps = r.pps; Q.nm = r.nm; Q.ntri = p->ds;
+        rc = gpmpc_timed_pair_sbf(D, grad, A.ns2, r.waves, Q, s);
+    } else {
+        rc = gpmpc_timed_pair(D, false, grad, r.tb, P.colsplit ? 4 : r.waves, P, s);
+    }
     if (rc != GPMPC_OK) return rc;
     hipLaunchKernelGGL(k_mom_finish<D>, dim3(A.nq), dim3(64), 0, s, A);
     if (A.out_cov && p->ds > 1 && A.npairs == 0) {          // direct N^2 kernel (also the bug-compatible form)
@@ -445,10 +498,12 @@ static int run_mom(const gpmpc_pack* p, MomArgs& A, const MomPlan& r, bool grad,
     return GPMPC_OK;
 }
 
-extern "C" int gpmpc_moment_match(const gpmpc_pack* p, int nq, const double* u, const double* S, unsigned flags,
-                                  double* out_mean, double* out_var, double* out_cov, double* out_l, double* dmean_du,
-                                  double* dmean_dS, double* dvar_du, double* dvar_dS, double* dcov_du, double* dcov_dS,
-                                  void* workspace, size_t workspace_bytes, void* stream) {
+// ns2: leading input dimensions whose S-derivatives are needed (D for the public entry point; state_dim for the
+// full-covariance rollout, whose action block of S is a constant).
+int gpmpc_moment_match_ex(const gpmpc_pack* p, int nq, const double* u, const double* S, unsigned flags,
+                          double* out_mean, double* out_var, double* out_cov, double* out_l, double* dmean_du,
+                          double* dmean_dS, double* dvar_du, double* dvar_dS, double* dcov_du, double* dcov_dS,
+                          void* workspace, size_t workspace_bytes, void* stream, int ns2) {
     if (!p || !u || !S || !out_mean || !out_var || !workspace || nq < 1) return GPMPC_E_ARG;
     if (!p->built) return GPMPC_E_STATE;
     const bool grad = (flags & GPMPC_WANT_GRAD) != 0;
@@ -458,8 +513,9 @@ extern "C" int gpmpc_moment_match(const gpmpc_pack* p, int nq, const double* u, 
     // cross-covariances through the pair kernel (with Jacobians) need the cross weight matrices of the pack
     const bool pair_cov = out_cov && !bug && p->fullcov && p->npairs > 0;
     if (dcov_du && (!grad || !out_cov || bug || (p->npairs > 0 && !p->fullcov))) return GPMPC_E_STATE;
+    if (ns2 < 1 || ns2 > p->D) return GPMPC_E_ARG;
     MomPlan r;
-    plan_mom(p, nq, grad, pair_cov, &r);
+    plan_mom(p, nq, grad, pair_cov, ns2, &r);
     if (workspace_bytes < r.total) return GPMPC_E_WORKSPACE;
     char* ws = (char*)workspace;
     MomArgs A;
@@ -474,6 +530,7 @@ extern "C" int gpmpc_moment_match(const gpmpc_pack* p, int nq, const double* u, 
     A.out_mean = out_mean; A.out_var = out_var; A.out_cov = out_cov; A.out_l = out_l;
     A.dmean_du = dmean_du; A.dmean_dS = dmean_dS; A.dvar_du = dvar_du; A.dvar_dS = dvar_dS;
     A.dcov_du = dcov_du; A.dcov_dS = dcov_dS;
+    A.G = r.sbf ? (double*)(ws + r.off_G) : nullptr; A.gw = r.gw; A.ns2 = ns2;
     A.flags = flags;
     hipStream_t s = (hipStream_t)stream;
     int* pairs_dev = (int*)(ws + r.off_pairs);
@@ -488,4 +545,13 @@ extern "C" int gpmpc_moment_match(const gpmpc_pack* p, int nq, const double* u, 
         case 8: return run_mom<8>(p, A, r, grad, s, pairs_dev);
     }
     return GPMPC_E_ARG;
+}
+
+extern "C" int gpmpc_moment_match(const gpmpc_pack* p, int nq, const double* u, const double* S, unsigned flags,
+                                  double* out_mean, double* out_var, double* out_cov, double* out_l, double* dmean_du,
+                                  double* dmean_dS, double* dvar_du, double* dvar_dS, double* dcov_du, double* dcov_dS,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+    if (!p) return GPMPC_E_ARG;
+    return gpmpc_moment_match_ex(p, nq, u, S, flags, out_mean, out_var, out_cov, out_l, dmean_du, dmean_dS, dvar_du, dvar_dS,
+                                 dcov_du, dcov_dS, workspace, workspace_bytes, stream, p->D);
 }

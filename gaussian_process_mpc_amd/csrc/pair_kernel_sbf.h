@@ -1,0 +1,146 @@
+// Scalar-broadcast pair kernel, general form: full input covariance S (upper-triangular transforms), variance AND
+// cross-covariance units, full second moments.  Used by gpmpc_moment_match with Jacobians and by the full-covariance
+// rollout (config 5).  Same regrouping as pair_kernel_sb.h, with different row / column transforms per unit:
+//     P_ij = M_ij exp(-|p_i + q_j|^2),      |p_i + q_j|^2 = |p_i|^2 + |q_j|^2 + sum_k (2 p_ik) q_jk
+//     r_i = sum_j P_ij,   v_ik = sum_j P_ij q_jk,   W_i,kl = sum_j P_ij q_jk q_jl      (k <= l < NS2)
+//     Z0 = sum_i r_i,  Z1_k = sum_i (p_ik r_i + v_ik),  Z2_kl = sum_i (p_ik p_il r_i + p_ik v_il + p_il v_ik + W_i,kl)
+// The column rows G[unit][j] = [q_j (D) | |q_j|^2 | q_jk q_jl (k <= l < NS2)] are written by k_mom_prep (moment.hip)
+// and fetched with scalar loads; reference: src/tools/uncertainty_prop.py:372-399 (variance), :402-465 (covariance).
+// NS2 < D (the rollout: NS2 = state_dim) leaves Z2_kl for k or l >= NS2 at zero: the transforms are upper
+// triangular, so dT/dS_rc for r, c < NS2 only needs Z2_kl with k <= r, l <= c.
+#pragma once
+#include <cstdlib>
+#include "gpmpc_internal.h"
+#include "fast_exp.h"
+
+template <int D, int NS2, bool GRAD>
+__global__ __launch_bounds__(256) void gpmpc_pair_kernel_sbf(PairSbfArgs A) {
+    constexpr int NW = NS2 * (NS2 + 1) / 2;
+    constexpr int GW = (D + 1 + NW + 1) & ~1;
+    constexpr int NM = GRAD ? 1 + D + D * (D + 1) / 2 : 1, NA = GRAD ? 1 + D + NW : 1;
+    __shared__ double s_red[4 * NM];
+    __shared__ double s_tab[GPMPC_EXP_N];
+    gpmpc_exp_table_to_lds(s_tab);
+
+    int b, wi;                                            // XCD-aware decode, see pair_kernel.h (TB = 1)
+    {
+        const int groups = A.B, items = A.nwork;
+        const int L = blockIdx.x, full = (items >> 3) << 3;
+        if (L < full * groups) { const int q = L >> 3; wi = (q / groups) * 8 + (L & 7); b = q % groups; }
+        else { const int Lt = L - full * groups; wi = full + Lt / groups; b = Lt % groups; }
+    }
+    const int unit = A.work[wi * 4 + 0], i0 = A.work[wi * 4 + 1], j0 = A.work[wi * 4 + 2], j1 = A.work[wi * 4 + 3];
+    const bool tri = unit < A.ntri;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);    // provably wave-uniform -> scalar loads of the G rows
+    const int Np = A.Np;
+    const int iw0 = i0 + w * 64;
+    const bool active = iw0 < Np;
+    const int i = iw0 + lane;
+
+    const double* __restrict__ prm = A.pp + ((size_t)b * A.nunits + unit) * A.pps;     // row-side transform
+    const double* __restrict__ G = A.G + ((size_t)b * A.nunits + unit) * Np * GW;
+    double p[D], p2[D], qi = 0.0;
+    {
+        double x[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) x[k] = active ? A.XT[(size_t)k * Np + i] : 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            double s = prm[k];
+#pragma unroll
+            for (int l = k; l < D; ++l) s = fma(-prm[D + k * D + l], x[l], s);
+            p[k] = s; p2[k] = 2.0 * s;
+            qi = fma(s, s, qi);
+        }
+    }
+    double acc[NA];
+#pragma unroll
+    for (int m = 0; m < NA; ++m) acc[m] = 0.0;
+
+    const double* __restrict__ Ma = A.M + (size_t)unit * Np * Np;
+    __syncthreads();                                      // exp table ready
+
+    if (active) {
+        const int jdiag = iw0 & ~63;
+        const int jstart = (tri && jdiag > j0) ? jdiag : j0;   // symmetric units: zero weight left of the diagonal chunk
+        for (int jc = jstart; jc < j1; jc += 4) {
+            double mij[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mij[q] = Ma[(size_t)(jc + q) * Np + i];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double* __restrict__ g = G + (size_t)(jc + q) * GW;              // wave-uniform address -> SGPRs
+                double s = qi + g[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k) s = fma(p2[k], g[k], s);
+                const double P = mij[q] * gpmpc_exp_neg(s, s_tab);
+                acc[0] += P;
+                if (GRAD) {
+#pragma unroll
+                    for (int k = 0; k < D; ++k) acc[1 + k] = fma(P, g[k], acc[1 + k]);
+#pragma unroll
+                    for (int k = 0; k < NW; ++k) acc[1 + D + k] = fma(P, g[D + 1 + k], acc[1 + D + k]);
+                }
+            }
+        }
+    }
+
+    double z[NM];
+    z[0] = acc[0];
+    if (GRAD) {
+        const double r = acc[0];
+#pragma unroll
+        for (int k = 0; k < D; ++k) z[1 + k] = fma(p[k], r, acc[GRAD ? 1 + k : 0]);
+        int o = 1 + D, ow = 0;
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+#pragma unroll
+            for (int l = k; l < D; ++l) {
+                double v = 0.0;
+                if (k < NS2 && l < NS2) {
+                    // position of (k,l), k <= l < NS2, in the packed W list (row-major upper triangle of NS2 x NS2)
+                    const int idx = k * NS2 - k * (k - 1) / 2 + (l - k);
+                    v = fma(p[k] * p[l], r, fma(p[k], acc[GRAD ? 1 + l : 0], fma(p[l], acc[GRAD ? 1 + k : 0], acc[GRAD ? 1 + D + idx : 0])));
+                }
+                z[GRAD ? o : 0] = v;
+                ++o; (void)ow;
+            }
+    }
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+        const double s = wave_sum(z[m]);
+        if (lane == 0) s_red[w * NM + m] = s;
+    }
+    __syncthreads();
+    for (int m = tid; m < NM; m += blockDim.x) {
+        double s = 0.0;
+        for (int ww = 0; ww < (int)(blockDim.x >> 6); ++ww) s += s_red[ww * NM + m];
+        A.part[((size_t)b * A.nwork + wi) * A.nm + m] = s;
+    }
+}
+
+template <int D, int NS2, bool GRAD>
+static int launch_pair_sbf_one(int waves, const PairSbfArgs& a, hipStream_t s) {
+    dim3 grid(a.B * a.nwork), block(64 * waves);
+    hipLaunchKernelGGL((gpmpc_pair_kernel_sbf<D, NS2, GRAD>), grid, block, 0, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { gpmpc_set_error("pair kernel (scalar broadcast, full S) launch", e); return GPMPC_E_LAUNCH; }
+    return GPMPC_OK;
+}
+
+template <int D>
+int gpmpc_launch_pair_sbf_D(bool grad, int ns2, int waves, const PairSbfArgs& a, hipStream_t s) {
+    if (a.nm != (grad ? 1 + D + D * (D + 1) / 2 : 1)) return GPMPC_E_ARG;
+#define GPMPC_SBF_CASE(GR)                                                                                   \
+    if (grad == GR) {                                                                                        \
+        if (ns2 == D) return launch_pair_sbf_one<D, D, GR>(waves, a, s);                                     \
+        if (D >= 2 && ns2 == D - 1) return launch_pair_sbf_one<D, (D >= 2 ? D - 1 : D), GR>(waves, a, s);   \
+        if (D >= 3 && ns2 == D - 2) return launch_pair_sbf_one<D, (D >= 3 ? D - 2 : D), GR>(waves, a, s);   \
+        return GPMPC_E_ARG;                                                                                  \
+    }
+    GPMPC_SBF_CASE(true)
+    GPMPC_SBF_CASE(false)
+#undef GPMPC_SBF_CASE
+    return GPMPC_E_ARG;
+}

@@ -461,6 +461,19 @@ int gpmpc_timed_pair_sb(int D, bool grad, int tb, int ns2, int waves, const Pair
     return rc;
 }
 
+int gpmpc_timed_pair_sbf(int D, bool grad, int ns2, int waves, const PairSbfArgs& a, hipStream_t s) {
+    if (!g_timing) return gpmpc_launch_pair_sbf(D, grad, ns2, waves, a, s);
+    if (g_npending == 4096) drain_events();
+    EvPair ev;
+    GPMPC_HIP(hipEventCreate(&ev.a));
+    GPMPC_HIP(hipEventCreate(&ev.b));
+    GPMPC_HIP(hipEventRecord(ev.a, s));
+    int rc = gpmpc_launch_pair_sbf(D, grad, ns2, waves, a, s);
+    GPMPC_HIP(hipEventRecord(ev.b, s));
+    g_pending[g_npending++] = ev;
+    return rc;
+}
+
 struct RollPlan { int tiling, tb, waves, nwork, nm, pps, sps, sb, gw; size_t off_G; size_t off_pp, off_sp, off_part, off_jac, off_means, off_vars, total; };
 
 static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag, RollPlan* r) {

@@ -344,3 +344,50 @@ def test_graph_replay_matches_eager(G, golden):
     e = G.rollout(pack, z["x0"][0], z["U"][0], cost2)
     g = G.rollout(pack, z["x0"][0], z["U"][0], cost2, graph=True)
     assert torch.equal(e["cost"], g["cost"]) and torch.equal(e["grad"], g["grad"])
+
+
+def test_scalar_broadcast_kernels_match_staged(G, golden, monkeypatch):
+    """The scalar-broadcast pair kernels (pair_kernel_sb.h / pair_kernel_sbf.h: expanded exponent, row-grouped moments)
+    take over once the grid fills the chip; force both forms on the same large batch and compare them with each other
+    and, for a few entries, with the reference's fixtures."""
+    z = golden("g2_adversarial.npz")
+    p = "c3_"                                                       # D = 4, full S
+    sf1, sf2, _ = z[p + "hyp"]
+    pack = G.GPPack(z[p + "X"], np.stack([z[p + "y1"], z[p + "y2"]], axis=1),
+                    np.stack([z[p + "Kinv1"], z[p + "Kinv2"]]), np.stack([z[p + "lam1"], z[p + "lam2"]]),
+                    np.array([sf1, sf2])).enable_fullcov()
+    rng = np.random.default_rng(8)
+    nq, D = 900, 4
+    u = z[p + "u"] + 0.3 * rng.normal(size=(nq, D))
+    Aq = rng.normal(size=(nq, D, D))
+    S = 0.03 * Aq @ np.swapaxes(Aq, 1, 2) + 0.01 * np.eye(D)
+    u[0], S[0] = z[p + "u"], z[p + "S"]
+    monkeypatch.setenv("GPMPC_PAIR_SB", "0")
+    a = G.moment_match(pack, u, S, want_cov=True, want_grad=True)
+    monkeypatch.setenv("GPMPC_PAIR_SB", "1")
+    b = G.moment_match(pack, u, S, want_cov=True, want_grad=True)
+    for k in a:
+        x, y = a[k].cpu().numpy(), b[k].cpu().numpy()
+        np.testing.assert_allclose(y, x, rtol=1e-6, atol=1e-9 * max(1.0, np.abs(x).max()), err_msg=k)
+    np.testing.assert_allclose(b["var"][0].cpu().numpy(), z[p + "var"], rtol=1e-6)
+    sym = lambda M: 0.5 * (M + M.T)                                 # noqa: E731
+    np.testing.assert_allclose(b["dvar_dS"][0, 0].cpu().numpy(), sym(z[p + "dv_dS"]), rtol=1e-5, atol=1e-7)
+    # rollouts: diagonal (pair_kernel_sb.h) and full covariance (pair_kernel_sbf.h with NS2 = state_dim)
+    from gaussian_process_mpc_amd.synth import synth_problem
+    from oracle import gpmpc_oracle as O
+    pb = synth_problem(31, 100, 2, 1, 3, 700)
+    gp = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"])
+    pk = G.GPPack(pb["X"], pb["Y"], gp.Ky_inv.numpy(), pb["lambdas"], pb["sigma_f"])
+    cost = G.CostParams(-1.0, pb["Q"] + 0.02 * (1 - np.eye(2)), pb["R"])
+    for fn in (G.rollout, G.rollout_fullcov):
+        monkeypatch.setenv("GPMPC_PAIR_SB", "0")
+        a = fn(pk, pb["x0"], pb["U"], cost)
+        monkeypatch.setenv("GPMPC_PAIR_SB", "1")
+        b = fn(pk, pb["x0"], pb["U"], cost)
+        for k in a:
+            x, y = a[k].cpu().numpy(), b[k].cpu().numpy()
+            np.testing.assert_allclose(y, x, rtol=1e-6, atol=1e-10, err_msg=f"{fn.__name__}:{k}")
+        assert not all(torch.equal(a[k], b[k]) for k in a)          # two different kernels really ran
+    o = O.objective_and_gradient_fullcov(gp, 3, pb["x0"][5], pb["U"][5], pb["x_ref"], pb["u_ref"], cost_Q := pb["Q"] + 0.02 * (1 - np.eye(2)), pb["R"], -1.0)
+    np.testing.assert_allclose(b["covs"][5].cpu().numpy(), o["covs"], rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(b["grad"][5].cpu().numpy(), o["grad"], rtol=1e-4, atol=1e-7)
