@@ -52,3 +52,21 @@ def gather_results(cost, grad, dist, sizes=None):
     cost_all = rows[:, 0].contiguous()
     grad_all = None if grad is None else rows[:, 1:].reshape(-1, *grad.shape[1:]).contiguous()
     return cost_all, grad_all
+
+
+def sharded_rollout(rollout_fn, x0, U, dist, want_grad=True):
+    """Evaluate a GLOBAL batch of candidate trajectories across the ranks of ``dist``: every rank calls this with the
+    same (x0, U); rank r evaluates its contiguous block with ``rollout_fn(x0_block, U_block) -> dict(cost, grad)`` and
+    all ranks receive the full (cost, grad).  x0: (B, ds) or (ds,); U: (B, H, da)."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    B = U.shape[0]
+    lo, hi = shard_range(B, world, rank)
+    sizes = shard_sizes(B, world)
+    x0_blk = x0 if getattr(x0, "ndim", 1) == 1 else x0[lo:hi]
+    if hi > lo:
+        r = rollout_fn(x0_blk, U[lo:hi])
+        cost, grad = r["cost"], (r["grad"] if want_grad else None)
+    else:                                   # more ranks than trajectories: contribute an empty block
+        cost = U.new_zeros((0,)) if isinstance(U, torch.Tensor) else torch.zeros(0, dtype=torch.float64)
+        grad = None if not want_grad else torch.zeros((0,) + tuple(U.shape[1:]), dtype=torch.float64, device=cost.device)
+    return gather_results(cost, grad, dist, sizes)

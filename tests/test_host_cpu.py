@@ -149,10 +149,15 @@ def _gloo_worker(rank, world, port, ragged, q):
     sizes = shard_sizes(n, world)
     c, g = gather_results(cost_all[lo:hi].clone(), grad_all[lo:hi].clone(), dist, sizes if ragged else None)
     c2, g2 = gather_results(cost_all[lo:hi].clone(), None, dist, sizes if ragged else None)
+    from gaussian_process_mpc_amd.parallel import sharded_rollout
+    fake = lambda x0b, Ub: {"cost": Ub.sum(dim=(1, 2)), "grad": 2.0 * Ub}      # stands in for the device rollout  # noqa: E731
+    Uall = torch.arange(n * H * da, dtype=torch.float64).reshape(n, H, da) / 7.0
+    cs, gs = sharded_rollout(fake, torch.zeros(3), Uall, dist)
+    ok_sharded = bool(torch.equal(cs, Uall.sum(dim=(1, 2))) and torch.equal(gs, 2.0 * Uall))
     kinv = torch.full((2, 4, 4), float(rank + 1), dtype=torch.float64)
     broadcast_kinv(kinv, dist, src=0)
     ok = bool(torch.equal(c, cost_all) and torch.equal(g, grad_all) and torch.equal(c2, cost_all) and g2 is None
-              and torch.all(kinv == 1.0))
+              and torch.all(kinv == 1.0) and ok_sharded)
     q.put((rank, ok))
     dist.destroy_process_group()
 
