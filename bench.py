@@ -202,10 +202,13 @@ def main():
                 "bound_note": "fp64 VALU issue (software exp dominates); priced against the fp64 peak, which is the "
                               "same 78.6 TFLOP/s for vector and MFMA on MI355X. HBM is not binding at B>=4.",
                 "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
-                # HBM bytes per launch from the PMC passes of the same command (FETCH_SIZE x 2 + WRITE_SIZE,
-                # gfx950 correction): profiles/r01/pmc_c3_v1c.txt.  Only measured for the default C3 workload.
-                "traffic": 7.6e7 if (args.config == "C3" and B == 256 and want_grad and not fullcov) else None,
-                "traffic_source": "profiles/r01/pmc_c3_v1c.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, x2 read correction)",
+                # Fabric-side bytes per launch from the PMC passes of the same command (FETCH_SIZE x 2 + WRITE_SIZE, the
+                # gfx950 correction for wide reads; an upper bound here, the scalar-cache line fills are uncalibrated):
+                # profiles/r01/pmc_c3_final.txt.  Only measured for the default C3 workload.  Algorithmic: 67 MB of M
+                # + 168 MB of column rows; the rows are re-read once per row tile (4.5x) because 256 trajectories x 20 KB
+                # overflow an XCD's 4 MB L2 between two tiles of a column block -- 0.3-0.6 TB/s, far from binding.
+                "traffic": 1.49e9 if (args.config == "C3" and B == 256 and want_grad and not fullcov) else None,
+                "traffic_source": "profiles/r01/pmc_c3_final.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, x2 read correction)",
                 "algorithmic_flops_per_pair": fl, "algorithmic_slots_per_pair": slots,
                 "valu_slot_frac": pairs_per_launch * slots / launch_s / 39.3e12,
                 "pairs_per_launch": pairs_per_launch, "avg_launch_ms": launch_s * 1e3, "launches": nl.value,
