@@ -1,4 +1,6 @@
-// The O(N^2) pair kernel: the dominant kernel of the rollout.
+// The O(N^2) pair kernel, general ("staged") form.  The rollout's hot path uses the scalar-broadcast forms
+// (pair_kernel_sb.h, pair_kernel_sbf.h) once the grid fills the chip; this kernel serves small batches (one-wave /
+// column-split 64x64 tiles), the objective-only full-S path and is the A/B reference of the others (GPMPC_PAIR_SB=0).
 //
 // For one (trajectory b, unit) it evaluates
 //     Z0 = sum_{i,j} M_ij exp(-|p_i + q_j|^2),      p_i = cvec_r - T_r x_i (rows),  q_j = cvec_c - T_c x_j (columns)

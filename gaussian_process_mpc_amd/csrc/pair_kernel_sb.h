@@ -26,10 +26,8 @@ struct PairSbTraits {
     static constexpr int GW = (D + 1 + NS2 + 1) & ~1;     // doubles per G row (even: rows stay 16-byte aligned)
 };
 
-// RI: rows per lane (the workgroup has it / (64 RI) waves; lane l of wave w owns rows iw0 + 64 r + l, r < RI).
-//     One fetched G row then serves RI pair-evaluations per lane.
-// GRAD = false: objective only (Z0), NM = 1.
-template <int D, int TB, int NS2, int RI, bool GRAD>
+// GRAD = false: objective only (Z0), NM = 1.  (A two-rows-per-lane shape was measured 15 % slower: occupancy wins.)
+template <int D, int TB, int NS2, bool GRAD>
 __global__ __launch_bounds__(256) void gpmpc_pair_kernel_sb(PairSbArgs A) {
     constexpr int GW = PairSbTraits<D, NS2>::GW;
     constexpr int NM = GRAD ? 1 + 2 * D : 1, NA = GRAD ? 1 + D + NS2 : 1;
@@ -50,7 +48,8 @@ __global__ __launch_bounds__(256) void gpmpc_pair_kernel_sb(PairSbArgs A) {
     // below is provably wave-uniform and the G rows are fetched by scalar loads
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Np = A.Np;
-    const int iw0 = i0 + w * 64 * RI;                     // first row of this wave (wave-uniform)
+    constexpr int RI = 1;
+    const int iw0 = i0 + w * 64;                          // first row of this wave (wave-uniform)
 
     const double* __restrict__ Gt[TB];
     double hi2[TB][RI][D], qi[TB][RI];
@@ -157,16 +156,13 @@ __global__ __launch_bounds__(256) void gpmpc_pair_kernel_sb(PairSbArgs A) {
     }
 }
 
-// `rows` = rows per tile of the work list (64 or 256); the workgroup has rows / (64 RI) waves.
-// RI = 1 and TB = 1 (59 VGPRs, 8 waves/SIMD at D = 5) is the fastest shape on MI355X: occupancy hides the scalar-load
-// and table-read latencies (C3: 2.30 ms per launch; TB 2: 2.41; RI 2: 2.65; staged pair_kernel.h TB 2: 2.82).
+// `rows` = rows per tile of the work list (64 or 256) = threads per workgroup.
+// TB = 1 (59 VGPRs, 8 waves/SIMD at D = 5) is the fastest shape on MI355X: occupancy hides the scalar-load and
+// table-read latencies (C3: 2.30 ms per launch; TB 2: 2.41; two rows per lane: 2.65; staged pair_kernel.h TB 2: 2.82).
 template <int D, int TB, int NS2, bool GRAD>
 static int launch_pair_sb_one(int rows, const PairSbArgs& a, hipStream_t s) {
-    int ri = 1;
-    if (const char* ev = getenv("GPMPC_PAIR_RI")) { const int v = atoi(ev); if ((v == 1 || v == 2) && rows >= 64 * v) ri = v; }
-    dim3 grid(((a.B + TB - 1) / TB) * a.nwork), block(rows / ri);
-    if (ri == 2) hipLaunchKernelGGL((gpmpc_pair_kernel_sb<D, TB, NS2, 2, GRAD>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((gpmpc_pair_kernel_sb<D, TB, NS2, 1, GRAD>), grid, block, 0, s, a);
+    dim3 grid(((a.B + TB - 1) / TB) * a.nwork), block(rows);
+    hipLaunchKernelGGL((gpmpc_pair_kernel_sb<D, TB, NS2, GRAD>), grid, block, 0, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { gpmpc_set_error("pair kernel (scalar broadcast) launch", e); return GPMPC_E_LAUNCH; }
     return GPMPC_OK;
