@@ -68,6 +68,8 @@ SIGNATURES = {
     "gpmpc_timing_enable": (_i, [_i]),
     "gpmpc_pair_kernel_time": (_i, [_dp, ctypes.POINTER(ctypes.c_longlong), _i]),
     "gpmpc_matvec": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
+    "gpmpc_kinv_append_workspace_bytes": (_sz, [_i]),
+    "gpmpc_kinv_append": (_i, [_i, _vp, _vp, _d, _vp, _vp, _sz, _vp]),
     "gpmpc_predict_workspace_bytes": (_sz, [_i, _i, _i]),
     "gpmpc_predict": (_i, [_i, _i, _vp, _dp, _d, _vp, _vp, _d, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
 }

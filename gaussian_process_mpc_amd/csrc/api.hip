@@ -135,3 +135,60 @@ extern "C" int gpmpc_predict(int n, int D, const double* X, const double* lambda
     GPMPC_HIP(hipGetLastError());
     return GPMPC_OK;
 }
+
+// ---------------------------------------------------------------------------
+// O(N^2) append of ONE observation to an explicit inverse (block-inverse / Schur-complement update; the idea of the
+// reference's update_Ky_inv_mat, src/gpr.py:137-157, which it abandons in favour of the O(N^3) rebuild):
+//   Ky' = [[Ky, k],[k^T, kappa]],   v = Ky_inv k,  w = Ky_inv^T k,  q = 1 / (kappa - k^T v)
+//   Ky'_inv = [[Ky_inv + q v w^T, -q v], [-q w^T, q]]
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_append_vw(const double* __restrict__ Kinv, const double* __restrict__ k, int n,
+                                                    double* __restrict__ v, double* __restrict__ wv) {
+    // row r: v[r] = Kinv[r] . k ; wv[r] = Kinv[:, r] . k  (second read is strided; n^2 doubles once per append)
+    __shared__ double s_scr[32], s_out[2];
+    const int r = blockIdx.x;
+    double acc[2] = {0.0, 0.0};
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        acc[0] = fma(Kinv[(size_t)r * n + i], k[i], acc[0]);
+        acc[1] = fma(Kinv[(size_t)i * n + r], k[i], acc[1]);
+    }
+    block_sum<2>(acc, s_scr, s_out);
+    if (threadIdx.x == 0) { v[r] = s_out[0]; wv[r] = s_out[1]; }
+}
+
+__global__ __launch_bounds__(256) void k_append_q(const double* __restrict__ k, const double* __restrict__ v, int n, double kappa,
+                                                   double* __restrict__ q) {
+    __shared__ double s_scr[16], s_out[1];
+    double acc[1] = {0.0};
+    for (int i = threadIdx.x; i < n; i += blockDim.x) acc[0] = fma(k[i], v[i], acc[0]);
+    block_sum<1>(acc, s_scr, s_out);
+    if (threadIdx.x == 0) q[0] = 1.0 / (kappa - s_out[0]);
+}
+
+__global__ void k_append_fill(const double* __restrict__ Kinv, const double* __restrict__ v, const double* __restrict__ wv,
+                              const double* __restrict__ q, int n, double* __restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y, m = n + 1;
+    if (j >= m) return;
+    const double qq = q[0];
+    double val;
+    if (i < n && j < n) val = fma(qq * v[i], wv[j], Kinv[(size_t)i * n + j]);
+    else if (i < n) val = -qq * v[i];
+    else if (j < n) val = -qq * wv[j];
+    else val = qq;
+    out[(size_t)i * m + j] = val;
+}
+
+extern "C" size_t gpmpc_kinv_append_workspace_bytes(int n) { return n < 1 ? 0 : sizeof(double) * (2 * (size_t)n + 8); }
+
+extern "C" int gpmpc_kinv_append(int n, const double* Kinv_dev, const double* k_dev, double kappa, double* out_dev,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    if (n < 1 || !Kinv_dev || !k_dev || !out_dev || !workspace) return GPMPC_E_ARG;
+    if (workspace_bytes < gpmpc_kinv_append_workspace_bytes(n)) return GPMPC_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    double* v = (double*)workspace; double* wv = v + n; double* q = wv + n;
+    hipLaunchKernelGGL(k_append_vw, dim3(n), dim3(256), 0, s, Kinv_dev, k_dev, n, v, wv);
+    hipLaunchKernelGGL(k_append_q, dim3(1), dim3(256), 0, s, k_dev, v, n, kappa, q);
+    hipLaunchKernelGGL(k_append_fill, dim3((n + 1 + 255) / 256, n + 1), dim3(256), 0, s, Kinv_dev, v, wv, q, n, out_dev);
+    GPMPC_HIP(hipGetLastError());
+    return GPMPC_OK;
+}

@@ -25,13 +25,14 @@ class Dynamics(object):
         self._pack = None
         self._pack_key = None
 
-    def append_train_data(self, state, action, next_state):
-        """(state, action, next_state) observations, one or many (src/dynamics.py:39-60)."""
+    def append_train_data(self, state, action, next_state, incremental=False):
+        """(state, action, next_state) observations, one or many (src/dynamics.py:39-60).  incremental=True: O(N^2)
+        update of every Ky_inv for a single new observation (see GaussianProcessRegression.append_train_data)."""
         state, action, next_state = np.asarray(state), np.asarray(action), np.asarray(next_state)
         if len(state.shape) == 1:
             x = np.concatenate((state, action))
             for i in range(self.state_dim):
-                self.gpr_err[i].append_train_data(x, next_state[i])
+                self.gpr_err[i].append_train_data(x, next_state[i], incremental=incremental)
         else:
             if len(action.shape) == 1:
                 action = action[:, None]

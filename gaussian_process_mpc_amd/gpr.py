@@ -60,8 +60,10 @@ class GaussianProcessRegression(object):
         return torch.exp(self.log_sigma_n.detach().cpu()).item()
 
     # -- data
-    def append_train_data(self, x, y):
-        """x: (x_dim,) or (n, x_dim) numpy; y: scalar or (n,) numpy (src/gpr.py:90-122)."""
+    def append_train_data(self, x, y, incremental=False):
+        """x: (x_dim,) or (n, x_dim) numpy; y: scalar or (n,) numpy (src/gpr.py:90-122).
+        incremental=True (extension, single observation, data already present): O(N^2) Schur-complement update of
+        Ky_inv (C ABI ``gpmpc_kinv_append``) instead of the reference's O(N^3) rebuild."""
         if not np.isscalar(y):
             num_obs = len(y)
             y = np.asarray(y)[:, None]
@@ -77,8 +79,39 @@ class GaussianProcessRegression(object):
         else:
             self.X_train = torch.cat((self.X_train, x), dim=0)
             self.y_train = torch.cat((self.y_train, y), dim=0)
+        if incremental and num_obs == 1 and self.num_train > 0 and self.Ky_inv is not None:
+            self._append_one_incremental(x)
+            self.num_train += 1
+            return
         self.num_train += num_obs
         self.build_Ky_inv_mat()
+
+    def _append_one_incremental(self, x_new):
+        """self.X_train / y_train already hold the new row (last); Kf, Ky, Ky_inv still have the old size n."""
+        n = self.num_train
+        X_old = self.X_train[:n].contiguous()
+        sigma_f = self.get_sigma_f()
+        noise = float((torch.exp(self.log_sigma_n.detach().cpu()) ** 2 * torch.ones(1)).item())
+        _, lp = host_doubles(self.get_lambdas())
+        k = torch.empty((1, n), dtype=torch.float64, device=self.device)
+        xn = x_new.reshape(1, self.x_dim).contiguous()
+        nb = lib().gpmpc_predict_workspace_bytes(n, self.x_dim, 1)
+        ws = torch.empty(nb, dtype=torch.uint8, device=self.device)
+        kinv_old = self.Ky_inv.contiguous()
+        out = torch.empty((n + 1, n + 1), dtype=torch.float64, device=self.device)
+        nb2 = lib().gpmpc_kinv_append_workspace_bytes(n)
+        ws2 = torch.empty(nb2, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().gpmpc_predict(n, self.x_dim, ptr(X_old), lp, sigma_f, None, None, 0.0, 1, ptr(xn), ptr(k), None, None,
+                                      ctypes.c_void_p(ws.data_ptr()), nb, stream_ptr()), "gpmpc_predict")
+            check(lib().gpmpc_kinv_append(n, ptr(kinv_old), ptr(k), sigma_f ** 2 + noise, ptr(out),
+                                          ctypes.c_void_p(ws2.data_ptr()), nb2, stream_ptr()), "gpmpc_kinv_append")
+        kff = torch.full((1, 1), sigma_f ** 2, dtype=torch.float64, device=self.device)
+        self.Kf = torch.cat((torch.cat((self.Kf, k.t()), dim=1), torch.cat((k, kff), dim=1)), dim=0)
+        self.Ky = torch.cat((torch.cat((self.Ky, k.t()), dim=1), torch.cat((k, kff + noise), dim=1)), dim=0)
+        self.Ky_inv = out
+        self._beta = None
+        self.version += 1
 
     def build_Ky_inv_mat(self):
         """Kf, Ky, Ky_inv from scratch (src/gpr.py:159-171)."""

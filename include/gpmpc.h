@@ -210,6 +210,14 @@ int gpmpc_predict(int n, int D, const double* X_dev, const double* lambdas_host,
                   int p, const double* X_pred_dev, double* out_K, double* out_mean, double* out_cov,
                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* O(N^2) append of ONE observation to an explicit inverse (Schur complement; the reference's abandoned
+ * update_Ky_inv_mat, src/gpr.py:137-157) instead of the O(N^3) rebuild of src/gpr.py:171 after every
+ * Simulator step (src/simulator.py:55).  Ky_inv dev [n][n]; k dev [n] = K_f(X, x_new); kappa = sigma_f^2 + noise_var;
+ * out dev [(n+1)][(n+1)] (must not alias Ky_inv).  Opt-in: results differ from a rebuild by rounding (~cond * eps). */
+size_t gpmpc_kinv_append_workspace_bytes(int n);
+int gpmpc_kinv_append(int n, const double* Ky_inv_dev, const double* k_dev, double kappa, double* out_dev,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

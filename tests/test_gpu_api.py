@@ -218,3 +218,23 @@ def test_closed_loop_simulator(G):
     assert len(hist) == 3 and hist[0][1].shape == (1,)
     assert mpc.dynamics.gpr_err[0].num_train == 43 and mpc.dynamics.pack().N == 43
     assert all(np.isfinite(h[2]) for h in hist) and all(abs(h[1][0]) <= 2.0 + 1e-9 for h in hist)
+
+
+def test_incremental_append_matches_rebuild(G, golden):
+    """gpmpc_kinv_append (Schur-complement append, O(N^2)) against the reference-style full rebuild (src/gpr.py:171)."""
+    z = golden("g6_gp.npz")
+    full = G.GaussianProcessRegression(3)
+    inc = G.GaussianProcessRegression(3)
+    for gp in (full, inc):
+        gp.set_lambdas(z["lam"]); gp.set_sigma_f(1.4); gp.set_sigma_n(0.2)
+        gp.append_train_data(z["X"][:50], z["y"][:50])
+    for i in range(50, 64):
+        full.append_train_data(z["X"][i], float(z["y"][i]))
+        inc.append_train_data(z["X"][i], float(z["y"][i]), incremental=True)
+    assert inc.num_train == 64 and inc.Ky_inv.shape == (64, 64)
+    np.testing.assert_allclose(inc.Ky.cpu().numpy(), z["Ky"], rtol=1e-12, atol=1e-14)
+    scale = np.abs(z["Ky_inv"]).max()
+    np.testing.assert_allclose(inc.Ky_inv.cpu().numpy(), full.Ky_inv.cpu().numpy(), rtol=0, atol=1e-10 * scale)
+    np.testing.assert_allclose(inc.Ky_inv.cpu().numpy(), z["Ky_inv"], rtol=0, atol=1e-9 * scale)
+    f_inc, _ = inc.predict_latent_vars(z["Xp"])
+    np.testing.assert_allclose(f_inc, z["f"], rtol=1e-8)
