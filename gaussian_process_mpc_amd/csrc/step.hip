@@ -120,7 +120,7 @@ __device__ static void finish_step(const RollArgs& A, int b, int t, int own, dou
 // sums, the pair-kernel parameters.
 template <int D>
 __device__ static void prep_step(const RollArgs& A, int b, int t, int a, const double* s_mu, const double* s_var,
-                                 double* s_u, double* s_s, double* s_scr, double* s_out) {
+                                 double* s_u, double* s_s, double* s_scr, double* s_out, double* s_g) {
     const int ds = A.ds;
     if (threadIdx.x < D) {
         const int k = threadIdx.x;
@@ -144,26 +144,36 @@ __device__ static void prep_step(const RollArgs& A, int b, int t, int a, const d
     double v[1 + 2 * D];
 #pragma unroll
     for (int m = 0; m < 1 + 2 * D; ++m) v[m] = 0.0;
-    for (int i = threadIdx.x; i < A.Np; i += blockDim.x) {
-        double d[D], xk[D], q = 0.0;
+    for (int i0 = 0; i0 < A.Np; i0 += blockDim.x) {          // uniform trip count: the G rows go through LDS
+        const int i = i0 + threadIdx.x;
+        if (i < A.Np) {
+            double d[D], xk[D], q = 0.0;
 #pragma unroll
-        for (int k = 0; k < D; ++k) { xk[k] = A.XT[(size_t)k * A.Np + i]; d[k] = u[k] - xk[k]; q = fma(Bk[k] * d[k], d[k], q); }
-        const double p = A.beta[(size_t)a * A.Np + i] * exp(-0.5 * q);
-        v[0] += p;
+            for (int k = 0; k < D; ++k) { xk[k] = A.XT[(size_t)k * A.Np + i]; d[k] = u[k] - xk[k]; q = fma(Bk[k] * d[k], d[k], q); }
+            const double p = A.beta[(size_t)a * A.Np + i] * exp(-0.5 * q);
+            v[0] += p;
 #pragma unroll
-        for (int k = 0; k < D; ++k) { v[1 + k] = fma(p, d[k], v[1 + k]); v[1 + D + k] = fma(p * d[k], d[k], v[1 + D + k]); }
-        if (Grow) {        // column row of point i: [h (D) | |h|^2 | h_k^2 (k < ds) | pad], h = sc o u - sc o x as in the pair kernel
-            double* g = Grow + (size_t)i * A.gw;
-            double qh = 0.0;
+            for (int k = 0; k < D; ++k) { v[1 + k] = fma(p, d[k], v[1 + k]); v[1 + D + k] = fma(p * d[k], d[k], v[1 + D + k]); }
+            if (Grow) {    // column row of point i: [h (D) | |h|^2 | h_k^2 (k < ds) | pad], h = sc o u - sc o x as in the pair kernel
+                double* g = s_g + threadIdx.x * A.gw;
+                double qh = 0.0;
 #pragma unroll
-            for (int k = 0; k < D; ++k) {
-                const double h = fma(-sck[k], xk[k], sck[k] * u[k]);
-                g[k] = h;
-                qh = fma(h, h, qh);
-                if (k < ds) g[D + 1 + k] = h * h;
+                for (int k = 0; k < D; ++k) {
+                    const double h = fma(-sck[k], xk[k], sck[k] * u[k]);
+                    g[k] = h;
+                    qh = fma(h, h, qh);
+                    if (k < ds) g[D + 1 + k] = h * h;
+                }
+                g[D] = qh;
+                for (int k = D + 1 + ds; k < A.gw; ++k) g[k] = 0.0;
             }
-            g[D] = qh;
-            for (int k = D + 1 + ds; k < A.gw; ++k) g[k] = 0.0;
+        }
+        if (Grow) {        // rows of blockDim.x consecutive points are contiguous in G: write them out lane-contiguously
+            __syncthreads();
+            const int rows = (A.Np - i0 < (int)blockDim.x) ? A.Np - i0 : (int)blockDim.x;
+            double* dst = Grow + (size_t)i0 * A.gw;
+            for (int e = threadIdx.x; e < rows * A.gw; e += blockDim.x) dst[e] = s_g[e];
+            __syncthreads();
         }
     }
     block_sum<1 + 2 * D>(v, s_scr, s_out);
@@ -202,6 +212,7 @@ __global__ __launch_bounds__(256) void k_roll_head(RollArgs A, int t) {
     __shared__ double s_mu[GPMPC_MAX_DS], s_var[GPMPC_MAX_DS];
     __shared__ double s_u[GPMPC_MAX_D], s_s[GPMPC_MAX_D];
     __shared__ double s_scr[16 * (1 + 2 * D)], s_out[1 + 2 * D];
+    __shared__ double s_g[256 * (2 * D + 2)];             // staging of 256 G rows (gw <= 2D + 2)
     const int b = blockIdx.x, a = blockIdx.y;
     if (t == 1) {
         if (threadIdx.x < A.ds) {
@@ -217,7 +228,7 @@ __global__ __launch_bounds__(256) void k_roll_head(RollArgs A, int t) {
     } else {
         finish_step(A, b, t - 1, a, s_z, s_zred, s_mu, s_var);
     }
-    prep_step<D>(A, b, t, a, s_mu, s_var, s_u, s_s, s_scr, s_out);
+    prep_step<D>(A, b, t, a, s_mu, s_var, s_u, s_s, s_scr, s_out, s_g);
 }
 
 // ---------------------------------------------------------------------------
