@@ -271,11 +271,12 @@ def test_rollout_fullcov_vs_oracle(G, N, ds, da, H, B, gamma):
 
 
 @pytest.mark.parametrize("N,ds,da,H,B", [(1, 2, 1, 2, 1), (2, 1, 1, 3, 2), (63, 2, 1, 2, 2), (64, 3, 1, 1, 3),
-                                         (65, 7, 1, 2, 2), (70, 6, 2, 2, 3), (257, 2, 2, 2, 600)])
+                                         (65, 7, 1, 2, 2), (70, 6, 2, 2, 3), (257, 2, 2, 2, 600),
+                                         (70, 6, 2, 2, 400), (65, 7, 1, 2, 320)])
 def test_rollout_edge_shapes(G, N, ds, da, H, B):
     """Edge cases: a single training point (the reference special-cases 0-D y, uncertainty_prop.py:324), N around the
-    64-row padding boundary, the largest supported input dimension D = 8, H = 1, and a batch large enough to take the
-    256-row tiles / scalar-broadcast kernel at small N (ragged last tile)."""
+    64-row padding boundary, the largest supported input dimension D = 8, H = 1, and batches large enough to take the
+    256-row tiles / scalar-broadcast kernel at small N (ragged last tile; D = 8 with one and two action dimensions)."""
     from oracle import gpmpc_oracle as O
     from gaussian_process_mpc_amd.synth import synth_problem
     pb = synth_problem(21, N, ds, da, H, B, sigma_n=0.05)
