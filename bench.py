@@ -70,6 +70,14 @@ def cpu_baseline(pb, H_sample, reps=2, fullcov=False):
             if r > 0:
                 best = min(best, dt)
         res[mode] = 1.0 / (best * H / H_sample)
+    if not fullcov:
+        # plain-C / OpenMP port of the O(N^2) algorithm (oracle/cport): whole horizon, 2 trajectories
+        from oracle import cport
+        nthr = torch.get_num_threads()
+        cport.rollout(pb, gp.Ky_inv.numpy(), -1.0, x0=pb["x0"][:1], U=pb["U"][:1, :2], nthreads=nthr)     # warm-up / build
+        t0 = time.perf_counter()
+        cport.rollout(pb, gp.Ky_inv.numpy(), -1.0, x0=pb["x0"][:2], U=pb["U"][:2], nthreads=nthr)
+        res["cport"] = 2.0 / (time.perf_counter() - t0)
     return res, gp
 
 
@@ -229,7 +237,11 @@ def main():
                           f"(N^3 trace GEMM + autograd) scaled x{H / H_s:g}; best of 1 after 1 warm-up",
                 "o2_value": res["o2"],
                 "o2_note": "same oracle with the trace evaluated as an O(N^2) elementwise sum (algorithmic baseline)",
+                "c_port_value": res.get("cport"),
+                "c_port_note": "plain-C / OpenMP port of the O(N^2) algorithm with the analytic adjoint (oracle/cport), "
+                               "2 trajectories over the whole horizon, same thread count; includes its own pack build",
                 "gpu_over_cpu": value / res["faithful"], "gpu_over_cpu_o2": value / res["o2"],
+                "gpu_over_c_port": (value / res["cport"]) if res.get("cport") else None,
             }
         print(json.dumps(out))
     if world > 1:

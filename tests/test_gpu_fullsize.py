@@ -123,3 +123,17 @@ def test_c4_first_step_against_oracle(G):
         np.testing.assert_allclose(r["grad"][b].cpu().numpy(), o["grad"], rtol=1e-4, atol=1e-7)
     del pack
     torch.cuda.empty_cache()
+
+
+def test_c3_full_horizon_against_cport(G, c3):
+    """The WHOLE C3 rollout (N=2048, H=20) with cost and gradient for two trajectories against the plain-C / OpenMP CPU
+    port (direct exponent, libm exp, analytic adjoint; pinned to the torch oracle and to the reference's fixtures by
+    tests/test_oracle_golden.py) -- the full-size, full-horizon parity the torch oracle cannot afford (46 GiB)."""
+    from oracle import cport
+    pb, gp, pack = c3
+    r = G.rollout(pack, pb["x0"][:2], pb["U"][:2], G.CostParams(-1.0, pb["Q"], pb["R"]))
+    c = cport.rollout(pb, gp.Ky_inv.numpy(), -1.0, x0=pb["x0"][:2], U=pb["U"][:2], nthreads=16)
+    np.testing.assert_allclose(r["means"].cpu().numpy(), c["means"], rtol=1e-5, atol=1e-9)       # north star
+    np.testing.assert_allclose(r["vars"].cpu().numpy(), c["vars"], rtol=1e-4)                    # north star
+    np.testing.assert_allclose(r["cost"].cpu().numpy(), c["cost"], rtol=1e-6)
+    np.testing.assert_allclose(r["grad"].cpu().numpy(), c["grad"], rtol=1e-4, atol=1e-7)

@@ -92,10 +92,9 @@ def test_product_never_touches_the_oracle():
                     all("import" not in ln for ln in txt.splitlines() if "oracle" in ln.lower()), f
     bench = open(os.path.join(ROOT, "bench.py")).read()
     hits = [m.start() for m in pat.finditer(bench)]
-    assert len(hits) == 1
     start = bench.index("def cpu_baseline")
     end = bench.index("def main")
-    assert start < hits[0] < end
+    assert 1 <= len(hits) <= 2 and all(start < h < end for h in hits)      # torch oracle + its C port, both inside cpu_baseline
 
 
 def test_cost_params_marshalling(built):
