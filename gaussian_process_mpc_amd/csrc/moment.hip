@@ -9,6 +9,7 @@
 //   dT/du  = -4 c Cm^T Z1,         dT/dS  = -1/2 T A + 8 c Cm^T Z2 Cm        (since A Cm^-1 = 8 Cm^T)
 // with S1 = sum p_i v_i, S2 = sum p_i v_i v_i^T and Z* the pair-kernel moments in h-space.
 #include "gpmpc_internal.h"
+#include "fast_exp.h"
 #include <cstdlib>
 
 int gpmpc_timed_pair(int D, bool diag, bool grad, int tb, int waves, const PairArgs& a, hipStream_t s);
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(256) void k_mom_prep(MomArgs A) {
                 qv[k] = sacc; g[k] = sacc;
                 qq = fma(sacc, sacc, qq);
             }
-            g[D] = qq;
+            g[D] = GPMPC_EXP_NEG_INV_C * qq;                  // pre-scaled for gpmpc_exp_neg_scaled (fast_exp.h)
             int o = D + 1;
 #pragma unroll
             for (int k = 0; k < D; ++k)

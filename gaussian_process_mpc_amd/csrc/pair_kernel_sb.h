@@ -8,7 +8,7 @@
 //     Z0   = sum_i r_i                          r_i  = sum_j P_ij
 //     Z1_k = sum_i ( h_ik r_i + v_ik )          v_ik = sum_j P_ij h_jk
 //     Z2_k = sum_i ( h_ik^2 r_i + 2 h_ik v_ik + w_ik )      w_ik = sum_j P_ij h_jk^2
-// The column rows G[j] = [h_j1..h_jD | q_j | h_j1^2..h_jNS2^2] are written once per (trajectory, GP, step) by the head
+// The column rows G[j] = [h_j1..h_jD | q_j N/ln2 | h_j1^2..h_jNS2^2] are written once per (trajectory, GP, step) by the head
 // kernel (step.hip) and read here through wave-uniform addresses, i.e. as SCALAR loads into SGPRs that the fp64 VALU
 // instructions take as their one scalar operand: no LDS staging, no barrier in the loop, no per-lane h_j registers.
 // Per pair the VALU issues 1 + D (exponent) + 10 (table exp) + 1 (M_ij e) + 1 + D + NS2 (r, v, w) fp64 instructions:
@@ -67,10 +67,10 @@ __global__ __launch_bounds__(256) void gpmpc_pair_kernel_sb(PairSbArgs A) {
             for (int k = 0; k < D; ++k) {
                 const double x = (iw0 + 64 * r < Np) ? A.XT[(size_t)k * Np + i] : 0.0;
                 const double h = fma(-prm[D + k], x, prm[k]);
-                hi2[tb][r][k] = 2.0 * h;
+                hi2[tb][r][k] = (2.0 * GPMPC_EXP_NEG_INV_C) * h;     // exponent carried as s * N/ln2 (fast_exp.h)
                 q = fma(h, h, q);
             }
-            qi[tb][r] = q;
+            qi[tb][r] = GPMPC_EXP_NEG_INV_C * q;
         }
     }
 
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void gpmpc_pair_kernel_sb(PairSbArgs A) {
                         double s = qi[tb][r] + g[D];
 #pragma unroll
                         for (int k = 0; k < D; ++k) s = fma(hi2[tb][r][k], g[k], s);
-                        const double P = mij[r][q] * gpmpc_exp_neg(s, s_tab);
+                        const double P = mij[r][q] * gpmpc_exp_neg_scaled(s, s_tab);
                         acc[tb][r][0] += P;
                         if (GRAD) {
 #pragma unroll
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void gpmpc_pair_kernel_sb(PairSbArgs A) {
             if (GRAD) {
 #pragma unroll
                 for (int k = 0; k < D; ++k) {
-                    const double h = 0.5 * hi2[tb][r][k], v = acc[tb][r][GRAD ? 1 + k : 0];
+                    const double h = (0.5 / GPMPC_EXP_NEG_INV_C) * hi2[tb][r][k], v = acc[tb][r][GRAD ? 1 + k : 0];
                     z[GRAD ? 1 + k : 0] += fma(h, rs, v);
                     if (k < NS2) z[GRAD ? 1 + D + k : 0] += fma(h * h, rs, fma(2.0 * h, v, acc[tb][r][GRAD ? 1 + D + (k < NS2 ? k : 0) : 0]));
                 }

@@ -4,7 +4,7 @@
 //     P_ij = M_ij exp(-|p_i + q_j|^2),      |p_i + q_j|^2 = |p_i|^2 + |q_j|^2 + sum_k (2 p_ik) q_jk
 //     r_i = sum_j P_ij,   v_ik = sum_j P_ij q_jk,   W_i,kl = sum_j P_ij q_jk q_jl      (k <= l < NS2)
 //     Z0 = sum_i r_i,  Z1_k = sum_i (p_ik r_i + v_ik),  Z2_kl = sum_i (p_ik p_il r_i + p_ik v_il + p_il v_ik + W_i,kl)
-// The column rows G[unit][j] = [q_j (D) | |q_j|^2 | q_jk q_jl (k <= l < NS2)] are written by k_mom_prep (moment.hip)
+// The column rows G[unit][j] = [q_j (D) | |q_j|^2 N/ln2 | q_jk q_jl (k <= l < NS2)] are written by k_mom_prep (moment.hip)
 // and fetched with scalar loads; reference: src/tools/uncertainty_prop.py:372-399 (variance), :402-465 (covariance).
 // NS2 < D (the rollout: NS2 = state_dim) leaves Z2_kl for k or l >= NS2 at zero: the transforms are upper
 // triangular, so dT/dS_rc for r, c < NS2 only needs Z2_kl with k <= r, l <= c.
@@ -50,9 +50,10 @@ __global__ __launch_bounds__(256) void gpmpc_pair_kernel_sbf(PairSbfArgs A) {
             double s = prm[k];
 #pragma unroll
             for (int l = k; l < D; ++l) s = fma(-prm[D + k * D + l], x[l], s);
-            p[k] = s; p2[k] = 2.0 * s;
+            p[k] = s; p2[k] = (2.0 * GPMPC_EXP_NEG_INV_C) * s;     // exponent carried as s * N/ln2 (fast_exp.h)
             qi = fma(s, s, qi);
         }
+        qi *= GPMPC_EXP_NEG_INV_C;
     }
     double acc[NA];
 #pragma unroll
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void gpmpc_pair_kernel_sbf(PairSbfArgs A) {
                 double s = qi + g[D];
 #pragma unroll
                 for (int k = 0; k < D; ++k) s = fma(p2[k], g[k], s);
-                const double P = mij[q] * gpmpc_exp_neg(s, s_tab);
+                const double P = mij[q] * gpmpc_exp_neg_scaled(s, s_tab);
                 acc[0] += P;
                 if (GRAD) {
 #pragma unroll

@@ -17,6 +17,7 @@
 //   T = c Z0,  dT/du_k = -4 sqrt(A_k/8) c Z1_k,  dT/ds_k = A_k (c Z2_kk - T/2)
 //   var = sf^2 - T - mu^2     (no clamp; src/tools/uncertainty_prop.py:399)
 #include "gpmpc_internal.h"
+#include "fast_exp.h"
 #include <cstdlib>
 
 struct RollArgs {
@@ -164,7 +165,7 @@ __device__ static void prep_step(const RollArgs& A, int b, int t, int a, const d
                     qh = fma(h, h, qh);
                     if (k < ds) g[D + 1 + k] = h * h;
                 }
-                g[D] = qh;
+                g[D] = GPMPC_EXP_NEG_INV_C * qh;               // pre-scaled for gpmpc_exp_neg_scaled (fast_exp.h)
                 for (int k = D + 1 + ds; k < A.gw; ++k) g[k] = 0.0;
             }
         }
