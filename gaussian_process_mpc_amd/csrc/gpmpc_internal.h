@@ -78,6 +78,7 @@ struct PairSbArgs {
     double* part;         // [B][nwork][nm]
     const int* work;      // [nwork][4] = {unit, i0, j0, j1}
     int Np, B, ds, nwork, pps, nm;
+    int rgroup;           // work items interleaved per trajectory in dispatch order (1 = item-major), see pair_kernel_sb.h
 };
 static inline int gpmpc_sb_gw(int D, int ns2) { return (D + 1 + ns2 + 1) & ~1; }
 int gpmpc_launch_pair_sb(int D, bool grad, int tb, int ns2, int waves, const PairSbArgs& a, hipStream_t s);

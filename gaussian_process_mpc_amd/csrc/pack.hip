@@ -145,6 +145,14 @@ static int build_worklist(int Np, int it, int jt, int ds, int npairs, bool xcd_s
             const int x = ((u & 1) ? (tj - 1 - tjx) : tjx) & 7;
             memcpy(q[x] + 4 * cnt[x]++, h + 4 * k, sizeof(int) * 4);
         }
+        // within an XCD: column block major, then row tile (consecutive items share their G rows, see pair_kernel_sb.h)
+        for (int x = 0; x < 8; ++x)
+            qsort(q[x], cnt[x], sizeof(int) * 4, [](const void* a, const void* b) {
+                const int* u = (const int*)a; const int* v = (const int*)b;
+                if (u[0] != v[0]) return u[0] - v[0];
+                if (u[2] != v[2]) return u[2] - v[2];
+                return u[1] - v[1];
+            });
         for (int p = 0; p < n; ++p) {
             int x = p & 7;
             if (pos[x] >= cnt[x]) {                             // this XCD's queue ran dry: take from the fullest one
@@ -190,6 +198,8 @@ extern "C" int gpmpc_pack_create(gpmpc_pack** out, int n_train, int state_dim, i
         if (e == hipSuccess) e = hipMemcpy(p->pair_ab_dev, hab, sizeof(int) * 2 * p->npairs, hipMemcpyHostToDevice);
     }
     bool ok = e == hipSuccess;
+    // 256-row workgroups: 512 / 1024 rows would cut the G-row re-reads 2x / 4x but ran 8 % / 46 % slower (C3)
+    // 256-row workgroups: 512 / 1024 rows would cut the G-row re-reads 2x / 4x but ran 8 % / 46 % slower on C3 (C4: -1 %)
     const int cfg[2][2] = {{256, 256}, {64, 64}};
     for (int mode = 0; mode < 2 && ok; ++mode)
         for (int k = 0; k < 2 && ok; ++k)

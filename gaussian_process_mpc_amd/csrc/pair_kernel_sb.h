@@ -11,8 +11,8 @@
 // The column rows G[j] = [h_j1..h_jD | q_j N/ln2 | h_j1^2..h_jNS2^2] are written once per (trajectory, GP, step) by the head
 // kernel (step.hip) and read here through wave-uniform addresses, i.e. as SCALAR loads into SGPRs that the fp64 VALU
 // instructions take as their one scalar operand: no LDS staging, no barrier in the loop, no per-lane h_j registers.
-// Per pair the VALU issues 1 + D (exponent) + 10 (table exp) + 1 (M_ij e) + 1 + D + NS2 (r, v, w) fp64 instructions:
-// 27 for D = 5, NS2 = 4 against 35 for the staged form, whose adds/squares of m are gone.  The exponent is the
+// Per pair the VALU issues 1 + D (exponent) + 9 (table exp) + 1 (M_ij e) + 1 + D + NS2 (r, v, w) fp64 instructions:
+// 26 for D = 5, NS2 = 4 against 35 for the staged form, whose adds/squares of m are gone.  The exponent is the
 // expanded form the reference itself uses (:380-389, u A u + X A X^T - ...), here centred on u (h = sc (u - x)), so
 // its absolute error is ~1e-16 (q_i + q_j) instead of ~1e-16 |m|^2; still fp64 throughout.
 // fp64 MFMA cannot help here: on MI355X it shares the fp64 VALU's issue capacity (profiles/r01/ubench_mfma_f64_overlap.txt).
@@ -35,12 +35,19 @@ __global__ __launch_bounds__(256) void gpmpc_pair_kernel_sb(PairSbArgs A) {
     __shared__ double s_tab[GPMPC_EXP_N];
     gpmpc_exp_table_to_lds(s_tab);
 
-    int bg, wi;                                           // XCD-aware decode, see pair_kernel.h
+    // XCD-aware decode (pair_kernel.h): position p of the work list runs on XCD p % 8.  Within an XCD the dispatch
+    // order is [group of R items][trajectory][item of the group]: the ~256 workgroups resident on an XCD are R row
+    // tiles x 256/R trajectories, and the R tiles of a group share their column block (build_worklist sorts the XCD
+    // lists that way), so each trajectory's G rows are fetched into the XCD's L2 once per R row tiles.
+    int bg, wi;
     {
-        const int groups = (A.B + TB - 1) / TB, items = A.nwork;
-        const int L = blockIdx.x, full = (items >> 3) << 3;
-        if (L < full * groups) { const int q = L >> 3; wi = (q / groups) * 8 + (L & 7); bg = q % groups; }
-        else { const int Lt = L - full * groups; wi = full + Lt / groups; bg = Lt % groups; }
+        const int groups = (A.B + TB - 1) / TB, items = A.nwork, R = A.rgroup;
+        const int L = blockIdx.x, full = (items / (8 * R)) * (8 * R);
+        if (L < full * groups) {
+            const int q = L >> 3, ir = q % R, t = q / R;
+            bg = t % groups;
+            wi = ((t / groups) * R + ir) * 8 + (L & 7);
+        } else { const int Lt = L - full * groups; wi = full + Lt / groups; bg = Lt % groups; }
     }
     const int unit = A.work[wi * 4 + 0], i0 = A.work[wi * 4 + 1], j0 = A.work[wi * 4 + 2], j1 = A.work[wi * 4 + 3];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -88,12 +95,22 @@ __global__ __launch_bounds__(256) void gpmpc_pair_kernel_sb(PairSbArgs A) {
     if (iw0 < Np) {
         // columns left of every row of this wave carry zero weight (upper-triangular M): start at the wave's diagonal chunk
         const int jstart = j0 > (iw0 & ~63) ? j0 : (iw0 & ~63);
+        __amdgpu_buffer_rsrc_t Mrs[RI];
+#pragma unroll
+        for (int r = 0; r < RI; ++r)
+            Mrs[r] = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Ma + (size_t)jstart * Np + iw0 + 64 * r), 0, 0x7fffffff, 0x00020000);
+        const int lane8 = lane * 8;
         for (int jc = jstart; jc < j1; jc += 4) {
             double mij[RI][4];
 #pragma unroll
             for (int r = 0; r < RI; ++r)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) mij[r][q] = (iw0 + 64 * r < Np) ? Ma[(size_t)(jc + q) * Np + iw0 + 64 * r + lane] : 0.0;
+                for (int q = 0; q < 4; ++q) {
+                    // buffer load: the column offset rides in the scalar offset, the lane offset is loop invariant,
+                    // so the M_ij stream costs no VALU address arithmetic
+                    const auto raw = __builtin_amdgcn_raw_buffer_load_b64(Mrs[r], lane8, (jc - jstart + q) * Np * 8, 0);
+                    mij[r][q] = __builtin_bit_cast(double, raw);
+                }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -158,7 +175,7 @@ __global__ __launch_bounds__(256) void gpmpc_pair_kernel_sb(PairSbArgs A) {
 
 // `rows` = rows per tile of the work list (64 or 256) = threads per workgroup.
 // TB = 1 (59 VGPRs, 8 waves/SIMD at D = 5) is the fastest shape on MI355X: occupancy hides the scalar-load and
-// table-read latencies (C3: 2.30 ms per launch; TB 2: 2.41; two rows per lane: 2.65; staged pair_kernel.h TB 2: 2.82).
+// table-read latencies (C3: 2.20 ms per launch; TB 2: 2.41 with the 10-slot exp; two rows per lane: 2.65; staged pair_kernel.h TB 2: 2.82).
 template <int D, int TB, int NS2, bool GRAD>
 static int launch_pair_sb_one(int rows, const PairSbArgs& a, hipStream_t s) {
     dim3 grid(((a.B + TB - 1) / TB) * a.nwork), block(rows);

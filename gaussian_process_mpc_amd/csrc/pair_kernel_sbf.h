@@ -65,10 +65,14 @@ __global__ __launch_bounds__(256) void gpmpc_pair_kernel_sbf(PairSbfArgs A) {
     if (active) {
         const int jdiag = iw0 & ~63;
         const int jstart = (tri && jdiag > j0) ? jdiag : j0;   // symmetric units: zero weight left of the diagonal chunk
+        const __amdgpu_buffer_rsrc_t Mrs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Ma + (size_t)jstart * Np + iw0), 0, 0x7fffffff, 0x00020000);
+        const int lane8 = lane * 8;
         for (int jc = jstart; jc < j1; jc += 4) {
             double mij[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) mij[q] = Ma[(size_t)(jc + q) * Np + i];
+            for (int q = 0; q < 4; ++q)      // buffer load with the column offset as scalar offset (see pair_kernel_sb.h)
+                mij[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, (jc - jstart + q) * Np * 8, 0));
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const double* __restrict__ g = G + (size_t)(jc + q) * GW;              // wave-uniform address -> SGPRs

@@ -486,7 +486,7 @@ int gpmpc_timed_pair_sbf(int D, bool grad, int ns2, int waves, const PairSbfArgs
     return rc;
 }
 
-struct RollPlan { int tiling, tb, waves, nwork, nm, pps, sps, sb, gw; size_t off_G; size_t off_pp, off_sp, off_part, off_jac, off_means, off_vars, total; };
+struct RollPlan { int tiling, tb, waves, nwork, nm, pps, sps, sb, gw, rgroup; size_t off_G; size_t off_pp, off_sp, off_part, off_jac, off_means, off_vars, total; };
 
 static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag, RollPlan* r) {
     const int D = p->D;
@@ -501,6 +501,11 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     if (!diag && grad && r->tb > 2) r->tb = 2;
     // big workgroups once they already oversubscribe the 256 CUs; one-wave tiles otherwise
     r->tiling = big ? 0 : 1;
+    // Dispatch interleave of the scalar-broadcast kernel (pair_kernel_sb.h): 4 row tiles per trajectory share each fetch
+    // of the G rows (C3 fabric reads per launch 757 -> 418 MB by FETCH_SIZE, same speed) as long as the weight matrices
+    // stay resident in the 256 MB infinity cache; past that the extra M re-reads cost more than they save (C4: -2.5 %).
+    r->rgroup = ((size_t)p->ds * p->Np * p->Np * sizeof(double) <= ((size_t)192 << 20)) ? 4 : 1;
+    if (const char* ev = getenv("GPMPC_RGROUP")) { const int v = atoi(ev); if (v >= 1 && v <= 16) r->rgroup = v; }
     r->waves = p->wl[0][r->tiling].waves;
     r->nwork = p->wl[0][r->tiling].nwork;
     r->nm = gpmpc_num_moments(D, diag, grad);
@@ -579,7 +584,7 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
         if (r.sb) {
             PairSbArgs Q;
             Q.M = p->M; Q.XT = p->XT; Q.pp = A.pp; Q.G = A.G; Q.part = A.part; Q.work = P.work;
-            Q.Np = p->Np; Q.B = B; Q.ds = p->ds; Q.nwork = r.nwork; Q.pps = r.pps; Q.nm = r.nm;
+            Q.Np = p->Np; Q.B = B; Q.ds = p->ds; Q.nwork = r.nwork; Q.pps = r.pps; Q.nm = r.nm; Q.rgroup = r.rgroup;
             rc = gpmpc_timed_pair_sb(p->D, grad, r.tb, p->ds, r.waves, Q, s);
         } else {
             rc = gpmpc_timed_pair(p->D, true, grad, r.tb, P.colsplit ? 4 : r.waves, P, s);

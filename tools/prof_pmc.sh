@@ -16,7 +16,7 @@ P5="SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INST_CYCLES
 i=0
 for P in "$P1" "$P2" "$P3" "$P4" "$P5"; do
   i=$((i+1))
-  rocprofv3 --pmc $P --output-format csv -d $OUT/p$i -- python3 $ROOTD/bench.py --steps 1 --warmup 1 --no-cpu-baseline "$@" > $OUT/p$i.log 2>&1 || echo "pass $i failed (see $OUT/p$i.log)"
+  timeout -k 10 240 rocprofv3 --pmc $P --output-format csv -d $OUT/p$i -- python3 $ROOTD/bench.py --steps 1 --warmup 1 --no-cpu-baseline "$@" > $OUT/p$i.log 2>&1 || echo "pass $i failed (see $OUT/p$i.log)"
 done
 python3 $ROOTD/tools/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
