@@ -97,6 +97,63 @@ def predict(X_pred, X, y, Ky_inv, lambdas, sigma_f, sigma_n, covar=False, target
 
 
 # --------------------------------------------------------------------------
+# Marginal likelihood and hyper-parameter training (src/gpr.py:240-251, 334-370)
+# --------------------------------------------------------------------------
+def marginal_likelihood(X, y, lambdas, sigma_f, sigma_n, nominal=None):
+    """compute_marginal_likelihood (src/gpr.py:240-251) on matrices built as build_Ky_inv_mat builds
+    them (:159-171): -1/2 r^T Ky_inv r - 1/2 log(det(Ky)) - N/2 log(2 pi), r = y - f_nom(X).
+    Returns a (1,1) tensor (graph attached when the hyper-parameters require grad)."""
+    X, y = _t(X), _t(y).reshape(-1, 1)
+    r = y if nominal is None else y - _t(nominal).reshape(-1, 1)
+    _, Ky, Ky_inv = kernel_matrices(X, lambdas, sigma_f, sigma_n)
+    return (-0.5 * r.mT @ Ky_inv @ r - 0.5 * torch.log(torch.linalg.det(Ky))
+            - X.shape[0] / 2 * np.log(2 * np.pi))
+
+
+class HyperTrainer:
+    """update_hyperparams (src/gpr.py:334-370) with the optimiser of the constructor (:46-49):
+    Adam(lr=0.1, betas=(0.9, 0.999), maximize=True) over [log_lambdas, log_sigma_n, log_sigma_f],
+    gradients by autograd through inv / det; one iteration = likelihood at the current matrices,
+    backward, Adam step, rebuild; stops when every |d ml / d log-hyper| < 1e-5 (:366-370).
+    ``step()`` returns what the reference prints per iteration: the likelihood BEFORE the step, the
+    gradients, and the log-hypers AFTER the step."""
+
+    def __init__(self, X, y, x_dim, nominal=None, log_lambdas=None, log_sigma_f=0.0, log_sigma_n=0.0):
+        self.X, self.y, self.nominal = _t(X), _t(y), nominal
+        ll = np.zeros(x_dim) if log_lambdas is None else np.asarray(log_lambdas, dtype=float)
+        self.log_lambdas = torch.tensor(ll, dtype=F64).requires_grad_()
+        self.log_sigma_n = torch.tensor(float(log_sigma_n), dtype=F64).requires_grad_()
+        self.log_sigma_f = torch.tensor(float(log_sigma_f), dtype=F64).requires_grad_()
+        self.optimizer = torch.optim.Adam(params=[self.log_lambdas, self.log_sigma_n, self.log_sigma_f],
+                                          lr=0.1, betas=(0.9, 0.999), maximize=True)
+
+    def likelihood(self):
+        return marginal_likelihood(self.X, self.y, torch.exp(self.log_lambdas), torch.exp(self.log_sigma_f),
+                                   torch.exp(self.log_sigma_n), self.nominal)
+
+    def step(self):
+        self.optimizer.zero_grad()
+        ml = self.likelihood()
+        ml.backward()
+        self.optimizer.step()
+        g = {"log_lambdas": self.log_lambdas.grad.detach().numpy().copy(),
+             "log_sigma_f": self.log_sigma_f.grad.item(), "log_sigma_n": self.log_sigma_n.grad.item()}
+        return {"ml": ml.item(), "grad": g,
+                "log_lambdas": self.log_lambdas.detach().numpy().copy(),
+                "log_sigma_f": self.log_sigma_f.item(), "log_sigma_n": self.log_sigma_n.item()}
+
+    def run(self, num_iters=1000):
+        hist = []
+        for _ in range(num_iters):
+            h = self.step()
+            hist.append(h)
+            g = h["grad"]
+            if (np.abs(g["log_lambdas"]) < 1e-5).all() and abs(g["log_sigma_f"]) < 1e-5 and abs(g["log_sigma_n"]) < 1e-5:
+                break
+        return hist
+
+
+# --------------------------------------------------------------------------
 # Exact moment matching (src/tools/uncertainty_prop.py:296-465)
 # --------------------------------------------------------------------------
 def mean_prop(Ky_inv, lambdas, u, S, X, y, sigma_f=1.0):

@@ -19,6 +19,7 @@ Fixtures:
   g5_cost.npz          literal cost cases of the reference's tests
   g6_gp.npz            Ky / Ky_inv / K* / predict
   g7_quirks.npz        dtype quirks of the rollout
+  g8_hyper.npz         marginal likelihood at set hyper-parameters; update_hyperparams trajectories (Adam)
 """
 import os
 import sys
@@ -271,8 +272,53 @@ def g7():
              action_var=np.array(act), float32_1e3=np.array(float(np.float32(1e-3))))
 
 
+def g8():
+    """compute_marginal_likelihood (src/gpr.py:240) and update_hyperparams (:334), one iteration per call so that
+    the per-iteration state can be recorded (the Adam state lives in the object, so k calls of one iteration are
+    k iterations)."""
+    import contextlib
+    import io
+    out = {}
+    # likelihood at set hyper-parameters (the g6 problem)
+    rng = np.random.default_rng(606)
+    N, D = 64, 3
+    X = rng.uniform(-2, 2, (N, D)); y = np.sin(X).sum(axis=1) + 0.1 * rng.normal(size=N)
+    g = GaussianProcessRegression(D)
+    g.set_lambdas(np.array([0.7, 1.9, 3.1])); g.set_sigma_f(1.4); g.set_sigma_n(0.2)
+    g.append_train_data(X, y)
+    out["ml_X"], out["ml_y"] = X, y
+    out["ml_lam"], out["ml_hyp"] = np.array([0.7, 1.9, 3.1]), np.array([1.4, 0.2])
+    out["ml_value"] = np.array(g.compute_marginal_likelihood().item())
+
+    def traj(tag, X, y, x_dim, nominal, iters):
+        gp = GaussianProcessRegression(x_dim, nominal_model=nominal)
+        gp.append_train_data(X, y)
+        ml, ll, lf, ln, gl, gf, gn = [], [], [], [], [], [], []
+        for _ in range(iters):
+            ml.append(gp.compute_marginal_likelihood().item())
+            with contextlib.redirect_stdout(io.StringIO()):
+                gp.update_hyperparams(num_iters=1)
+            ll.append(gp.log_lambdas.detach().numpy().copy()); lf.append(gp.log_sigma_f.item()); ln.append(gp.log_sigma_n.item())
+            gl.append(gp.log_lambdas.grad.numpy().copy()); gf.append(gp.log_sigma_f.grad.item()); gn.append(gp.log_sigma_n.grad.item())
+        out[tag + "_X"], out[tag + "_y"] = X, y
+        out[tag + "_ml"] = np.array(ml)
+        out[tag + "_log_lambdas"], out[tag + "_log_sigma_f"], out[tag + "_log_sigma_n"] = np.array(ll), np.array(lf), np.array(ln)
+        out[tag + "_g_log_lambdas"], out[tag + "_g_log_sigma_f"], out[tag + "_g_log_sigma_n"] = np.array(gl), np.array(gf), np.array(gn)
+
+    rng = np.random.default_rng(808)
+    X1 = np.arange(-5, 6, dtype=float)[:, None]                      # the reference's own test data shape (test_gpr.py:984-997)
+    traj("t1", X1, X1[:, 0] ** 2 + rng.normal(size=11), 1, None, 12)
+    traj("t2", X1, X1[:, 0] + np.sin(X1[:, 0]) + rng.normal(size=11), 1, (lambda x: x), 12)     # test_gpr.py:1065-1080
+    X3 = rng.uniform(-2, 2, (40, 3))
+    traj("t3", X3, np.sin(X3).sum(axis=1) + 0.1 * rng.normal(size=40), 3, None, 10)
+    np.savez(os.path.join(OUT, "g8_hyper.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    for fn in (g1, g2, g3, g4, g5, g6, g7):
+    only = sys.argv[1:]
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8):
+        if only and fn.__name__ not in only:
+            continue
         fn()
         print("wrote", fn.__name__)

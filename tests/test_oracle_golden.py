@@ -189,3 +189,29 @@ def test_cport_matches_reference_fixture(golden):
         np.testing.assert_allclose(r["vars"], z["vars"], rtol=1e-6)
         np.testing.assert_allclose(r["cost"], z["costs"][gi], rtol=1e-7)
         np.testing.assert_allclose(r["grad"], z["grads"][gi], rtol=1e-6, atol=1e-9)
+
+
+def test_g8_marginal_likelihood(golden):
+    """compute_marginal_likelihood at set hyper-parameters (src/gpr.py:240-251)."""
+    d = golden("g8_hyper.npz")
+    lam = torch.as_tensor(O.effective_hyper(d["ml_lam"]))
+    sf, sn = (float(O.effective_hyper(float(v))) for v in d["ml_hyp"])
+    ml = O.marginal_likelihood(d["ml_X"], d["ml_y"], lam, sf, sn).item()
+    assert ml == pytest.approx(float(d["ml_value"]), rel=1e-12)
+
+
+@pytest.mark.parametrize("tag,x_dim,nominal", [("t1", 1, False), ("t2", 1, True), ("t3", 3, False)])
+def test_g8_update_hyperparams(golden, tag, x_dim, nominal):
+    """update_hyperparams trajectories (src/gpr.py:334-370): likelihood, autograd gradients and the Adam iterates."""
+    d = golden("g8_hyper.npz")
+    X, y = d[tag + "_X"], d[tag + "_y"]
+    tr = O.HyperTrainer(X, y, x_dim, nominal=X[:, 0] if nominal else None)
+    for k in range(len(d[tag + "_ml"])):
+        h = tr.step()
+        assert h["ml"] == pytest.approx(d[tag + "_ml"][k], rel=1e-10)
+        np.testing.assert_allclose(h["grad"]["log_lambdas"], d[tag + "_g_log_lambdas"][k], rtol=1e-7, atol=1e-9)
+        assert h["grad"]["log_sigma_f"] == pytest.approx(d[tag + "_g_log_sigma_f"][k], rel=1e-7, abs=1e-9)
+        assert h["grad"]["log_sigma_n"] == pytest.approx(d[tag + "_g_log_sigma_n"][k], rel=1e-6, abs=1e-7)
+        np.testing.assert_allclose(h["log_lambdas"], d[tag + "_log_lambdas"][k], rtol=1e-8, atol=1e-10)
+        assert h["log_sigma_f"] == pytest.approx(d[tag + "_log_sigma_f"][k], rel=1e-8, abs=1e-10)
+        assert h["log_sigma_n"] == pytest.approx(d[tag + "_log_sigma_n"][k], rel=1e-8, abs=1e-10)
