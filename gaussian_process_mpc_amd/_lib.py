@@ -72,6 +72,8 @@ SIGNATURES = {
     "gpmpc_kinv_append": (_i, [_i, _vp, _vp, _d, _vp, _vp, _sz, _vp]),
     "gpmpc_predict_workspace_bytes": (_sz, [_i, _i, _i]),
     "gpmpc_predict": (_i, [_i, _i, _vp, _dp, _d, _vp, _vp, _d, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "gpmpc_ml_grad_workspace_bytes": (_sz, [_i, _i]),
+    "gpmpc_ml_grad": (_i, [_i, _i, _vp, _vp, _vp, _vp, _dp, _d, _d, _vp, _vp, _sz, _vp]),
 }
 
 _lib = None

@@ -1,11 +1,9 @@
-"""GaussianProcessRegression: host-side mirror of the reference class (src/gpr.py:5-332) for the
-parts the rollout path touches: training-data state, hyper-parameter setters/getters,
-``build_Ky_inv_mat`` and the predict API.  Arithmetic runs on the device through the C ABI
-(``gpmpc_build_ky``, ``gpmpc_matvec``, ``gpmpc_predict``); the matrix inverse is
-``torch.linalg.inv`` on the device, as in the reference (src/gpr.py:171).
-
-Out of scope (not on the path): hyper-parameter training
-(``update_hyperparams``, marginal-likelihood gradients) and ``update_Ky_inv_mat``.
+"""GaussianProcessRegression: host-side mirror of the reference class (src/gpr.py:5-370): training-data
+state, hyper-parameter setters/getters, ``build_Ky_inv_mat``, the predict API and hyper-parameter
+training (``compute_marginal_likelihood``, ``update_hyperparams``).  Arithmetic runs on the device
+through the C ABI (``gpmpc_build_ky``, ``gpmpc_matvec``, ``gpmpc_predict``, ``gpmpc_ml_grad``,
+``gpmpc_kinv_append``); the matrix inverse / Cholesky factor are torch's (rocSOLVER) on the device,
+as in the reference (src/gpr.py:171).
 """
 import ctypes
 
@@ -32,6 +30,7 @@ class GaussianProcessRegression(object):
         self.f_nom = nominal_model
         self.version = 0            # bumped whenever Ky_inv changes (Dynamics uses it to refresh its pack)
         self._beta = None
+        self._adam = None           # (optimizer, host parameters) of update_hyperparams, created on first use
 
     # -- hyper-parameters: same expressions as the reference setters (src/gpr.py:51-88), including the
     #    dtype inference of torch.tensor (a Python float / list is float32 before the log).  Like the
@@ -39,6 +38,7 @@ class GaussianProcessRegression(object):
     #    result moved to the device, so the values are those of the CPU reference the oracle is pinned
     #    to (float32 log differs by an ulp between host and device libm).
     def _log_param(self, value):
+        self._adam = None           # the optimiser state belongs to the parameters it was created on
         return torch.log(torch.tensor(value)).type(torch.float64).to(self.device).requires_grad_()
 
     def set_lambdas(self, lambdas):
@@ -185,3 +185,101 @@ class GaussianProcessRegression(object):
         if not covar:
             return f.cpu().detach().numpy(), None
         return f.cpu().detach().numpy(), cov.cpu().detach().numpy()
+
+    # -- hyper-parameter training (src/gpr.py:173-251, 334-370)
+    def _noise_var(self):
+        # src/gpr.py:170: the noise variance on the diagonal of Ky is float32(sigma_n^2)
+        return float((torch.exp(self.log_sigma_n.detach().cpu()) ** 2 * torch.ones(1)).item())
+
+    def _ml_terms(self):
+        """One device pass (C ABI ``gpmpc_ml_grad``): [d ml/d log lambda (D), d/d log sigma_f, d/d log sigma_n, r^T alpha]."""
+        n, D = self.num_train, self.x_dim
+        X, kinv, resid, alpha = self.X_train.contiguous(), self.Ky_inv.contiguous(), self._targets(), self.beta()
+        _, lp = host_doubles(self.get_lambdas())
+        out = torch.empty(D + 3, dtype=torch.float64, device=self.device)
+        nb = lib().gpmpc_ml_grad_workspace_bytes(n, D)
+        ws = torch.empty(nb, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().gpmpc_ml_grad(n, D, ptr(X), ptr(kinv), ptr(alpha), ptr(resid), lp, self.get_sigma_f(), self._noise_var(),
+                                      ptr(out), ctypes.c_void_p(ws.data_ptr()), nb, stream_ptr()), "gpmpc_ml_grad")
+        return out
+
+    def _logdet_Ky(self):
+        """log det(Ky).  The reference takes log(det(Ky)) (src/gpr.py:245), which over/underflows for large N; the
+        Cholesky form is the same number whenever that one is finite."""
+        L, info = torch.linalg.cholesky_ex(self.Ky)
+        if int(info.item()) == 0:
+            return 2.0 * torch.log(torch.diagonal(L)).sum()
+        sign, logabs = torch.linalg.slogdet(self.Ky)
+        return logabs if sign.item() > 0 else torch.tensor(float("nan"), dtype=torch.float64, device=self.device)
+
+    def compute_marginal_likelihood(self):
+        """-1/2 r^T Ky_inv r - 1/2 log det Ky - N/2 log(2 pi), r = y - f_nom(X): (1,1) device tensor
+        (src/gpr.py:240-251; no autograd graph -- the gradient is ``marginal_likelihood_gradient``)."""
+        quad = self._ml_terms()[self.x_dim + 2]
+        ml = -0.5 * quad - 0.5 * self._logdet_Ky() - self.num_train / 2 * np.log(2 * np.pi)
+        return ml.reshape(1, 1)
+
+    def marginal_likelihood_gradient(self):
+        """Gradient of the likelihood w.r.t. the log hyper-parameters, as numpy: what ``.grad`` of log_lambdas /
+        log_sigma_f / log_sigma_n holds after ``ml.backward()`` in the reference (src/gpr.py:337-338); also the
+        'log_*' entries of marginal_likelihood_grad (src/gpr.py:200-238)."""
+        g = self._ml_terms().cpu().numpy()
+        D = self.x_dim
+        return {"log_lambda": g[:D].copy(), "log_sigma_f": float(g[D]), "log_sigma_n": float(g[D + 1])}
+
+    def kernel_matrix_gradient(self):
+        """Dense dKy/dlambda_k (N,N,D), dKy/dsigma_f, dKy/dsigma_n as in src/gpr.py:173-198 (device tensors).  API
+        compatibility only: the training path never materialises them."""
+        lam = torch.exp(self.log_lambdas.detach())
+        sf, sn = torch.exp(self.log_sigma_f.detach()), torch.exp(self.log_sigma_n.detach())
+        diff2 = torch.square(self.X_train[:, None, :] - self.X_train[None, :, :])
+        return {"lambda": self.Kf[:, :, None] * diff2 / (2 * lam ** 2), "sigma_f": 2 / sf * self.Kf,
+                "sigma_n": 2 * sn * torch.eye(self.num_train, dtype=torch.float64, device=self.device)}
+
+    def marginal_likelihood_grad(self, gradient_dict=None):
+        """Same keys as src/gpr.py:200-238; computed from the one-pass kernel (``gradient_dict`` is accepted and ignored)."""
+        g = self.marginal_likelihood_gradient()
+        lam, sf, sn = self.get_lambdas(), self.get_sigma_f(), self.get_sigma_n()
+        dev = lambda v: torch.as_tensor(v, dtype=torch.float64, device=self.device)   # noqa: E731
+        return {"lambda": dev(g["log_lambda"] / lam), "sigma_f": dev(g["log_sigma_f"] / sf), "sigma_n": dev(g["log_sigma_n"] / sn),
+                "log_lambda": dev(g["log_lambda"]), "log_sigma_f": dev(g["log_sigma_f"]), "log_sigma_n": dev(g["log_sigma_n"])}
+
+    def update_hyperparams(self, num_iters=1000, verbose=False):
+        """Maximise the marginal likelihood with Adam(lr=0.1, betas=(0.9, 0.999)) over [log_lambdas, log_sigma_n,
+        log_sigma_f]; per iteration: gradient at the current matrices, Adam step, rebuild; stops when every
+        |gradient| < 1e-5 (src/gpr.py:46-49, 334-370).  The gradient is the analytic trace form evaluated by
+        ``gpmpc_ml_grad`` instead of autograd through inv / det.  Differences from the reference: nothing is
+        printed unless ``verbose``; the optimiser follows hyper-parameters changed through the setters (in the
+        reference the setters replace the tensors the optimiser was built on, so training after a setter call
+        silently updates nothing).  Returns the list of per-iteration records."""
+        if self._adam is None:
+            host = [self.log_lambdas.detach().cpu().clone().requires_grad_(),
+                    self.log_sigma_n.detach().cpu().clone().requires_grad_(),
+                    self.log_sigma_f.detach().cpu().clone().requires_grad_()]
+            adam = torch.optim.Adam(params=host, lr=0.1, betas=(0.9, 0.999), maximize=True)
+            self._adam = (adam, host)
+        adam, host = self._adam
+        history = []
+        for it in range(num_iters):
+            g = self._ml_terms().cpu()
+            D = self.x_dim
+            ml = (-0.5 * g[D + 2] - 0.5 * self._logdet_Ky().cpu() - self.num_train / 2 * np.log(2 * np.pi)).item()
+            host[0].grad = g[:D].clone()
+            host[1].grad = g[D + 1].clone().reshape(())
+            host[2].grad = g[D].clone().reshape(())
+            adam.step()
+            self.log_lambdas = host[0].detach().clone().to(self.device).requires_grad_()
+            self.log_sigma_n = host[1].detach().clone().to(self.device).requires_grad_()
+            self.log_sigma_f = host[2].detach().clone().to(self.device).requires_grad_()
+            self.build_Ky_inv_mat()
+            rec = {"ml": ml, "grad": {"log_lambdas": g[:D].numpy().copy(), "log_sigma_f": g[D].item(), "log_sigma_n": g[D + 1].item()},
+                   "log_lambdas": host[0].detach().numpy().copy(), "log_sigma_f": host[2].item(), "log_sigma_n": host[1].item()}
+            history.append(rec)
+            if verbose:
+                print("Iter: ", it, " ml: ", ml, " lambdas: ", self.get_lambdas(), " sigma_f: ", self.get_sigma_f(),
+                      " sigma_n: ", self.get_sigma_n())
+            gr = rec["grad"]
+            if (np.abs(gr["log_lambdas"]) < 1e-5).all() and abs(gr["log_sigma_f"]) < 1e-5 and abs(gr["log_sigma_n"]) < 1e-5:
+                break
+        return history

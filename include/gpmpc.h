@@ -218,6 +218,17 @@ size_t gpmpc_kinv_append_workspace_bytes(int n);
 int gpmpc_kinv_append(int n, const double* Ky_inv_dev, const double* k_dev, double kappa, double* out_dev,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* Gradient of the log marginal likelihood w.r.t. the LOG hyper-parameters in one pass over Ky_inv: replaces the autograd
+ * backward through inv / det of update_hyperparams (src/gpr.py:334-338; likelihood src/gpr.py:240-251) and the dense
+ * N x N x D derivative tensors of kernel_matrix_gradient / marginal_likelihood_grad (src/gpr.py:173-238).
+ * X dev [n][D] row-major; Ky_inv dev [n][n]; alpha dev [n] = Ky_inv r; resid dev [n] = r = y - f_nom(X);
+ * lambdas host [D]; noise_var = sigma_n^2 as it sits on the diagonal of Ky.
+ * out dev [D+3]: d ml/d log lambda_k (D), d ml/d log sigma_f, d ml/d log sigma_n, and r^T alpha (the data-fit term of ml). */
+size_t gpmpc_ml_grad_workspace_bytes(int n, int D);
+int gpmpc_ml_grad(int n, int D, const double* X_dev, const double* Ky_inv_dev, const double* alpha_dev,
+                  const double* resid_dev, const double* lambdas_host, double sigma_f, double noise_var,
+                  double* out_dev, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -238,3 +238,96 @@ def test_incremental_append_matches_rebuild(G, golden):
     np.testing.assert_allclose(inc.Ky_inv.cpu().numpy(), z["Ky_inv"], rtol=0, atol=1e-9 * scale)
     f_inc, _ = inc.predict_latent_vars(z["Xp"])
     np.testing.assert_allclose(f_inc, z["f"], rtol=1e-8)
+
+
+# ---- hyper-parameter training: src/gpr.py:173-251, 334-370 -------------------------------------------
+def test_marginal_likelihood_value(G, golden):
+    d = golden("g8_hyper.npz")
+    gp = G.GaussianProcessRegression(3)
+    gp.set_lambdas(d["ml_lam"]); gp.set_sigma_f(1.4); gp.set_sigma_n(0.2)
+    gp.append_train_data(d["ml_X"], d["ml_y"])
+    ml = gp.compute_marginal_likelihood()
+    assert tuple(ml.shape) == (1, 1) and ml.is_cuda
+    assert ml.item() == pytest.approx(float(d["ml_value"]), rel=1e-10)
+
+
+def test_marginal_likelihood_gradient_against_oracle_autograd(G):
+    """one-pass trace kernel (gpmpc_ml_grad) vs autograd through inv / det (the reference's backward)."""
+    from oracle import gpmpc_oracle as O
+    rng = np.random.default_rng(31)
+    for N, D, nominal in [(37, 2, False), (130, 5, False), (64, 1, True), (200, 8, False)]:
+        X = rng.uniform(-2, 2, (N, D)); y = np.sin(X).sum(axis=1) + 0.1 * rng.normal(size=N)
+        ll, lf, ln = rng.uniform(-0.5, 1.0, D), 0.3, -1.2
+        nom = (lambda x: 0.5 * x[:, 0:1]) if nominal else None
+        gp = G.GaussianProcessRegression(D, nominal_model=nom)
+        gp.set_lambdas(np.exp(ll)); gp.set_sigma_f(np.array(np.exp(lf))); gp.set_sigma_n(np.array(np.exp(ln)))   # float64 arrays: exact logs
+        gp.append_train_data(X, y)
+        tr = O.HyperTrainer(X, y, D, nominal=0.5 * X[:, 0] if nominal else None,
+                            log_lambdas=gp.log_lambdas.detach().cpu().numpy(), log_sigma_f=gp.log_sigma_f.item(),
+                            log_sigma_n=gp.log_sigma_n.item())
+        ref = tr.step()                                   # likelihood + gradients at the initial point
+        g = gp.marginal_likelihood_gradient()
+        assert gp.compute_marginal_likelihood().item() == pytest.approx(ref["ml"], rel=1e-9)
+        np.testing.assert_allclose(g["log_lambda"], ref["grad"]["log_lambdas"], rtol=1e-7, atol=1e-8)
+        assert g["log_sigma_f"] == pytest.approx(ref["grad"]["log_sigma_f"], rel=1e-7, abs=1e-8)
+        assert g["log_sigma_n"] == pytest.approx(ref["grad"]["log_sigma_n"], rel=2e-6, abs=1e-6)   # float32 noise path in the reference
+        # dense API-compatibility tensors: 1/2 tr(B dK) reproduces the kernel's numbers
+        dK = gp.kernel_matrix_gradient()
+        a = gp.beta().reshape(-1, 1)
+        Bm = a @ a.T - gp.Ky_inv
+        dense = np.array([0.5 * (Bm * dK["lambda"][:, :, k].T).sum().item() for k in range(D)]) * gp.get_lambdas()
+        np.testing.assert_allclose(dense, g["log_lambda"], rtol=1e-9, atol=1e-10)
+        mg = gp.marginal_likelihood_grad(dK)
+        assert mg["sigma_f"].item() * gp.get_sigma_f() == pytest.approx(g["log_sigma_f"], rel=1e-12)
+
+
+@pytest.mark.parametrize("tag,x_dim,nominal", [("t1", 1, False), ("t2", 1, True), ("t3", 3, False)])
+def test_update_hyperparams_matches_reference_trajectory(G, golden, tag, x_dim, nominal):
+    """Adam iterates of update_hyperparams against the reference's own (src/gpr.py:334-370; fixture g8)."""
+    d = golden("g8_hyper.npz")
+    gp = G.GaussianProcessRegression(x_dim, nominal_model=(lambda x: x) if nominal else None)
+    gp.append_train_data(d[tag + "_X"], d[tag + "_y"])
+    K = len(d[tag + "_ml"])
+    hist = gp.update_hyperparams(num_iters=K)
+    assert len(hist) == K
+    # The reference's sigma_n gradient passes through a float32 product (sigma_n**2 * float32 eye, src/gpr.py:170), i.e.
+    # carries ~1e-7 relative noise that Adam feeds back into every iterate; the kernel's gradient is float64.  The
+    # trajectories therefore agree to ~1e-7 in the log-parameters and, with |d ml / d theta| ~ 1e2, ~1e-6 in ml.
+    for k, h in enumerate(hist):
+        assert h["ml"] == pytest.approx(d[tag + "_ml"][k], rel=2e-6)
+        np.testing.assert_allclose(h["grad"]["log_lambdas"], d[tag + "_g_log_lambdas"][k], rtol=2e-5, atol=1e-5)
+        assert h["grad"]["log_sigma_n"] == pytest.approx(d[tag + "_g_log_sigma_n"][k], rel=2e-5, abs=1e-5)
+        np.testing.assert_allclose(h["log_lambdas"], d[tag + "_log_lambdas"][k], rtol=1e-5, atol=1e-6)
+        assert h["log_sigma_f"] == pytest.approx(d[tag + "_log_sigma_f"][k], rel=1e-5, abs=1e-6)
+        assert h["log_sigma_n"] == pytest.approx(d[tag + "_log_sigma_n"][k], rel=1e-5, abs=1e-6)
+    # the matrices were rebuilt at the final hyper-parameters, and the likelihood went up
+    assert hist[-1]["ml"] > hist[0]["ml"]
+    np.testing.assert_allclose(gp.get_lambdas(), np.exp(d[tag + "_log_lambdas"][-1]), rtol=1e-5)
+    # a second call continues with the same Adam state (k calls of one iteration == k iterations)
+    gp2 = G.GaussianProcessRegression(x_dim, nominal_model=(lambda x: x) if nominal else None)
+    gp2.append_train_data(d[tag + "_X"], d[tag + "_y"])
+    for _ in range(3):
+        gp2.update_hyperparams(num_iters=1)
+    np.testing.assert_allclose(gp2.log_lambdas.detach().cpu().numpy(), d[tag + "_log_lambdas"][2], rtol=1e-5, atol=1e-6)
+
+
+def test_ml_grad_abi_errors(G):
+    import ctypes
+    from gaussian_process_mpc_amd._lib import lib, ptr, host_doubles
+    L = lib()
+    assert L.gpmpc_ml_grad_workspace_bytes(0, 3) == 0 and L.gpmpc_ml_grad_workspace_bytes(10, 9) == 0
+    n, D = 16, 2
+    X = torch.zeros((n, D), dtype=torch.float64, device="cuda"); K = torch.eye(n, dtype=torch.float64, device="cuda")
+    a = torch.zeros(n, dtype=torch.float64, device="cuda"); out = torch.zeros(D + 3, dtype=torch.float64, device="cuda")
+    nb = L.gpmpc_ml_grad_workspace_bytes(n, D)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    _, lp = host_doubles(np.array([1.0, 2.0]))
+    _, bad = host_doubles(np.array([1.0, -2.0]))
+    wsp = ctypes.c_void_p(ws.data_ptr())
+    assert L.gpmpc_ml_grad(n, D, ptr(X), ptr(K), ptr(a), ptr(a), lp, 1.0, 0.01, ptr(out), wsp, nb - 8, None) != 0   # workspace
+    assert L.gpmpc_ml_grad(n, D, ptr(X), ptr(K), ptr(a), ptr(a), bad, 1.0, 0.01, ptr(out), wsp, nb, None) != 0     # lambda <= 0
+    assert L.gpmpc_ml_grad(n, 9, ptr(X), ptr(K), ptr(a), ptr(a), lp, 1.0, 0.01, ptr(out), wsp, nb, None) != 0      # D > GPMPC_MAX_D
+    assert L.gpmpc_ml_grad(n, D, ptr(X), ptr(K), ptr(a), ptr(a), lp, 1.0, 0.01, ptr(out), wsp, nb, None) == 0
+    torch.cuda.synchronize()
+    # alpha = 0, Ky_inv = I, X = 0: B = -I, Kf = sigma_f^2 -> d/dlog sigma_f = -n, d/dlog sigma_n = -n * noise, lambda terms 0
+    np.testing.assert_allclose(out.cpu().numpy(), [0.0, 0.0, -n, -n * 0.01, 0.0], atol=1e-12)
