@@ -53,10 +53,36 @@ __host__ __device__ static inline int sps_of(int D) { return 3 + 4 * D; }
 __device__ static void finish_step(const RollArgs& A, int b, int t, int own, double* s_z /* [ds*nm] */,
                                    double* s_red /* [ds*nm*GPMPC_RED_CH] */, double* s_mu, double* s_var) {
     const int ds = A.ds, D = A.D, nm = A.nm;
-    // Sum the per-tile partials of every (GP, moment) output.  GPMPC_RED_CH threads share one output (each a strided
-    // subset of the work items, so the global loads of a pass are independent), then a fixed-order combine: the
-    // summation order depends only on the shapes, never on timing.
-    {
+    // Sum the per-tile partials of every (GP, moment) output; either way the summation order depends only on the
+    // shapes, never on timing.
+    if (A.nwork > 128 * ds) {
+        // Many items per GP (small batches of a large N use 64 x 64 tiles: 528 per GP at N = 2048, which the scheme
+        // below walked 66 deep, 45 us per step): one wave per GP, a lane takes whole work items -- the nm moments of an
+        // item are contiguous and the loads of different items are independent -- and the wave sum is the final value.
+        constexpr int NMAX = 1 + 2 * GPMPC_MAX_D;
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+        const double* p = A.part + (size_t)b * A.nwork * nm;
+        for (int a = w; a < ds; a += nw) {
+            double acc[NMAX];
+#pragma unroll
+            for (int m = 0; m < NMAX; ++m) acc[m] = 0.0;
+            const int w0 = A.work ? 0 : A.ustart[a], w1 = A.work ? A.nwork : A.ustart[a + 1];
+            for (int wi = w0 + lane; wi < w1; wi += 64) {
+                if (A.work && A.work[4 * wi] != a) continue;
+                const double* q = p + (size_t)wi * nm;
+#pragma unroll
+                for (int m = 0; m < NMAX; ++m) if (m < nm) acc[m] += q[m];
+            }
+#pragma unroll
+            for (int m = 0; m < NMAX; ++m)
+                if (m < nm) {
+                    const double sw = wave_sum(acc[m]);
+                    if (lane == 0) s_z[a * nm + m] = sw;
+                }
+        }
+    } else {
+        // Few items per GP: GPMPC_RED_CH threads share one output (each a strided subset of the work items, so the
+        // global loads of a pass are independent), then a fixed-order combine.
         const int nout = ds * nm, ch = threadIdx.x % GPMPC_RED_CH, per_pass = blockDim.x / GPMPC_RED_CH;
         for (int o0 = 0; o0 < nout; o0 += per_pass) {
             const int o = o0 + threadIdx.x / GPMPC_RED_CH;
