@@ -516,22 +516,30 @@ struct RollPlan { int tiling, tb, waves, nwork, nm, pps, sps, sb, gw, rgroup; si
 
 static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag, RollPlan* r) {
     const int D = p->D;
-    // scalar-broadcast pair kernel (pair_kernel_sb.h) for the rollout; GPMPC_PAIR_SB=0 selects the staged kernel.
-    // Shapes (C3, ms per launch): scalar-broadcast TB 1: 2.30, TB 2: 2.41; staged TB 2: 2.82, TB 4: 3.37.
-    // (one-wave 64x64 tiles of small batches keep the staged kernel: too few waves to hide the scalar loads)
-    const bool big = (long)((B + 1) / 2) * p->wl[0][0].nwork >= 1024;
-    r->sb = (diag && p->da <= 2 && big) ? 1 : 0;
-    if (const char* ev = getenv("GPMPC_PAIR_SB")) r->sb = (atoi(ev) != 0 && diag && p->da <= 2) ? 1 : 0;
+    // Shapes, by how many workgroups they give (>= 1024 fills the 256 CUs four deep):
+    //   256x256 tiles, scalar-broadcast kernel   large batches (C3: 2.2 ms per launch; staged kernel TB 2: 2.82)
+    //   256x64 tiles, scalar-broadcast kernel    small batches of a large N (N = 2048: B = 2..8 run 17-39 % faster than
+    //                                            on one-wave tiles; 256x32 only helps B = 1, by 2 %)
+    //   64x64 one-wave tiles, staged kernel      everything smaller (too few waves to hide the scalar loads)
+    const bool sb_ok = diag && p->da <= 2;
+    // (N = 2048: 256x256 wins from B ~ 24 on: B = 16 3.4 k vs 3.7 k rollouts/s on 256x64, B = 32 4.6 k vs 4.3 k)
+    const bool big = sb_ok ? (long)B * p->wl[0][0].nwork >= 3072 : (long)((B + 1) / 2) * p->wl[0][0].nwork >= 1024;
+    const bool mid = !big && sb_ok && (long)B * p->wl[0][2].nwork >= 1024;
+    r->sb = (sb_ok && (big || mid)) ? 1 : 0;
+    r->tiling = big ? 0 : (mid ? 2 : 1);
+    if (const char* ev = getenv("GPMPC_PAIR_SB")) {          // tuning override: 0 = staged kernel, 1 = scalar broadcast
+        r->sb = (atoi(ev) != 0 && sb_ok) ? 1 : 0;
+        r->tiling = r->sb ? (big ? 0 : 2) : (big ? 0 : 1);
+    }
     r->tb = r->sb ? 1 : (B >= 2 ? 2 : 1);
     if (const char* ev = getenv("GPMPC_PAIR_TB")) { const int v = atoi(ev); if (v == 1 || v == 2 || (v == 4 && !r->sb)) r->tb = v; }
     if (!diag && grad && r->tb > 2) r->tb = 2;
-    // big workgroups once they already oversubscribe the 256 CUs; one-wave tiles otherwise
-    r->tiling = big ? 0 : 1;
     // Dispatch interleave of the scalar-broadcast kernel (pair_kernel_sb.h): 4 row tiles per trajectory share each fetch
     // of the G rows (C3 fabric reads per launch 757 -> 418 MB by FETCH_SIZE, same speed) as long as the weight matrices
     // stay resident in the 256 MB infinity cache; past that the extra M re-reads cost more than they save (C4: -2.5 %).
     r->rgroup = ((size_t)p->ds * p->Np * p->Np * sizeof(double) <= ((size_t)192 << 20)) ? 4 : 1;
     if (const char* ev = getenv("GPMPC_RGROUP")) { const int v = atoi(ev); if (v >= 1 && v <= 16) r->rgroup = v; }
+    if (r->tiling != 0) r->rgroup = 1;
     r->waves = p->wl[0][r->tiling].waves;
     r->nwork = p->wl[0][r->tiling].nwork;
     r->nm = gpmpc_num_moments(D, diag, grad);
