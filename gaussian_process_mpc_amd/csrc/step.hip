@@ -531,6 +531,7 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
         r->sb = (atoi(ev) != 0 && sb_ok) ? 1 : 0;
         r->tiling = r->sb ? (big ? 0 : 2) : (big ? 0 : 1);
     }
+    if (const char* ev = getenv("GPMPC_TILING")) { const int v = atoi(ev); if (v == 0 || (v == 1 && !r->sb) || (v == 2 && r->sb)) r->tiling = v; }
     r->tb = r->sb ? 1 : (B >= 2 ? 2 : 1);
     if (const char* ev = getenv("GPMPC_PAIR_TB")) { const int v = atoi(ev); if (v == 1 || v == 2 || (v == 4 && !r->sb)) r->tb = v; }
     if (!diag && grad && r->tb > 2) r->tb = 2;
