@@ -47,7 +47,7 @@ struct gpmpc_pack {
     double lam_host[GPMPC_MAX_DS][GPMPC_MAX_D];
     double sf_host[GPMPC_MAX_DS];
     void* graph_cache;         // captured rollout (GPMPC_USE_GRAPH), owned by step.hip
-    gpmpc_worklist wl[2][3];   // [0: variance units only | 1: + cross units][0: 256x256 tiles | 1: 64x64 one-wave tiles | 2: 256x64]
+    gpmpc_worklist wl[2][4];   // [0: variance units only | 1: + cross units][0: 256x256 tiles | 1: 64x64 | 2: 256x64 | 3: 64x128]
 };
 
 // Number of pair-kernel output moments per (trajectory, GP, tile).

@@ -200,10 +200,12 @@ extern "C" int gpmpc_pack_create(gpmpc_pack** out, int n_train, int state_dim, i
     bool ok = e == hipSuccess;
     // 256-row workgroups: 512 / 1024 rows would cut the G-row re-reads 2x / 4x but ran 8 % / 46 % slower on C3 (C4: -1 %).
     // 256x64: scalar-broadcast kernel for small batches of a large N (enough workgroups to fill the chip at B = 1).
-    const int cfg[3][2] = {{256, 256}, {64, 64}, {256, 64}};
+    // 64x128: staged kernel for B = 1 of a large N (fewer partial sums to reduce per step: N = 2048 1.30 -> 1.18 ms per
+    // rollout; N <= 512 is 10 % slower on it and stays on 64x64).
+    const int cfg[4][2] = {{256, 256}, {64, 64}, {256, 64}, {64, 128}};
     for (int mode = 0; mode < 2 && ok; ++mode)
-        for (int k = 0; k < 3 && ok; ++k) {
-            if (mode == 1 && k == 2) continue;
+        for (int k = 0; k < 4 && ok; ++k) {
+            if (mode == 1 && k >= 2) continue;
             ok = build_worklist(p->Np, cfg[k][0], cfg[k][1], state_dim, mode ? p->npairs : 0, mode == 0 && k == 0 && !getenv("GPMPC_NO_XCD_SORT"), &p->wl[mode][k]) == 0;
         }
     if (!ok) { gpmpc_set_error("gpmpc_pack_create", e); gpmpc_pack_destroy(p); return GPMPC_E_ALLOC; }
@@ -222,7 +224,7 @@ extern "C" int gpmpc_pack_destroy(gpmpc_pack* p) {
     gpmpc_graph_cache_free(p->graph_cache);
     if (p->pair_ab_dev) (void)hipFree(p->pair_ab_dev);
     for (int mode = 0; mode < 2; ++mode)
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < 4; ++k) {
             if (p->wl[mode][k].work_dev) (void)hipFree(p->wl[mode][k].work_dev);
             if (p->wl[mode][k].ustart_dev) (void)hipFree(p->wl[mode][k].ustart_dev);
         }

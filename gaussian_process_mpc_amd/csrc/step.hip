@@ -520,18 +520,20 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     //   256x256 tiles, scalar-broadcast kernel   large batches (C3: 2.2 ms per launch; staged kernel TB 2: 2.82)
     //   256x64 tiles, scalar-broadcast kernel    small batches of a large N (N = 2048: B = 2..8 run 17-39 % faster than
     //                                            on one-wave tiles; 256x32 only helps B = 1, by 2 %)
-    //   64x64 one-wave tiles, staged kernel      everything smaller (too few waves to hide the scalar loads)
+    //   64x64 / 64x128 tiles, staged kernel      everything smaller (too few waves to hide the scalar loads); the rows
+    //                                            of a tile are shared by 4 waves that split its columns
     const bool sb_ok = diag && p->da <= 2;
     // (N = 2048: 256x256 wins from B ~ 24 on: B = 16 3.4 k vs 3.7 k rollouts/s on 256x64, B = 32 4.6 k vs 4.3 k)
     const bool big = sb_ok ? (long)B * p->wl[0][0].nwork >= 3072 : (long)((B + 1) / 2) * p->wl[0][0].nwork >= 1024;
     const bool mid = !big && sb_ok && (long)B * p->wl[0][2].nwork >= 1024;
     r->sb = (sb_ok && (big || mid)) ? 1 : 0;
-    r->tiling = big ? 0 : (mid ? 2 : 1);
+    const bool many = (long)p->wl[0][1].nwork > 256L * p->ds;        // > 256 one-wave tiles per GP (N >= 1472)
+    r->tiling = big ? 0 : (mid ? 2 : (many ? 3 : 1));
     if (const char* ev = getenv("GPMPC_PAIR_SB")) {          // tuning override: 0 = staged kernel, 1 = scalar broadcast
         r->sb = (atoi(ev) != 0 && sb_ok) ? 1 : 0;
-        r->tiling = r->sb ? (big ? 0 : 2) : (big ? 0 : 1);
+        r->tiling = r->sb ? (big ? 0 : 2) : (big ? 0 : (many ? 3 : 1));
     }
-    if (const char* ev = getenv("GPMPC_TILING")) { const int v = atoi(ev); if (v == 0 || (v == 1 && !r->sb) || (v == 2 && r->sb)) r->tiling = v; }
+    if (const char* ev = getenv("GPMPC_TILING")) { const int v = atoi(ev); if (v == 0 || ((v == 1 || v == 3) && !r->sb) || (v == 2 && r->sb)) r->tiling = v; }
     r->tb = r->sb ? 1 : (B >= 2 ? 2 : 1);
     if (const char* ev = getenv("GPMPC_PAIR_TB")) { const int v = atoi(ev); if (v == 1 || v == 2 || (v == 4 && !r->sb)) r->tb = v; }
     if (!diag && grad && r->tb > 2) r->tb = 2;
@@ -601,7 +603,7 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
     PairArgs P;
     P.M = p->M; P.XT = p->XT; P.pp = A.pp; P.part = A.part; P.work = p->wl[0][r.tiling].work_dev;
     P.Np = p->Np; P.B = B; P.nunits = p->ds; P.nwork = r.nwork; P.pps = r.pps; P.nm = r.nm;
-    P.jside_off = 0; P.ntri = p->ds; P.ns2 = p->ds; P.colsplit = (r.tiling == 1) ? 1 : 0;
+    P.jside_off = 0; P.ntri = p->ds; P.ns2 = p->ds; P.colsplit = (r.tiling == 1 || r.tiling == 3) ? 1 : 0;
 
     for (int t = 1; t <= H; ++t) {
         switch (p->D) {
