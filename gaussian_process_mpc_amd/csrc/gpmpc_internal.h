@@ -113,10 +113,24 @@ void gpmpc_graph_cache_free(void* cache);
 // ---------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------
+// Sum over the 64 lanes of a wave, result in every lane.  DPP butterflies inside each row of 16 lanes (VALU moves: no
+// LDS round trips as with __shfl_xor / ds_bpermute, ~8x lower latency), then the four row sums are read with
+// v_readlane and added in a fixed order.
+template <int CTRL>
+__device__ __forceinline__ double gpmpc_dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double gpmpc_readlane_f64(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += gpmpc_dpp_f64<0xB1>(v);        // quad_perm [1,0,3,2]
+    v += gpmpc_dpp_f64<0x4E>(v);        // quad_perm [2,3,0,1]
+    v += gpmpc_dpp_f64<0x141>(v);       // row_half_mirror
+    v += gpmpc_dpp_f64<0x140>(v);       // row_mirror: every lane of a row holds the row's sum
+    return (gpmpc_readlane_f64(v, 0) + gpmpc_readlane_f64(v, 16)) + (gpmpc_readlane_f64(v, 32) + gpmpc_readlane_f64(v, 48));
 }
 
 // Sum NV per-thread values over the workgroup (<= 16 waves).  Result in out[0..NV) (LDS), visible to all

@@ -149,23 +149,36 @@ template <int D>
 __device__ static void prep_step(const RollArgs& A, int b, int t, int a, const double* s_mu, const double* s_var,
                                  double* s_u, double* s_s, double* s_scr, double* s_out, double* s_g) {
     const int ds = A.ds;
+    // per-dimension scalars: one lane per input dimension (the divisions and square roots are long dependent chains;
+    // every thread redoing all D of them, and thread 0 redoing them again at the end, was half of this kernel's time
+    // for small batches)
+    __shared__ double s_B[GPMPC_MAX_D], s_A[GPMPC_MAX_D], s_sc[GPMPC_MAX_D], s_r1[GPMPC_MAX_D], s_r2[GPMPC_MAX_D];
     if (threadIdx.x < D) {
         const int k = threadIdx.x;
+        double uk, sk;
         if (k < ds) {
-            s_u[k] = s_mu[k];
-            s_s[k] = s_var[k];
+            uk = s_mu[k];
+            sk = s_var[k];
         } else {
-            s_u[k] = A.U[((size_t)b * A.H + (t - 1)) * A.da + (k - ds)];
-            s_s[k] = GPMPC_ACTION_VAR;
+            uk = A.U[((size_t)b * A.H + (t - 1)) * A.da + (k - ds)];
+            sk = GPMPC_ACTION_VAR;
         }
+        const double lam = A.lam[a * D + k];
+        s_u[k] = uk;
+        s_s[k] = sk;
+        s_B[k] = 1.0 / (sk + lam);
+        s_A[k] = 1.0 / (0.5 * lam + sk);
+        s_sc[k] = sqrt(0.125 / (0.5 * lam + sk));          // the scale of the pair transform h = sc (u - x): pp and G rows use this value
+        s_r1[k] = sk / lam + 1.0;                          // factors of det(S/Lambda + I) and det(2S/Lambda + I)
+        s_r2[k] = 2.0 * sk / lam + 1.0;
     }
     __syncthreads();
     double u[D], Bk[D], sck[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) {
         u[k] = s_u[k];
-        Bk[k] = 1.0 / (s_s[k] + A.lam[a * D + k]);
-        sck[k] = sqrt(0.125 / (0.5 * A.lam[a * D + k] + s_s[k]));     // same expression as the pair parameters below
+        Bk[k] = s_B[k];
+        sck[k] = s_sc[k];
     }
     double* __restrict__ Grow = A.G ? A.G + ((size_t)b * ds + a) * A.Np * A.gw : nullptr;
     double v[1 + 2 * D];
@@ -204,29 +217,22 @@ __device__ static void prep_step(const RollArgs& A, int b, int t, int a, const d
         }
     }
     block_sum<1 + 2 * D>(v, s_scr, s_out);
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < D) {                                    // lane k writes the entries of dimension k; lane 0 the scalars
+        const int k = threadIdx.x;
         const double sf = A.sf[a], sf2 = sf * sf;
         double detm = 1.0, detv = 1.0;
-        for (int k = 0; k < D; ++k) {
-            const double lam = A.lam[a * D + k];
-            detm *= s_s[k] / lam + 1.0;
-            detv *= 2.0 * s_s[k] / lam + 1.0;
-        }
+        for (int l = 0; l < D; ++l) { detm *= s_r1[l]; detv *= s_r2[l]; }
         const double cm = sf2 / sqrt(detm), c = 1.0 / sqrt(detv);
         const double mu = cm * s_out[0];
         double* sp = A.sp + (((size_t)(t & 1) * A.B + b) * ds + a) * A.sps;   // other parity than the finish phase reads
         double* pp = A.pp + ((size_t)b * ds + a) * A.pps;
-        sp[0] = c; sp[1] = mu; sp[2] = sf2;
-        for (int k = 0; k < D; ++k) {
-            const double lam = A.lam[a * D + k];
-            const double Ak = 1.0 / (0.5 * lam + s_s[k]);
-            const double sc = sqrt(0.125 / (0.5 * lam + s_s[k]));
-            sp[3 + k] = Ak; sp[3 + D + k] = sc;
-            sp[3 + 2 * D + k] = -Bk[k] * cm * s_out[1 + k];
-            sp[3 + 3 * D + k] = -0.5 * mu * Bk[k] + 0.5 * Bk[k] * Bk[k] * cm * s_out[1 + D + k];
-            pp[k] = sc * s_u[k];
-            pp[D + k] = sc;
-        }
+        if (k == 0) { sp[0] = c; sp[1] = mu; sp[2] = sf2; }
+        const double Bq = s_B[k], sc = s_sc[k];
+        sp[3 + k] = s_A[k]; sp[3 + D + k] = sc;
+        sp[3 + 2 * D + k] = -Bq * cm * s_out[1 + k];
+        sp[3 + 3 * D + k] = -0.5 * mu * Bq + 0.5 * Bq * Bq * cm * s_out[1 + D + k];
+        pp[k] = sc * s_u[k];
+        pp[D + k] = sc;
     }
 }
 
