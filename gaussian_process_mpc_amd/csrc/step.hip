@@ -339,6 +339,124 @@ __device__ static double state_cost(int ds, const gpmpc_cost_params& C, const do
     return log(det) / g + quad;
 }
 
+// Input-cost terms of ONE step j (src/mpc.py:188-198) with their gradient w.r.t. U_j written (not accumulated) to gUj:
+// lets the tail evaluate the H steps on H threads.  The R_delta term couples neighbours: step j owns
+// d/dU_j of both (U_j - U_{j-1})^T R_d (U_j - U_{j-1}) and (U_{j+1} - U_j)^T R_d (U_{j+1} - U_j).
+__device__ static double input_cost_step(int j, int H, int da, const gpmpc_cost_params& C, const double* __restrict__ U,
+                                         double* gUj) {
+    double d[GPMPC_MAX_D], dd[GPMPC_MAX_D], dn[GPMPC_MAX_D];
+    for (int k = 0; k < da; ++k) {
+        const double uj = U[j * da + k];
+        d[k] = uj - C.u_ref[k];
+        dd[k] = uj - (j == 0 ? C.last_u[k] : U[(j - 1) * da + k]);
+        dn[k] = (j + 1 < H) ? U[(j + 1) * da + k] - uj : 0.0;
+    }
+    double c = 0.0;
+    for (int k = 0; k < da; ++k) {
+        double rd = 0.0, rtd = 0.0;
+        for (int l = 0; l < da; ++l) { rd += C.R[k * da + l] * d[l]; rtd += C.R[l * da + k] * d[l]; }
+        c += d[k] * rd;
+        double g = rd + rtd;
+        if (C.has_R_delta) {
+            double qd = 0.0, qtd = 0.0, qn = 0.0, qtn = 0.0;
+            for (int l = 0; l < da; ++l) {
+                qd += C.R_delta[k * da + l] * dd[l]; qtd += C.R_delta[l * da + k] * dd[l];
+                qn += C.R_delta[k * da + l] * dn[l]; qtn += C.R_delta[l * da + k] * dn[l];
+            }
+            c += dd[k] * qd;
+            g += (qd + qtd) - (qn + qtn);
+        }
+        if (gUj) gUj[k] = g;
+    }
+    return c;
+}
+
+// The same cost term for a DIAGONAL covariance with the state dimension known at compile time: everything lives in
+// registers (the generic version above walks an LDS scratch and the kernel-argument Q with run-time indices, ~20 k
+// cycles of dependent latency per call at ds = 3, which was most of the tail kernel for small batches).
+template <int DS>
+__device__ static double state_cost_diag(const gpmpc_cost_params& C, const double* __restrict__ mu,
+                                         const double* __restrict__ var, double* dmu, double* dvar) {
+    const double g = C.gamma;
+    double e[DS], Q[DS][DS], sg[DS];
+#pragma unroll
+    for (int k = 0; k < DS; ++k) {
+        e[k] = mu[k] - C.x_ref[k];
+        sg[k] = var[k];
+#pragma unroll
+        for (int l = 0; l < DS; ++l) Q[k][l] = C.Q[k * DS + l];
+    }
+    if (g == 0.0) {
+        double c = 0.0;
+#pragma unroll
+        for (int k = 0; k < DS; ++k) {
+            double qe = 0.0, qte = 0.0;
+#pragma unroll
+            for (int l = 0; l < DS; ++l) { qe += Q[k][l] * e[l]; qte += Q[l][k] * e[l]; }
+            c += Q[k][k] * sg[k];
+            c += e[k] * qe;
+            if (dmu) { dmu[k] = qe + qte; dvar[k] = Q[k][k]; }
+        }
+        return c;
+    }
+    double w[DS][2 * DS];          // augmented [I + gamma Q Sig | Q]
+#pragma unroll
+    for (int r = 0; r < DS; ++r)
+#pragma unroll
+        for (int cc = 0; cc < DS; ++cc) {
+            w[r][cc] = (r == cc ? 1.0 : 0.0) + g * (Q[r][cc] * sg[cc]);
+            w[r][DS + cc] = Q[r][cc];
+        }
+    double det = 1.0;
+#pragma unroll
+    for (int k = 0; k < DS; ++k) {           // Gauss-Jordan with partial pivoting (row swaps as predicated moves)
+        int piv = k;
+        double best = fabs(w[k][k]);
+#pragma unroll
+        for (int r = k + 1; r < DS; ++r) { const double v = fabs(w[r][k]); if (v > best) { best = v; piv = r; } }
+#pragma unroll
+        for (int r = k + 1; r < DS; ++r) {
+            const bool sw = piv == r;
+#pragma unroll
+            for (int cc = 0; cc < 2 * DS; ++cc) {
+                const double a = w[k][cc], bb = w[r][cc];
+                w[k][cc] = sw ? bb : a;
+                w[r][cc] = sw ? a : bb;
+            }
+        }
+        if (piv != k) det = -det;
+        const double pv = w[k][k];
+        det *= pv;
+        const double inv = 1.0 / pv;
+#pragma unroll
+        for (int cc = 0; cc < 2 * DS; ++cc) w[k][cc] *= inv;
+#pragma unroll
+        for (int r = 0; r < DS; ++r) {
+            if (r == k) continue;
+            const double f = w[r][k];
+#pragma unroll
+            for (int cc = 0; cc < 2 * DS; ++cc) w[r][cc] = fma(-f, w[k][cc], w[r][cc]);
+        }
+    }
+    double ze[DS], zte[DS], quad = 0.0;
+#pragma unroll
+    for (int k = 0; k < DS; ++k) {
+        double s1 = 0.0, st = 0.0;
+#pragma unroll
+        for (int l = 0; l < DS; ++l) { s1 += w[k][DS + l] * e[l]; st += w[l][DS + k] * e[l]; }
+        ze[k] = s1; zte[k] = st;
+        quad += e[k] * s1;
+    }
+    if (dmu) {
+#pragma unroll
+        for (int k = 0; k < DS; ++k) {
+            dmu[k] = ze[k] + zte[k];
+            dvar[k] = w[k][DS + k] - g * zte[k] * ze[k];
+        }
+    }
+    return log(det) / g + quad;
+}
+
 // Input-cost terms (src/mpc.py:188-198) for one trajectory; optionally accumulates d/dU into gU [H][da].
 __device__ static double input_cost(int H, int da, const gpmpc_cost_params& C, const double* U, double* gU) {
     double c = 0.0;
@@ -365,10 +483,11 @@ __device__ static double input_cost(int H, int da, const gpmpc_cost_params& C, c
 }
 
 // Tail: finish step H, cost, adjoint sweep.  One workgroup (256 threads) per trajectory; the first
-// GPMPC_TAIL_WORKERS threads evaluate the per-step cost terms (each needs an LU scratch in LDS), then the reverse
-// sweep runs one step per iteration with the (2ds) x (2ds+da) Jacobian of the next step prefetched into registers.
-// dynamic LDS: [WORKERS][ds*2ds] LU scratch | [H+1] cost terms | [H+1][2ds] local derivatives | [H*da] grad | [nz*nc] J
+// GPMPC_TAIL_WORKERS threads evaluate the per-step cost terms (register-resident LU, state_cost_diag), then the
+// reverse sweep over the (2ds) x (2ds+da) step Jacobians.
+// dynamic LDS: [H+1] cost terms | [H+1][2ds] local derivatives | [H*da] grad | [H] input-cost terms | [H or 1][nz*nc] J
 #define GPMPC_TAIL_WORKERS 32
+template <bool ALLJ, int DS>
 __global__ __launch_bounds__(256) void k_roll_tail(RollArgs A) {
     extern __shared__ double s_dyn[];
     __shared__ double s_z[GPMPC_MAX_DS * (1 + 2 * GPMPC_MAX_D)];
@@ -378,31 +497,60 @@ __global__ __launch_bounds__(256) void k_roll_tail(RollArgs A) {
     const int b = blockIdx.x, ds = A.ds, da = A.da, H = A.H, tid = threadIdx.x;
     const int nz = 2 * ds, nc = 2 * ds + da;
     finish_step(A, b, H, -1, s_z, s_zred, s_mu, s_var);
-    double* s_lu = s_dyn;
-    double* s_ct = s_dyn + GPMPC_TAIL_WORKERS * ds * 2 * ds;
+    double* s_ct = s_dyn;
     double* s_dl = s_ct + (H + 1);
     double* s_gU = s_dl + (size_t)(H + 1) * nz;
-    double* s_J = s_gU + H * da;
+    double* s_ci = s_gU + H * da;
+    double* s_J = s_ci + H;
     const double* mu = A.means + (size_t)b * (H + 1) * ds;
     const double* var = A.vars + (size_t)b * (H + 1) * ds;
+    if (ALLJ && A.grad) {                                 // issue the Jacobian loads before the (long, serial) cost terms
+        const double* Jb = A.jac + (size_t)b * H * nz * nc;
+        for (int q = tid; q < H * nz * nc; q += blockDim.x) s_J[q] = Jb[q];
+    }
     for (int i = tid; i <= H && tid < GPMPC_TAIL_WORKERS; i += GPMPC_TAIL_WORKERS)
-        s_ct[i] = state_cost(ds, A.cost, mu + i * ds, var + i * ds, 0, true, s_lu + tid * ds * 2 * ds,
-                             A.grad ? s_dl + i * nz : nullptr, A.grad ? s_dl + i * nz + ds : nullptr);
-    for (int q = tid; q < H * da; q += blockDim.x) s_gU[q] = 0.0;
-    // Jacobian of step H into registers while the cost terms are finished (nz*nc <= 288 doubles: <= 2 per thread)
+        s_ct[i] = state_cost_diag<DS>(A.cost, mu + i * ds, var + i * ds, A.grad ? s_dl + i * nz : nullptr,
+                                      A.grad ? s_dl + i * nz + ds : nullptr);
+    // input-cost terms: one thread per step, on the waves that do not carry the state-cost workers
+    for (int j = tid - 64; j >= 0 && j < H; j += blockDim.x - 64)
+        s_ci[j] = input_cost_step(j, H, da, A.cost, A.U + (size_t)b * H * da, A.grad ? s_gU + j * da : nullptr);
+    // ALLJ: the Jacobians of ALL steps fit in LDS: fetch them in one round of independent loads while the cost terms are
+    // finished, then wave 0 runs the whole reverse sweep alone -- no workgroup barriers, no exposed global-load latency
+    // per step (small batches: 29 -> 16 us at H = 20).  Otherwise: one step per iteration, the Jacobian of the next
+    // step prefetched into registers (nz*nc <= 288 doubles: <= 2 per thread).
     const double* Jg = A.grad ? A.jac + ((size_t)b * H + (H - 1)) * nz * nc : nullptr;
-    double j0 = (Jg && tid < nz * nc) ? Jg[tid] : 0.0, j1 = (Jg && tid + 256 < nz * nc) ? Jg[tid + 256] : 0.0;
+    double j0 = 0.0, j1 = 0.0;
+    if (!ALLJ) {
+        j0 = (Jg && tid < nz * nc) ? Jg[tid] : 0.0;
+        j1 = (Jg && tid + 256 < nz * nc) ? Jg[tid + 256] : 0.0;
+    }
     __syncthreads();
     if (tid == 0) {
-        const double* U = A.U + (size_t)b * H * da;
         double total = 0.0;
         for (int i = 0; i <= H; ++i) total += s_ct[i];
-        total += input_cost(H, da, A.cost, U, A.grad ? s_gU : nullptr);
+        for (int j = 0; j < H; ++j) total += s_ci[j];
         A.out_cost[b] = total;
     }
     if (!A.grad) return;
     if (tid < nz) s_adj[0][tid] = s_dl[H * nz + tid];
     int cur = 0;
+    if (ALLJ) {
+        if (tid >= 64) return;                            // wave 0 carries on alone: LDS ops of one wave execute in order
+        for (int t = H; t >= 1; --t) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // s_adj[cur] / s_gU of the previous iteration are written
+            if (tid < nc) {
+                const double* Jt = s_J + (size_t)(t - 1) * nz * nc;
+                double sum = 0.0;
+                for (int r = 0; r < nz; ++r) sum = fma(Jt[r * nc + tid], s_adj[cur][r], sum);
+                if (tid < nz) s_adj[cur ^ 1][tid] = s_dl[(t - 1) * nz + tid] + sum;
+                else s_gU[(t - 1) * da + (tid - nz)] += sum;    // input-cost gradients were written before the barrier above
+            }
+            cur ^= 1;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int q = tid; q < H * da; q += 64) A.out_grad[(size_t)b * H * da + q] = s_gU[q];
+        return;
+    }
     for (int t = H; t >= 1; --t) {
         if (tid < nz * nc) s_J[tid] = j0;
         if (tid + 256 < nz * nc) s_J[tid + 256] = j1;
@@ -413,10 +561,10 @@ __global__ __launch_bounds__(256) void k_roll_tail(RollArgs A) {
             j1 = tid + 256 < nz * nc ? Jn[tid + 256] : 0.0;
         }
         if (tid < nc) {
-            double s = 0.0;
-            for (int r = 0; r < nz; ++r) s = fma(s_J[r * nc + tid], s_adj[cur][r], s);
-            if (tid < nz) s_adj[cur ^ 1][tid] = s_dl[(t - 1) * nz + tid] + s;
-            else s_gU[(t - 1) * da + (tid - nz)] += s;     // thread 0 finished input_cost before the first barrier above
+            double sum = 0.0;
+            for (int r = 0; r < nz; ++r) sum = fma(s_J[r * nc + tid], s_adj[cur][r], sum);
+            if (tid < nz) s_adj[cur ^ 1][tid] = s_dl[(t - 1) * nz + tid] + sum;
+            else s_gU[(t - 1) * da + (tid - nz)] += sum;   // input-cost gradients were written before the first barrier above
         }
         __syncthreads();
         cur ^= 1;
@@ -635,10 +783,22 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
         if (rc != GPMPC_OK) return rc;
     }
     const size_t nzc = (size_t)2 * p->ds * (2 * p->ds + p->da);
-    const size_t lds = sizeof(double) * ((size_t)GPMPC_TAIL_WORKERS * p->ds * 2 * p->ds + (size_t)(H + 1) * (1 + 2 * p->ds) +
-                                         (size_t)H * p->da + nzc);
-    if (lds > 48 * 1024) return GPMPC_E_ARG;   // horizon too long for the tail kernel's LDS budget
-    hipLaunchKernelGGL(k_roll_tail, dim3(B), dim3(256), lds, s, A);
+    const size_t lds0 = sizeof(double) * ((size_t)(H + 1) * (1 + 2 * p->ds) + (size_t)H * p->da + (size_t)H);
+    const size_t lds_all = lds0 + sizeof(double) * nzc * (grad ? H : 1), lds_one = lds0 + sizeof(double) * nzc;
+    const bool allj = lds_all <= 48 * 1024;
+    if (!allj && lds_one > 48 * 1024) return GPMPC_E_ARG;   // horizon too long for the tail kernel's LDS budget
+    const size_t lds = allj ? lds_all : lds_one;
+#define GPMPC_TAIL_CASE(DSV)                                                                             \
+    case DSV:                                                                                            \
+        if (allj) hipLaunchKernelGGL((k_roll_tail<true, DSV>), dim3(B), dim3(256), lds, s, A);           \
+        else hipLaunchKernelGGL((k_roll_tail<false, DSV>), dim3(B), dim3(256), lds, s, A);               \
+        break;
+    switch (p->ds) {
+        GPMPC_TAIL_CASE(1) GPMPC_TAIL_CASE(2) GPMPC_TAIL_CASE(3) GPMPC_TAIL_CASE(4)
+        GPMPC_TAIL_CASE(5) GPMPC_TAIL_CASE(6) GPMPC_TAIL_CASE(7) GPMPC_TAIL_CASE(8)
+        default: return GPMPC_E_ARG;
+    }
+#undef GPMPC_TAIL_CASE
     GPMPC_HIP(hipGetLastError());
     return GPMPC_OK;
 }
