@@ -79,6 +79,7 @@ struct PairSbArgs {
     const int* work;      // [nwork][4] = {unit, i0, j0, j1}
     int Np, B, ds, nwork, pps, nm;
     int rgroup;           // work items interleaved per trajectory in dispatch order (1 = item-major), see pair_kernel_sb.h
+    int first_step;       // horizon step 1: derivatives w.r.t. the (constant) state inputs are not needed
 };
 static inline int gpmpc_sb_gw(int D, int ns2) { return (D + 1 + ns2 + 1) & ~1; }
 int gpmpc_launch_pair_sb(int D, bool grad, int tb, int ns2, int waves, const PairSbArgs& a, hipStream_t s);

@@ -27,7 +27,9 @@ struct PairSbTraits {
 };
 
 // GRAD = false: objective only (Z0), NM = 1.  (A two-rows-per-lane shape was measured 15 % slower: occupancy wins.)
-template <int D, int TB, int NS2, bool GRAD>
+// FIRST: horizon step 1, whose state inputs (x0, Sigma_0) are constants: only the derivatives w.r.t. the action dimensions
+// (k >= NS2) are needed, so the w and the state-dimension v accumulations are dropped (8 of 30 VALU instructions at D = 5).
+template <int D, int TB, int NS2, bool GRAD, bool FIRST = false>
 __global__ __launch_bounds__(256) void gpmpc_pair_kernel_sb(PairSbArgs A) {
     constexpr int GW = PairSbTraits<D, NS2>::GW;
     constexpr int NM = GRAD ? 1 + 2 * D : 1, NA = GRAD ? 1 + D + NS2 : 1;
@@ -126,9 +128,9 @@ __global__ __launch_bounds__(256) void gpmpc_pair_kernel_sb(PairSbArgs A) {
                         acc[tb][r][0] += P;
                         if (GRAD) {
 #pragma unroll
-                            for (int k = 0; k < D; ++k) acc[tb][r][1 + k] = fma(P, g[k], acc[tb][r][1 + k]);
+                            for (int k = 0; k < D; ++k) if (!FIRST || k >= NS2) acc[tb][r][1 + k] = fma(P, g[k], acc[tb][r][1 + k]);
 #pragma unroll
-                            for (int k = 0; k < NS2; ++k) acc[tb][r][1 + D + k] = fma(P, g[D + 1 + k], acc[tb][r][1 + D + k]);
+                            for (int k = 0; k < NS2; ++k) if (!FIRST) acc[tb][r][1 + D + k] = fma(P, g[D + 1 + k], acc[tb][r][1 + D + k]);
                         }
                     }
                 }
@@ -150,8 +152,8 @@ __global__ __launch_bounds__(256) void gpmpc_pair_kernel_sb(PairSbArgs A) {
 #pragma unroll
                 for (int k = 0; k < D; ++k) {
                     const double h = (0.5 / GPMPC_EXP_NEG_INV_C) * hi2[tb][r][k], v = acc[tb][r][GRAD ? 1 + k : 0];
-                    z[GRAD ? 1 + k : 0] += fma(h, rs, v);
-                    if (k < NS2) z[GRAD ? 1 + D + k : 0] += fma(h * h, rs, fma(2.0 * h, v, acc[tb][r][GRAD ? 1 + D + (k < NS2 ? k : 0) : 0]));
+                    if (!FIRST || k >= NS2) z[GRAD ? 1 + k : 0] += fma(h, rs, v);
+                    if (k < NS2 && !FIRST) z[GRAD ? 1 + D + k : 0] += fma(h * h, rs, fma(2.0 * h, v, acc[tb][r][GRAD ? 1 + D + (k < NS2 ? k : 0) : 0]));
                 }
             }
         }
@@ -176,10 +178,10 @@ __global__ __launch_bounds__(256) void gpmpc_pair_kernel_sb(PairSbArgs A) {
 // `rows` = rows per tile of the work list (64 or 256) = threads per workgroup.
 // TB = 1 (59 VGPRs, 8 waves/SIMD at D = 5) is the fastest shape on MI355X: occupancy hides the scalar-load and
 // table-read latencies (C3: 2.20 ms per launch; TB 2: 2.41 with the 10-slot exp; two rows per lane: 2.65; staged pair_kernel.h TB 2: 2.82).
-template <int D, int TB, int NS2, bool GRAD>
+template <int D, int TB, int NS2, bool GRAD, bool FIRST = false>
 static int launch_pair_sb_one(int rows, const PairSbArgs& a, hipStream_t s) {
     dim3 grid(((a.B + TB - 1) / TB) * a.nwork), block(rows);
-    hipLaunchKernelGGL((gpmpc_pair_kernel_sb<D, TB, NS2, GRAD>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((gpmpc_pair_kernel_sb<D, TB, NS2, GRAD, FIRST>), grid, block, 0, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { gpmpc_set_error("pair kernel (scalar broadcast) launch", e); return GPMPC_E_LAUNCH; }
     return GPMPC_OK;
@@ -190,6 +192,12 @@ template <int D>
 int gpmpc_launch_pair_sb_D(bool grad, int tb, int ns2, int waves, const PairSbArgs& a, hipStream_t s) {
     const int rows = 64 * waves;
     if (a.nm != (grad ? 1 + 2 * D : 1)) return GPMPC_E_ARG;
+    if (a.first_step && grad && tb == 1) {
+        if (ns2 == D) return launch_pair_sb_one<D, 1, D, true, true>(rows, a, s);
+        if (D >= 2 && ns2 == D - 1) return launch_pair_sb_one<D, 1, (D >= 2 ? D - 1 : D), true, true>(rows, a, s);
+        if (D >= 3 && ns2 == D - 2) return launch_pair_sb_one<D, 1, (D >= 3 ? D - 2 : D), true, true>(rows, a, s);
+        return GPMPC_E_ARG;
+    }
 #define GPMPC_SB_CASE(TBV, GR)                                                                             \
     if (tb == TBV && grad == GR) {                                                                         \
         if (ns2 == D) return launch_pair_sb_one<D, TBV, D, GR>(rows, a, s);                                \
