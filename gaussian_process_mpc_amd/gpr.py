@@ -31,6 +31,7 @@ class GaussianProcessRegression(object):
         self.version = 0            # bumped whenever Ky_inv changes (Dynamics uses it to refresh its pack)
         self._beta = None
         self._adam = None           # (optimizer, host parameters) of update_hyperparams, created on first use
+        self._hcache = {}           # host copies of the log-hypers, keyed on tensor identity and version
 
     # -- hyper-parameters: same expressions as the reference setters (src/gpr.py:51-88), including the
     #    dtype inference of torch.tensor (a Python float / list is float32 before the log).  Like the
@@ -41,23 +42,34 @@ class GaussianProcessRegression(object):
         self._adam = None           # the optimiser state belongs to the parameters it was created on
         return torch.log(torch.tensor(value)).type(torch.float64).to(self.device).requires_grad_()
 
+    def _host(self, name):
+        """Host copy of a log-hyper tensor, refreshed when the attribute is replaced or modified in place (the getters
+        run on every solver callback through Dynamics.pack(); a device-to-host copy each time costs more than the
+        rollout itself for small problems)."""
+        t = getattr(self, name)
+        c = self._hcache.get(name)
+        if c is None or c[0] is not t or c[1] != t._version:     # the cache keeps t alive, so `is` cannot alias a new tensor
+            c = (t, t._version, t.detach().cpu())
+            self._hcache[name] = c
+        return c[2]
+
     def set_lambdas(self, lambdas):
         self.log_lambdas = self._log_param(lambdas)
 
     def get_lambdas(self):
-        return torch.exp(self.log_lambdas.detach().cpu()).numpy()
+        return torch.exp(self._host("log_lambdas")).numpy()
 
     def set_sigma_f(self, sigma_f):
         self.log_sigma_f = self._log_param(sigma_f)
 
     def get_sigma_f(self):
-        return torch.exp(self.log_sigma_f.detach().cpu()).item()
+        return torch.exp(self._host("log_sigma_f")).item()
 
     def set_sigma_n(self, sigma_n):
         self.log_sigma_n = self._log_param(sigma_n)
 
     def get_sigma_n(self):
-        return torch.exp(self.log_sigma_n.detach().cpu()).item()
+        return torch.exp(self._host("log_sigma_n")).item()
 
     # -- data
     def append_train_data(self, x, y, incremental=False):
@@ -91,7 +103,7 @@ class GaussianProcessRegression(object):
         n = self.num_train
         X_old = self.X_train[:n].contiguous()
         sigma_f = self.get_sigma_f()
-        noise = float((torch.exp(self.log_sigma_n.detach().cpu()) ** 2 * torch.ones(1)).item())
+        noise = float((torch.exp(self._host("log_sigma_n")) ** 2 * torch.ones(1)).item())
         _, lp = host_doubles(self.get_lambdas())
         k = torch.empty((1, n), dtype=torch.float64, device=self.device)
         xn = x_new.reshape(1, self.x_dim).contiguous()
@@ -120,7 +132,7 @@ class GaussianProcessRegression(object):
         lam, lp = host_doubles(self.get_lambdas())
         sigma_f = self.get_sigma_f()
         # src/gpr.py:170: sigma_n**2 (0-dim float64) * torch.eye (float32) is a float32 tensor
-        noise = float((torch.exp(self.log_sigma_n.detach().cpu()) ** 2 * torch.ones(1)).item())
+        noise = float((torch.exp(self._host("log_sigma_n")) ** 2 * torch.ones(1)).item())
         self.Kf = torch.empty((n, n), dtype=torch.float64, device=self.device)
         self.Ky = torch.empty((n, n), dtype=torch.float64, device=self.device)
         with torch.cuda.device(self.device):
@@ -189,7 +201,7 @@ class GaussianProcessRegression(object):
     # -- hyper-parameter training (src/gpr.py:173-251, 334-370)
     def _noise_var(self):
         # src/gpr.py:170: the noise variance on the diagonal of Ky is float32(sigma_n^2)
-        return float((torch.exp(self.log_sigma_n.detach().cpu()) ** 2 * torch.ones(1)).item())
+        return float((torch.exp(self._host("log_sigma_n")) ** 2 * torch.ones(1)).item())
 
     def _ml_terms(self):
         """One device pass (C ABI ``gpmpc_ml_grad``): [d ml/d log lambda (D), d/d log sigma_f, d/d log sigma_n, r^T alpha]."""

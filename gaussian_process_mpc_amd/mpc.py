@@ -80,10 +80,19 @@ class RiskSensitiveMPC:
     def _cost_params(self, x_ref=None, u_ref=None):
         xr = self.x_ref if x_ref is None else x_ref
         ur = self.u_ref if u_ref is None else u_ref
-        to_np = lambda t: t.detach().cpu().numpy().astype(np.float64) if isinstance(t, torch.Tensor) else np.asarray(t, dtype=np.float64)  # noqa: E731
         last_u = np.asarray(self.last_traj, dtype=np.float64)[0:self.input_dim] if self.R_delta is not None else None
-        return CostParams(self.gamma, self.Q, self.R, R_delta=self.R_delta, x_ref=to_np(xr), u_ref=to_np(ur),
-                          last_u=last_u)
+        # rebuilt only when one of its inputs changes: the solver calls this once per callback and the device-to-host
+        # copies of x_ref / u_ref alone cost as much as a small rollout
+        objs = (self.Q, self.R, self.R_delta, xr, ur)             # kept alive by the cache: `is` cannot alias new objects
+        vers = tuple(t._version if isinstance(t, torch.Tensor) else None for t in objs)
+        key = (self.gamma, vers, None if last_u is None else last_u.tobytes())
+        old = getattr(self, "_cp_state", None)
+        if old is None or old[0] != key or any(a is not b for a, b in zip(old[1], objs)):
+            to_np = lambda t: t.detach().cpu().numpy().astype(np.float64) if isinstance(t, torch.Tensor) else np.asarray(t, dtype=np.float64)  # noqa: E731
+            self._cp = CostParams(self.gamma, self.Q, self.R, R_delta=self.R_delta, x_ref=to_np(xr), u_ref=to_np(ur),
+                                  last_u=last_u)
+            self._cp_state = (key, objs)
+        return self._cp
 
     def cost(self, x, u, sig, x_ref, u_ref):
         """numpy risk-sensitive cost, no input-rate term (src/mpc.py:118-154); host arithmetic in the
@@ -114,20 +123,26 @@ class RiskSensitiveMPC:
     # -- cyipopt problem object (src/mpc.py:202-267)
     def _evaluate(self, x):
         x = np.array(x, dtype=np.float64, copy=True).reshape(-1)
-        key = (x.tobytes(), None if self.curr_state is None else self.curr_state.detach().cpu().numpy().tobytes())
-        if key != self._cache_key:
+        cs, pack, cp = self.curr_state, self.dynamics.pack(), self._cost_params()
+        key = (x.tobytes(), None if cs is None else cs._version)
+        held = getattr(self, "_cache_held", (None, None, None))    # kept alive so that `is` cannot alias later objects
+        if key != self._cache_key or cs is not held[0] or pack is not held[1] or cp is not held[2]:
             if self.full_covariance:
-                r = rollout_fullcov(self.dynamics.pack(), self.curr_state, x.reshape(self.horizon, self.input_dim),
-                                    self._cost_params(), want_grad=True)
+                r = rollout_fullcov(pack, cs, x.reshape(self.horizon, self.input_dim), cp, want_grad=True)
+                self.curr_cost = float(r["cost"][0].item())
+                self.curr_grad = r["grad"][0].cpu().numpy()
             else:
-                # B = 1 is launch-latency bound: replay the 2H+1 launches as one hipGraph
-                r = rollout(self.dynamics.pack(), self.curr_state, x.reshape(self.horizon, self.input_dim),
-                            self._cost_params(), want_grad=True, want_traj=False, graph=True)
-            self.curr_cost = float(r["cost"][0].item())
-            self.curr_grad = r["grad"][0].cpu().numpy()
+                # B = 1 is launch-latency bound: replay the 2H+1 launches as one hipGraph; cost and gradient come back
+                # in one device-to-host copy
+                r = rollout(pack, cs, x.reshape(self.horizon, self.input_dim), cp, want_grad=True, want_traj=False,
+                            graph=True)
+                cg = r["cost_grad"].cpu().numpy()
+                self.curr_cost = float(cg[0])
+                self.curr_grad = cg[1:].reshape(self.horizon, self.input_dim).copy()
             self.curr_u = x.reshape(self.horizon, self.input_dim)
             self.backward_taken = True
             self._cache_key = key
+            self._cache_held = (cs, pack, cp)
         return self.curr_cost, self.curr_grad
 
     def objective(self, x):

@@ -133,10 +133,17 @@ def rollout(pack, x0, U, cost, want_grad=True, want_traj=True, graph=False):
     B = 1 callbacks of a solver loop): inputs are copied into buffers owned by the pack and the returned tensors are
     views of buffers that the NEXT graph call with the same shape overwrites."""
     dev = pack.device
-    U = _dev(U, dev)
-    if U.dim() == 2:
-        U = U.unsqueeze(0)
-    B, H, da = U.shape
+    U_host = None
+    if graph and not isinstance(U, torch.Tensor):          # solver callbacks hand numpy: stage through pinned memory
+        U_host = np.ascontiguousarray(np.asarray(U, dtype=np.float64))
+        if U_host.ndim == 2:
+            U_host = U_host[None]
+        B, H, da = U_host.shape
+    else:
+        U = _dev(U, dev)
+        if U.dim() == 2:
+            U = U.unsqueeze(0)
+        B, H, da = U.shape
     x0 = _dev(x0, dev).reshape(-1, pack.ds)
     if x0.shape[0] == 1 and B > 1:
         x0 = x0.expand(B, pack.ds).contiguous()
@@ -149,17 +156,27 @@ def rollout(pack, x0, U, cost, want_grad=True, want_traj=True, graph=False):
         key = (B, H, bool(want_grad), bool(want_traj))
         buf = pack._graph_bufs.get(key)
         if buf is None:
-            buf = {"x0": e(B, pack.ds), "U": e(B, H, da), "cost": e(B),
+            # cost and grad are views of ONE block so that a caller can fetch both with a single device-to-host copy
+            cg = e(B * (1 + (H * da if want_grad else 0)))
+            buf = {"x0": e(B, pack.ds), "U": e(B, H, da), "cost_grad": cg, "cost": cg[:B],
+                   "U_pinned": torch.empty((B, H, da), dtype=torch.float64).pin_memory(),
                    "ws": torch.empty(int(nbytes), dtype=torch.uint8, device=dev)}
             if want_grad:
-                buf["grad"] = e(B, H, da)
+                buf["grad"] = cg[B:].view(B, H, da)
             if want_traj:
                 buf["means"], buf["vars"] = e(B, H + 1, pack.ds), e(B, H + 1, pack.ds)
             pack._graph_bufs = {key: buf}                    # one captured shape at a time
         buf["x0"].copy_(x0)
-        buf["U"].copy_(U)
+        if U_host is not None:
+            # the previous copy out of the pinned buffer has completed: every graph call is followed by a synchronising
+            # read of its results before the next one can be issued from the same host thread
+            torch.cuda.current_stream(dev).synchronize()
+            buf["U_pinned"].numpy()[...] = U_host
+            buf["U"].copy_(buf["U_pinned"], non_blocking=True)
+        else:
+            buf["U"].copy_(U)
         x0, U, ws = buf["x0"], buf["U"], buf["ws"]
-        out = {k: buf[k] for k in ("cost", "grad", "means", "vars") if k in buf}
+        out = {k: buf[k] for k in ("cost", "grad", "means", "vars", "cost_grad") if k in buf}
     else:
         out = {"cost": e(B)}
         if want_grad:

@@ -145,6 +145,24 @@ def test_objective_cache_semantics(G, golden):
     assert not np.allclose(g0, g1)
     x_alias[0] -= 0.25
     assert mpc.objective(x_alias) == c0
+    # the caches behind the callbacks follow every input that the reference reads at call time
+    g_keep = mpc.gradient(x_alias).copy()
+    mpc.curr_state = torch.tensor(z["x0"][0] + 0.1).to(mpc.device)       # attribute replaced
+    c2 = mpc.objective(x_alias)
+    assert c2 != c0
+    mpc.curr_state.add_(-0.1)                                              # modified in place
+    assert mpc.objective(x_alias) == pytest.approx(c0, rel=1e-12)
+    np.testing.assert_allclose(mpc.gradient(x_alias), g_keep, rtol=1e-10)
+    mpc.set_xref(np.full(mpc.state_dim, 0.3))                               # cost parameters
+    c3 = mpc.objective(x_alias)
+    assert c3 != pytest.approx(c0, rel=1e-6)
+    mpc.x_ref = torch.zeros(mpc.state_dim, device=mpc.device)             # direct attribute assignment, as the reference's tests do
+    assert mpc.objective(x_alias) == pytest.approx(c0, rel=1e-12)
+    lam_old = mpc.dynamics.gpr_err[0].get_lambdas().copy()
+    mpc.dynamics.gpr_err[0].set_lambdas(lam_old * 1.5)                     # hyper-parameter change -> new pack
+    for gp in mpc.dynamics.gpr_err:
+        gp.build_Ky_inv_mat()
+    assert mpc.objective(x_alias) != pytest.approx(c0, rel=1e-6)
 
 
 def test_cost_methods_known_answers(G, golden):
