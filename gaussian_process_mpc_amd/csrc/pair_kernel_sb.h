@@ -21,6 +21,13 @@
 #include "fast_exp.h"
 #include <cstdlib>
 
+// Columns per iteration of the column loop.  ONE is fastest: the plain load / wait / evaluate loop (43 instructions,
+// 45 VGPRs at D = 5) beat the 2- and 4-column unrollings by 0.9 % / 1.7 % on C3 and 1.5 % / 6 % on C4 -- with 8
+// waves/SIMD the other waves cover the exposed latencies, and the short body is kinder to instruction fetch.
+#ifndef GPMPC_SB_CU
+#define GPMPC_SB_CU(gw) 1
+#endif
+
 template <int D, int NS2>
 struct PairSbTraits {
     static constexpr int GW = (D + 1 + NS2 + 1) & ~1;     // doubles per G row (even: rows stay 16-byte aligned)
@@ -102,25 +109,26 @@ __global__ __launch_bounds__(256) void gpmpc_pair_kernel_sb(PairSbArgs A) {
         for (int r = 0; r < RI; ++r)
             Mrs[r] = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Ma + (size_t)jstart * Np + iw0 + 64 * r), 0, 0x7fffffff, 0x00020000);
         const int lane8 = lane * 8;
-        for (int jc = jstart; jc < j1; jc += 4) {
-            double mij[RI][4];
+        constexpr int CU = GPMPC_SB_CU(GW);      // columns per loop iteration
+        for (int jc = jstart; jc < j1; jc += CU) {
+            double mij[RI][CU];
 #pragma unroll
             for (int r = 0; r < RI; ++r)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < CU; ++q) {
                     // buffer load: the column offset rides in the scalar offset, the lane offset is loop invariant,
                     // so the M_ij stream costs no VALU address arithmetic
                     const auto raw = __builtin_amdgcn_raw_buffer_load_b64(Mrs[r], lane8, (jc - jstart + q) * Np * 8, 0);
                     mij[r][q] = __builtin_bit_cast(double, raw);
                 }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < CU; ++q) {
 #pragma unroll
                 for (int tb = 0; tb < TB; ++tb) {
                     const double* __restrict__ g = Gt[tb] + (size_t)(jc + q) * GW;     // wave-uniform address -> SGPRs
 #pragma unroll
                     for (int r = 0; r < RI; ++r) {
-                        if (r > 0 && jc + 3 < iw0 + 64 * r) continue;                  // row block r is still below the diagonal
+                        if (r > 0 && jc + CU - 1 < iw0 + 64 * r) continue;                  // row block r is still below the diagonal
                         double s = qi[tb][r] + g[D];
 #pragma unroll
                         for (int k = 0; k < D; ++k) s = fma(hi2[tb][r][k], g[k], s);
@@ -192,12 +200,16 @@ template <int D>
 int gpmpc_launch_pair_sb_D(bool grad, int tb, int ns2, int waves, const PairSbArgs& a, hipStream_t s) {
     const int rows = 64 * waves;
     if (a.nm != (grad ? 1 + 2 * D : 1)) return GPMPC_E_ARG;
-    if (a.first_step && grad && tb == 1) {
-        if (ns2 == D) return launch_pair_sb_one<D, 1, D, true, true>(rows, a, s);
-        if (D >= 2 && ns2 == D - 1) return launch_pair_sb_one<D, 1, (D >= 2 ? D - 1 : D), true, true>(rows, a, s);
-        if (D >= 3 && ns2 == D - 2) return launch_pair_sb_one<D, 1, (D >= 3 ? D - 2 : D), true, true>(rows, a, s);
-        return GPMPC_E_ARG;
+#define GPMPC_SB_FIRST(TBV)                                                                                      \
+    if (a.first_step && grad && tb == TBV) {                                                                     \
+        if (ns2 == D) return launch_pair_sb_one<D, TBV, D, true, true>(rows, a, s);                              \
+        if (D >= 2 && ns2 == D - 1) return launch_pair_sb_one<D, TBV, (D >= 2 ? D - 1 : D), true, true>(rows, a, s);  \
+        if (D >= 3 && ns2 == D - 2) return launch_pair_sb_one<D, TBV, (D >= 3 ? D - 2 : D), true, true>(rows, a, s);  \
+        return GPMPC_E_ARG;                                                                                      \
     }
+    GPMPC_SB_FIRST(1)
+    GPMPC_SB_FIRST(2)
+#undef GPMPC_SB_FIRST
 #define GPMPC_SB_CASE(TBV, GR)                                                                             \
     if (tb == TBV && grad == GR) {                                                                         \
         if (ns2 == D) return launch_pair_sb_one<D, TBV, D, GR>(rows, a, s);                                \

@@ -688,7 +688,9 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
         r->tiling = r->sb ? (big ? 0 : 2) : (big ? 0 : (many ? 3 : 1));
     }
     if (const char* ev = getenv("GPMPC_TILING")) { const int v = atoi(ev); if (v == 0 || ((v == 1 || v == 3) && !r->sb) || (v == 2 && r->sb)) r->tiling = v; }
-    r->tb = r->sb ? 1 : (B >= 2 ? 2 : 1);
+    // scalar-broadcast kernel: two trajectories per wave on the big tiling up to D = 5 (two independent dependency chains per
+    // lane, one M_ij load for both: C3 +2.6 %, objective-only +14 %; 82 VGPRs); D = 7 (C4) is 2.5 % faster with one
+    r->tb = r->sb ? ((big && D <= 5 && B >= 2) ? 2 : 1) : (B >= 2 ? 2 : 1);
     if (const char* ev = getenv("GPMPC_PAIR_TB")) { const int v = atoi(ev); if (v == 1 || v == 2 || (v == 4 && !r->sb)) r->tb = v; }
     if (!diag && grad && r->tb > 2) r->tb = 2;
     // Dispatch interleave of the scalar-broadcast kernel (pair_kernel_sb.h): 4 row tiles per trajectory share each fetch
