@@ -68,25 +68,19 @@ __global__ __launch_bounds__(256) void gpmpc_pair_kernel_sbf(PairSbfArgs A) {
         const __amdgpu_buffer_rsrc_t Mrs =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Ma + (size_t)jstart * Np + iw0), 0, 0x7fffffff, 0x00020000);
         const int lane8 = lane * 8;
-        for (int jc = jstart; jc < j1; jc += 4) {
-            double mij[4];
+        for (int jc = jstart; jc < j1; ++jc) {           // one column per iteration: see GPMPC_SB_CU in pair_kernel_sb.h
+            const double mij = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, (jc - jstart) * Np * 8, 0));
+            const double* __restrict__ g = G + (size_t)jc * GW;              // wave-uniform address -> SGPRs
+            double s = qi + g[D];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)      // buffer load with the column offset as scalar offset (see pair_kernel_sb.h)
-                mij[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, (jc - jstart + q) * Np * 8, 0));
+            for (int k = 0; k < D; ++k) s = fma(p2[k], g[k], s);
+            const double P = mij * gpmpc_exp_neg_scaled(s, s_tab);
+            acc[0] += P;
+            if (GRAD) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const double* __restrict__ g = G + (size_t)(jc + q) * GW;              // wave-uniform address -> SGPRs
-                double s = qi + g[D];
+                for (int k = 0; k < D; ++k) acc[1 + k] = fma(P, g[k], acc[1 + k]);
 #pragma unroll
-                for (int k = 0; k < D; ++k) s = fma(p2[k], g[k], s);
-                const double P = mij[q] * gpmpc_exp_neg_scaled(s, s_tab);
-                acc[0] += P;
-                if (GRAD) {
-#pragma unroll
-                    for (int k = 0; k < D; ++k) acc[1 + k] = fma(P, g[k], acc[1 + k]);
-#pragma unroll
-                    for (int k = 0; k < NW; ++k) acc[1 + D + k] = fma(P, g[D + 1 + k], acc[1 + D + k]);
-                }
+                for (int k = 0; k < NW; ++k) acc[1 + D + k] = fma(P, g[D + 1 + k], acc[1 + D + k]);
             }
         }
     }
