@@ -37,7 +37,7 @@ struct PairSbTraits {
 // FIRST: horizon step 1, whose state inputs (x0, Sigma_0) are constants: only the derivatives w.r.t. the action dimensions
 // (k >= NS2) are needed, so the w and the state-dimension v accumulations are dropped (8 of 30 VALU instructions at D = 5).
 template <int D, int TB, int NS2, bool GRAD, bool FIRST = false>
-__global__ __launch_bounds__(256) void gpmpc_pair_kernel_sb(PairSbArgs A) {
+__global__ __launch_bounds__(256, (TB == 2 && D <= 5) ? 6 : 1) void gpmpc_pair_kernel_sb(PairSbArgs A) {
     constexpr int GW = PairSbTraits<D, NS2>::GW;
     constexpr int NM = GRAD ? 1 + 2 * D : 1, NA = GRAD ? 1 + D + NS2 : 1;
     __shared__ double s_red[4 * TB * NM];
