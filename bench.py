@@ -214,9 +214,9 @@ def main():
                 # gfx950 correction for wide reads; an upper bound here, the scalar-cache line fills are uncalibrated, and
                 # Infinity-Cache hits are included): profiles/r01/pmc_c3_final.txt.  Only measured for the default C3
                 # workload.  Algorithmic: 67 MB of M + 168 MB of column rows; the dispatch order lets 4 row tiles share
-                # each fetch of a trajectory's rows and re-reads each M tile 4x (pair_kernel_sb.h) -- 0.4 TB/s, far
+                # each fetch of a trajectory's rows and re-reads each M tile 4x (pair_kernel_sb.h) -- 0.5 TB/s, far
                 # from binding.
-                "traffic": 8.6e8 if (args.config == "C3" and B == 256 and want_grad and not fullcov) else None,
+                "traffic": 1.14e9 if (args.config == "C3" and B == 256 and want_grad and not fullcov) else None,
                 "traffic_source": "profiles/r01/pmc_c3_final.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, x2 read correction)",
                 "algorithmic_flops_per_pair": fl, "algorithmic_slots_per_pair": slots,
                 "valu_slot_frac": pairs_per_launch * slots / launch_s / 39.3e12,
