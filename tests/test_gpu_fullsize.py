@@ -90,6 +90,28 @@ def test_c3_full_horizon_properties(G, c3):
     assert abs((cp - cm) / (2 * eps) - g0) < 2e-4 * max(1.0, abs(g0)), ((cp - cm) / (2 * eps), g0)
 
 
+def test_c3_big_tiling_odd_batch(G, c3):
+    """The large-batch shape (256x256 tiles, two trajectories per wave) with an odd batch: the padded partner of the
+    last trajectory must not leak, every trajectory is independent of its partner, and the shape agrees with the
+    small-batch kernels on the same trajectories."""
+    from gaussian_process_mpc_amd.synth import synth_problem
+    pb, gp, pack = c3
+    big = synth_problem(3, pb["N"], pb["ds"], pb["da"], pb["H"], 25)
+    cost = G.CostParams(-1.0, pb["Q"], pb["R"])
+    r25 = G.rollout(pack, big["x0"], big["U"], cost)
+    r24 = G.rollout(pack, big["x0"][:24], big["U"][:24], cost)
+    assert all(torch.isfinite(v).all() for v in r25.values())
+    for k in r24:
+        assert torch.equal(r25[k][:24], r24[k]), k                     # partner-independent, bit for bit
+    r8 = G.rollout(pack, big["x0"][17:25], big["U"][17:25], cost)         # 256x64 tiles, one trajectory per wave
+    # different tilings sum the cancelling N^2 terms in different orders: ~1e-6 of noise in the variances, which the
+    # next steps' means inherit at ~1e-8
+    np.testing.assert_allclose(r8["means"].cpu().numpy(), r25["means"][17:25].cpu().numpy(), rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(r8["vars"].cpu().numpy(), r25["vars"][17:25].cpu().numpy(), rtol=1e-5)
+    np.testing.assert_allclose(r8["cost"].cpu().numpy(), r25["cost"][17:25].cpu().numpy(), rtol=1e-8)
+    np.testing.assert_allclose(r8["grad"].cpu().numpy(), r25["grad"][17:25].cpu().numpy(), rtol=1e-4, atol=1e-8)
+
+
 def test_c3_training_set_permutation_invariance(G, c3):
     """The result is a sum over pairs: re-ordering the training points only re-orders the tiles."""
     pb, gp, pack = c3
