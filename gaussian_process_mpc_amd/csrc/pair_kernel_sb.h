@@ -24,6 +24,9 @@
 // Columns per iteration of the column loop.  ONE is fastest: the plain load / wait / evaluate loop (43 instructions,
 // 45 VGPRs at D = 5) beat the 2- and 4-column unrollings by 0.9 % / 1.7 % on C3 and 1.5 % / 6 % on C4 -- with 8
 // waves/SIMD the other waves cover the exposed latencies, and the short body is kinder to instruction fetch.
+// NOTE: the loop nest below keeps its generic form (RI row chunks, CU columns per iteration, both 1) on purpose.  A
+// hand-simplified body with the same arithmetic made the compiler rotate the loop (M_ij fetched one iteration ahead, the
+// two exp-table reads serialised) and ran 2.5 % slower on C3: check the ISA and A/B on one box before touching it.
 #ifndef GPMPC_SB_CU
 #define GPMPC_SB_CU(gw) 1
 #endif
