@@ -189,6 +189,34 @@ def test_rollout_vs_oracle_seeded(G, N, ds, da, H, B):
             np.testing.assert_allclose(r["grad"][b].cpu().numpy(), o["grad"], rtol=1e-4, atol=1e-7)
 
 
+@pytest.mark.parametrize("N,ds,da,H", [(200, 3, 1, 3), (300, 4, 1, 2), (130, 2, 2, 3)])
+def test_large_batch_shape_vs_oracle(G, N, ds, da, H):
+    """The large-batch shape of the rollout (256x256 tiles, scalar-broadcast kernel, two trajectories per wave, the
+    horizon-step-1 variant) is selected by the amount of work: drive it with a thousand-plus trajectories of a small
+    problem and hold a handful of them to the CPU oracle (values and gradient)."""
+    from oracle import gpmpc_oracle as O
+    from gaussian_process_mpc_amd.synth import synth_problem
+    tiles = {1: 1, 2: 3}[(N + 255) // 256]
+    B = 3072 // (tiles * ds) + 77         # B * (tiles * ds) >= 3072 work items selects the shape; odd batch on purpose
+    B += 1 - B % 2
+    pb = synth_problem(11, N, ds, da, H, B)
+    gp = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"])
+    pack = G.GPPack(pb["X"], pb["Y"], gp.Ky_inv.numpy(), pb["lambdas"], pb["sigma_f"])
+    r = G.rollout(pack, pb["x0"], pb["U"], G.CostParams(-1.0, pb["Q"], pb["R"]))
+    assert all(torch.isfinite(v).all() for v in r.values())
+    for b in (0, 1, B // 2, B - 2, B - 1):
+        o = O.objective_and_gradient(gp, H, pb["x0"][b], pb["U"][b], pb["x_ref"], pb["u_ref"], pb["Q"], pb["R"], -1.0,
+                                     mode="o2")
+        np.testing.assert_allclose(r["means"][b].cpu().numpy(), o["means"], rtol=MEAN_RTOL, atol=1e-9)
+        np.testing.assert_allclose(r["vars"][b].cpu().numpy(), o["vars"], rtol=VAR_RTOL, atol=1e-12)
+        np.testing.assert_allclose(r["cost"][b].item(), o["cost"], rtol=1e-6)
+        np.testing.assert_allclose(r["grad"][b].cpu().numpy(), o["grad"], rtol=1e-4, atol=1e-7)
+    # the same trajectories through the small-batch kernels
+    r5 = G.rollout(pack, pb["x0"][:5], pb["U"][:5], G.CostParams(-1.0, pb["Q"], pb["R"]))
+    np.testing.assert_allclose(r5["cost"].cpu().numpy(), r["cost"][:5].cpu().numpy(), rtol=1e-8)
+    np.testing.assert_allclose(r5["grad"].cpu().numpy(), r["grad"][:5].cpu().numpy(), rtol=1e-5, atol=1e-9)
+
+
 def test_gradient_finite_difference(G):
     """Analytic adjoint against central differences of the HIP objective itself."""
     from oracle import gpmpc_oracle as O
