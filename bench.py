@@ -193,6 +193,10 @@ def main():
             fl, slots = 2 * D + 37, D + 22
         if fullcov and want_grad:          # full second moments: D(D+1)/2 instead of D accumulations per pair
             fl, slots = 4 * D + 37 + D * (D - 1), 2 * D + 23 + D * (D - 1) // 2
+        if want_grad and not fullcov:
+            # horizon step 1 has constant state inputs: its ds state-dimension P*V accumulations are not part of the
+            # algorithm (the kernel skips them); average the per-launch count over the H launches of a rollout
+            fl, slots = fl - 2.0 * ds / H, slots - 1.0 * ds / H
         launch_s = (ms.value / max(nl.value, 1)) * 1e-3 if nl.value else float('nan')
         achieved = pairs_per_launch * fl / launch_s / 1e12
         out = {
