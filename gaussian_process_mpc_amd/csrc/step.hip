@@ -694,9 +694,8 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     if (const char* ev = getenv("GPMPC_PAIR_TB")) { const int v = atoi(ev); if (v == 1 || v == 2 || (v == 4 && !r->sb)) r->tb = v; }
     if (!diag && grad && r->tb > 2) r->tb = 2;
     // Dispatch interleave of the scalar-broadcast kernel (pair_kernel_sb.h): 4 row tiles per trajectory share each fetch
-    // of the G rows (C3 fabric reads per launch 757 -> 418 MB by FETCH_SIZE, same speed) as long as the weight matrices
-    // stay resident in the 256 MB infinity cache; past that the extra M re-reads cost more than they save (C4: -2.5 %).
-    r->rgroup = ((size_t)p->ds * p->Np * p->Np * sizeof(double) <= ((size_t)192 << 20)) ? 4 : 1;
+    // of the G rows (C3 fabric reads per launch 757 -> 418 MB by FETCH_SIZE at the same speed; C4 +0.5 %).
+    r->rgroup = 4;
     if (const char* ev = getenv("GPMPC_RGROUP")) { const int v = atoi(ev); if (v >= 1 && v <= 16) r->rgroup = v; }
     if (r->tiling != 0) r->rgroup = 1;
     r->waves = p->wl[0][r->tiling].waves;
