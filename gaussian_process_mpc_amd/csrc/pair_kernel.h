@@ -137,12 +137,12 @@ __global__ __launch_bounds__(256) void gpmpc_pair_kernel(PairArgs A) {
         const double* __restrict__ Mc = Ma + (size_t)jc * Np + i;
         const int jb0 = A.colsplit ? w * 16 : 0, jb1 = A.colsplit ? w * 16 + 16 : 64;
 #pragma unroll 1
-        for (int jb = jb0; jb < jb1; jb += 8) {
-            double mij[8];
+        for (int jb = jb0; jb < jb1; jb += 4) {
+            double mij[4];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) mij[q] = Mc[(size_t)(jb + q) * Np];
+            for (int q = 0; q < 4; ++q) mij[q] = Mc[(size_t)(jb + q) * Np];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < 4; ++q) {
 #pragma unroll
                 for (int tb = 0; tb < TB; ++tb) {
                     const double* hj = &s_hj[(tb * 64 + jb + q) * DP];
