@@ -217,6 +217,26 @@ def test_large_batch_shape_vs_oracle(G, N, ds, da, H):
     np.testing.assert_allclose(r5["grad"].cpu().numpy(), r["grad"][:5].cpu().numpy(), rtol=1e-5, atol=1e-9)
 
 
+def test_long_horizon_uses_the_streaming_tail(G):
+    """H = 100 at ds = 4: the step Jacobians no longer fit in LDS together, so the tail kernel falls back to one
+    Jacobian per iteration (prefetched); hold it to the oracle like the short horizons."""
+    from oracle import gpmpc_oracle as O
+    from gaussian_process_mpc_amd.synth import synth_problem
+    N, ds, da, H, B = 40, 4, 1, 100, 2
+    pb = synth_problem(13, N, ds, da, H, B)
+    pb["U"] = 0.3 * pb["U"]                                   # keep the long rollout inside the data
+    gp = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"])
+    pack = G.GPPack(pb["X"], pb["Y"], gp.Ky_inv.numpy(), pb["lambdas"], pb["sigma_f"])
+    r = G.rollout(pack, pb["x0"], pb["U"], G.CostParams(1e-5, pb["Q"], pb["R"]))
+    for b in range(B):
+        o = O.objective_and_gradient(gp, H, pb["x0"][b], pb["U"][b], pb["x_ref"], pb["u_ref"], pb["Q"], pb["R"], 1e-5,
+                                     mode="o2")
+        np.testing.assert_allclose(r["means"][b].cpu().numpy(), o["means"], rtol=MEAN_RTOL, atol=1e-9)
+        np.testing.assert_allclose(r["vars"][b].cpu().numpy(), o["vars"], rtol=VAR_RTOL, atol=1e-12)
+        np.testing.assert_allclose(r["cost"][b].item(), o["cost"], rtol=1e-6)
+        np.testing.assert_allclose(r["grad"][b].cpu().numpy(), o["grad"], rtol=1e-4, atol=1e-7)
+
+
 def test_gradient_finite_difference(G):
     """Analytic adjoint against central differences of the HIP objective itself."""
     from oracle import gpmpc_oracle as O
