@@ -230,6 +230,16 @@ def main():
             },
             "pack_build_ms": pack_ms,
         }
+        if world == 1 and want_grad and not fullcov:
+            # objective-only rate beside the headline, outside the timed region
+            for _ in range(2):
+                g.rollout(pack, x0, U, cost, want_grad=False, want_traj=False)
+            torch.cuda.synchronize()
+            tf = time.perf_counter()
+            for _ in range(3):
+                g.rollout(pack, x0, U, cost, want_grad=False, want_traj=False)
+            torch.cuda.synchronize()
+            out["forward_only_rollouts_per_s"] = 3 * B / (time.perf_counter() - tf)
         if not args.no_cpu_baseline and world == 1:
             H_s = 2 if N >= 1024 else H
             # the GPU box exposes every host core but grants a 16-core share per GPU: more threads than
