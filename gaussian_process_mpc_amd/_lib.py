@@ -17,6 +17,8 @@ MAX_DS = 8
 WANT_GRAD = 1
 COV_BUG_COMPAT = 2
 USE_GRAPH = 4
+FP32_ACCUM = 8
+FP32_ALL = 16
 
 _ERR = {-1: "bad argument", -2: "device allocation failed", -3: "HIP call / kernel launch failed",
         -4: "workspace too small", -5: "pack not built"}

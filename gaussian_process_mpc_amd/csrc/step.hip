@@ -668,7 +668,7 @@ int gpmpc_timed_pair_sbf(int D, bool grad, int ns2, int waves, const PairSbfArgs
 
 struct RollPlan { int tiling, tb, waves, nwork, nm, pps, sps, sb, gw, rgroup; size_t off_G; size_t off_pp, off_sp, off_part, off_jac, off_means, off_vars, total; };
 
-static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag, RollPlan* r) {
+static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag, RollPlan* r, bool lowprec = false) {
     const int D = p->D;
     // Shapes, by how many workgroups they give (>= 1024 fills the 256 CUs four deep):
     //   256x256 tiles, scalar-broadcast kernel   large batches (C3: 2.2 ms per launch; staged kernel TB 2: 2.82)
@@ -698,6 +698,7 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     r->rgroup = 4;
     if (const char* ev = getenv("GPMPC_RGROUP")) { const int v = atoi(ev); if (v >= 1 && v <= 16) r->rgroup = v; }
     if (r->tiling != 0) r->rgroup = 1;
+    if (lowprec) { r->sb = 0; r->tiling = 0; r->tb = 1; }      // tolerance-sweep kernels: 256x256 work list, one trajectory per workgroup
     r->waves = p->wl[0][r->tiling].waves;
     r->nwork = p->wl[0][r->tiling].nwork;
     r->nm = gpmpc_num_moments(D, diag, grad);
@@ -719,7 +720,7 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
 extern "C" size_t gpmpc_rollout_workspace_bytes(const gpmpc_pack* p, int B, int H, unsigned flags) {
     if (!p || B < 1 || H < 1) return 0;
     RollPlan r;
-    plan_rollout(p, B, H, (flags & GPMPC_WANT_GRAD) != 0, true, &r);
+    plan_rollout(p, B, H, (flags & GPMPC_WANT_GRAD) != 0, true, &r, (flags & (GPMPC_FP32_ACCUM | GPMPC_FP32_ALL)) != 0);
     return r.total;
 }
 
@@ -735,8 +736,10 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
     if (!p->built) return GPMPC_E_STATE;
     const bool grad = (flags & GPMPC_WANT_GRAD) != 0;
     if (grad && !out_grad) return GPMPC_E_ARG;
+    const int lowprec = (flags & GPMPC_FP32_ALL) ? 2 : ((flags & GPMPC_FP32_ACCUM) ? 1 : 0);
+    if (lowprec && grad) return GPMPC_E_ARG;                   // the sweep modes are objective only
     RollPlan r;
-    plan_rollout(p, B, H, grad, true, &r);
+    plan_rollout(p, B, H, grad, true, &r, lowprec != 0);
     if (workspace_bytes < r.total) return GPMPC_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace;
@@ -773,7 +776,9 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
             default: return GPMPC_E_ARG;
         }
         int rc;
-        if (r.sb) {
+        if (lowprec) {
+            rc = gpmpc_launch_pair_lowprec(p->D, lowprec, P, s);
+        } else if (r.sb) {
             PairSbArgs Q;
             Q.M = p->M; Q.XT = p->XT; Q.pp = A.pp; Q.G = A.G; Q.part = A.part; Q.work = P.work;
             Q.Np = p->Np; Q.B = B; Q.ds = p->ds; Q.nwork = r.nwork; Q.pps = r.pps; Q.nm = r.nm; Q.rgroup = r.rgroup;

@@ -123,7 +123,7 @@ class GPPack:
         return out
 
 
-def rollout(pack, x0, U, cost, want_grad=True, want_traj=True, graph=False):
+def rollout(pack, x0, U, cost, want_grad=True, want_traj=True, graph=False, precision="fp64"):
     """B shooting rollouts + cost (+ gradient) in one call (C ABI ``gpmpc_rollout``).
 
     x0: (B, ds) or (ds,); U: (B, H, da) or (H, da).  Returns a dict of CUDA tensors:
@@ -131,7 +131,11 @@ def rollout(pack, x0, U, cost, want_grad=True, want_traj=True, graph=False):
 
     graph=True replays the 2H+1 kernel launches as one hipGraph (for launch-latency-bound small batches, e.g. the
     B = 1 callbacks of a solver loop): inputs are copied into buffers owned by the pack and the returned tensors are
-    views of buffers that the NEXT graph call with the same shape overwrites."""
+    views of buffers that the NEXT graph call with the same shape overwrites.
+
+    precision: "fp64" (default), or -- objective only, for the tolerance sweep of BASELINE config 3 -- "fp32acc" (N^2
+    products and sum in fp32) / "fp32" (exponent and exp in fp32 too).  Single precision fails the variance tolerance
+    by orders of magnitude (profiles/r01/fp32_sweep.txt); it is a measurement aid, not a fast path."""
     dev = pack.device
     U_host = None
     if graph and not isinstance(U, torch.Tensor):          # solver callbacks hand numpy: stage through pinned memory
@@ -149,7 +153,10 @@ def rollout(pack, x0, U, cost, want_grad=True, want_traj=True, graph=False):
         x0 = x0.expand(B, pack.ds).contiguous()
     if da != pack.da or x0.shape[0] != B or cost.ds != pack.ds or cost.da != pack.da:
         raise ValueError("shape mismatch between pack, x0, U and cost parameters")
-    flags = (_lib.WANT_GRAD if want_grad else 0) | (_lib.USE_GRAPH if graph else 0)
+    prec = {"fp64": 0, "fp32acc": _lib.FP32_ACCUM, "fp32": _lib.FP32_ALL}[precision]
+    if prec and want_grad:
+        raise ValueError("the reduced-precision sweep modes are objective only: pass want_grad=False")
+    flags = (_lib.WANT_GRAD if want_grad else 0) | (_lib.USE_GRAPH if graph else 0) | prec
     nbytes = lib().gpmpc_rollout_workspace_bytes(pack.handle, B, H, flags)
     e = lambda *shape: torch.empty(shape, dtype=torch.float64, device=dev)  # noqa: E731
     if graph:

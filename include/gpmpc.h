@@ -46,6 +46,10 @@ extern "C" {
                                      all pointer arguments (inputs, outputs, workspace) are the same buffers on every
                                      call with this flag; a changed argument re-captures.  For launch-latency-bound
                                      small batches (B = 1 solver loops). */
+#define GPMPC_FP32_ACCUM     8u   /* gpmpc_rollout, objective only: N^2 products and their sum in fp32 (exponent / exp in fp64) */
+#define GPMPC_FP32_ALL      16u   /* gpmpc_rollout, objective only: transformed points, exponent, exp and sum in fp32.
+                                     Both exist for the fp64-vs-fp32 tolerance sweep of BASELINE config 3: the variance is a
+                                     cancelling sum and single precision FAILS the 1e-4 tolerance (profiles/r01/fp32_sweep.txt) */
 #define GPMPC_COV_BUG_COMPAT 2u   /* cross-covariance with the reference's transposed cross term
                                      (src/tools/uncertainty_prop.py:446) instead of the consistent one */
 

@@ -237,6 +237,29 @@ def test_long_horizon_uses_the_streaming_tail(G):
         np.testing.assert_allclose(r["grad"][b].cpu().numpy(), o["grad"], rtol=1e-4, atol=1e-7)
 
 
+def test_reduced_precision_sweep_modes_document_the_failure(G):
+    """BASELINE config 3 asks for an fp64-vs-fp32 tolerance sweep: the fp32 modes (objective only) must run, and must
+    be far outside the tolerance that fp64 meets (the variance is a cancelling N^2 sum)."""
+    from oracle import gpmpc_oracle as O
+    from gaussian_process_mpc_amd.synth import synth_problem
+    N, ds, da, H, B = 512, 3, 1, 2, 2
+    pb = synth_problem(15, N, ds, da, H, B, sigma_n=0.1)
+    gp = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"])
+    pack = G.GPPack(pb["X"], pb["Y"], gp.Ky_inv.numpy(), pb["lambdas"], pb["sigma_f"])
+    cost = G.CostParams(-1.0, pb["Q"], pb["R"])
+    ref = np.stack([torch.stack([torch.diagonal(c) for c in O.forward_propagate(gp, H, pb["x0"][b], torch.as_tensor(pb["U"][b]),
+                                                                                mode="o2")[1]]).numpy() for b in range(B)])
+    err = {}
+    for prec in ("fp64", "fp32acc", "fp32"):
+        v = G.rollout(pack, pb["x0"], pb["U"], cost, want_grad=False, precision=prec)["vars"].cpu().numpy()
+        assert np.isfinite(v).all()
+        err[prec] = np.max(np.abs(v[:, 1:] - ref[:, 1:]) / np.abs(ref[:, 1:]))
+    assert err["fp64"] < 1e-7
+    assert err["fp32acc"] > 1e3 * err["fp64"] and err["fp32"] > 1e3 * err["fp64"]
+    with pytest.raises(ValueError):
+        G.rollout(pack, pb["x0"], pb["U"], cost, want_grad=True, precision="fp32")
+
+
 def test_gradient_finite_difference(G):
     """Analytic adjoint against central differences of the HIP objective itself."""
     from oracle import gpmpc_oracle as O
