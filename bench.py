@@ -78,6 +78,9 @@ def cpu_baseline(pb, H_sample, reps=2, fullcov=False):
         t0 = time.perf_counter()
         cport.rollout(pb, gp.Ky_inv.numpy(), -1.0, x0=pb["x0"][:2], U=pb["U"][:2], nthreads=nthr)
         res["cport"] = 2.0 / (time.perf_counter() - t0)
+        t0 = time.perf_counter()                                        # the same port on ONE core (1 thread and all cores)
+        cport.rollout(pb, gp.Ky_inv.numpy(), -1.0, x0=pb["x0"][:1], U=pb["U"][:1], nthreads=1)
+        res["cport_1thread"] = 1.0 / (time.perf_counter() - t0)
     return res, gp
 
 
@@ -253,6 +256,7 @@ def main():
                 "o2_value": res["o2"],
                 "o2_note": "same oracle with the trace evaluated as an O(N^2) elementwise sum (algorithmic baseline)",
                 "c_port_value": res.get("cport"),
+                "c_port_value_1_thread": res.get("cport_1thread"),
                 "c_port_note": "plain-C / OpenMP port of the O(N^2) algorithm with the analytic adjoint (oracle/cport), "
                                "2 trajectories over the whole horizon, same thread count; includes its own pack build",
                 "gpu_over_cpu": value / res["faithful"], "gpu_over_cpu_o2": value / res["o2"],
