@@ -11,7 +11,8 @@
  * Conventions
  *  - All matrices are row-major fp64.  "dev" = device (HBM) pointer, "host" =
  *    host pointer.  The caller owns every buffer; the library never frees or
- *    reallocates caller memory and keeps no global state besides the pack.
+ *    reallocates caller memory and keeps no global state besides the pack (exceptions: the opt-in timing
+ *    counters of gpmpc_timing_enable, process-wide and not thread-safe; GPMPC_* tuning environment variables).
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).
  *    All work is enqueued asynchronously on it; nothing synchronises the
  *    device.  Calls are re-entrant across streams as long as workspaces differ.
