@@ -21,7 +21,8 @@ FP32_ACCUM = 8
 FP32_ALL = 16
 
 _ERR = {-1: "bad argument", -2: "device allocation failed", -3: "HIP call / kernel launch failed",
-        -4: "workspace too small", -5: "pack not built"}
+        -4: "workspace too small", -5: "pack not built",
+        -6: "current HIP device differs from the device the pack was created on"}
 
 
 class LibraryMissing(RuntimeError):
@@ -54,6 +55,7 @@ SIGNATURES = {
     "gpmpc_last_error": (ctypes.c_char_p, []),
     "gpmpc_pack_create": (_i, [ctypes.POINTER(_vp), _i, _i, _i]),
     "gpmpc_pack_destroy": (_i, [_vp]),
+    "gpmpc_pack_reload_tuning": (_i, [_vp]),
     "gpmpc_build_ky": (_i, [_i, _i, _vp, _dp, _d, _d, _vp, _vp, _vp]),
     "gpmpc_pack_build": (_i, [_vp, _vp, _vp, _vp, _dp, _dp, _vp]),
     "gpmpc_pack_build_beta": (_i, [_vp, _vp, _vp, _vp, _dp, _dp, _vp]),
@@ -69,6 +71,7 @@ SIGNATURES = {
     "gpmpc_rollout_fullcov": (_i, [_vp, _i, _i, _vp, _vp, ctypes.POINTER(CostParamsC), _u, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gpmpc_timing_enable": (_i, [_i]),
     "gpmpc_pair_kernel_time": (_i, [_dp, ctypes.POINTER(ctypes.c_longlong), _i]),
+    "gpmpc_pair_kernel_time_class": (_i, [_i, _dp, ctypes.POINTER(ctypes.c_longlong)]),
     "gpmpc_matvec": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
     "gpmpc_kinv_append_workspace_bytes": (_sz, [_i]),
     "gpmpc_kinv_append": (_i, [_i, _vp, _vp, _d, _vp, _vp, _sz, _vp]),

@@ -222,6 +222,8 @@ extern "C" int gpmpc_rollout_fullcov(const gpmpc_pack* p, int B, int H, const do
                                      const gpmpc_cost_params* cost, unsigned flags, double* out_means, double* out_covs,
                                      double* out_cost, double* out_grad, void* workspace, size_t workspace_bytes,
                                      void* stream) {
+    if (!p) return GPMPC_E_ARG;
+    if (int rc_dev = gpmpc_check_device(p)) return rc_dev;
     if (!p || !x0 || !U || !cost || !out_means || !out_covs || !out_cost || !workspace || B < 1 || H < 1) return GPMPC_E_ARG;
     if (!p->built || (p->npairs > 0 && !p->fullcov)) return GPMPC_E_STATE;
     const bool grad = (flags & GPMPC_WANT_GRAD) != 0;

@@ -29,8 +29,23 @@ struct gpmpc_worklist {
     int ustart_host[GPMPC_MAX_DS + GPMPC_MAX_PAIRS + 1];
 };
 
+// Tuning overrides (GPMPC_* environment variables), read ONCE per pack -- at gpmpc_pack_create and again on
+// gpmpc_pack_reload_tuning -- never on the per-call path (a solver loop issues thousands of B = 1 rollouts per second).
+// -1 / 0 = not set: the measured defaults of plan_rollout / plan_mom apply.
+struct gpmpc_tuning {
+    int pair_sb;     // GPMPC_PAIR_SB     0 staged kernel | 1 scalar broadcast | -1 unset
+    int tiling;      // GPMPC_TILING      0..3 | -1 unset
+    int tb;          // GPMPC_PAIR_TB     1 | 2 | 4 | 0 unset
+    int rgroup;      // GPMPC_RGROUP      1..16 | 0 unset
+    int no_first;    // GPMPC_NO_FIRST    full moments at horizon step 1 too
+    int no_xcd_sort; // GPMPC_NO_XCD_SORT natural tile order of the 256x256 work list (takes effect at pack creation only)
+};
+void gpmpc_read_tuning(gpmpc_tuning* t);
+
 struct gpmpc_pack {
     int N, Np, ds, da, D;
+    int device;     // HIP device ordinal the pack's memory lives on (hipGetDevice at creation)
+    gpmpc_tuning tune;
     int built;
     int npairs;     // ds (ds - 1) / 2 cross-covariance units (a < b, lexicographic)
     int fullcov;    // cross-covariance weight matrices are allocated and kept up to date
@@ -106,6 +121,15 @@ int gpmpc_launch_pair(int D, bool diag, bool grad, int tb, int waves, const Pair
 template <int D> int gpmpc_launch_pair_D(bool diag, bool grad, int tb, int waves, const PairArgs& a, hipStream_t s);
 
 void gpmpc_set_error(const char* what, hipError_t e);
+// GPMPC_OK if the calling thread's current device is the pack's, else GPMPC_E_DEVICE (kernels launched on another
+// device would dereference this pack's memory without peer access: a GPU page fault, not an error code)
+static inline int gpmpc_check_device(const gpmpc_pack* p) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return GPMPC_E_LAUNCH;
+    return dev == p->device ? GPMPC_OK : GPMPC_E_DEVICE;
+}
+// pair-kernel timing classes (gpmpc_pair_kernel_time_class): the horizon-step-1 variant is cheaper than the full kernel
+enum { GPMPC_TIME_FULL = 0, GPMPC_TIME_FIRST = 1, GPMPC_TIME_CLASSES = 2 };
 void gpmpc_graph_cache_free(void* cache);
 #define GPMPC_HIP(call)                                              \
     do {                                                             \

@@ -433,9 +433,9 @@ static void plan_mom(const gpmpc_pack* p, int nq, bool grad, bool pair_cov, int 
     r->tb = nq >= 2 ? 2 : 1;
     const long groups = (nq + r->tb - 1) / r->tb;
     r->tiling = (groups * p->wl[r->mode][0].nwork >= 1024) ? 0 : 1;
-    // scalar-broadcast kernel (pair_kernel_sbf.h) once the grid fills the chip; GPMPC_PAIR_SB=0 keeps the staged kernel
+    // scalar-broadcast kernel (pair_kernel_sbf.h) once the grid fills the chip; GPMPC_PAIR_SB=0 (read at pack creation) keeps the staged kernel
     r->sbf = (r->tiling == 0 && D - ns2 <= 2) ? 1 : 0;
-    if (const char* ev = getenv("GPMPC_PAIR_SB")) if (atoi(ev) == 0) r->sbf = 0;
+    if (p->tune.pair_sb == 0) r->sbf = 0;
     r->gw = gpmpc_sbf_gw(D, ns2);
     const gpmpc_worklist& w = p->wl[r->mode][r->tiling];
     r->waves = w.waves; r->nwork = w.nwork; r->nunits = w.nunits;
@@ -552,6 +552,8 @@ extern "C" int gpmpc_moment_match(const gpmpc_pack* p, int nq, const double* u, 
                                   double* out_mean, double* out_var, double* out_cov, double* out_l, double* dmean_du,
                                   double* dmean_dS, double* dvar_du, double* dvar_dS, double* dcov_du, double* dcov_dS,
                                   void* workspace, size_t workspace_bytes, void* stream) {
+    if (!p) return GPMPC_E_ARG;
+    if (int rc_dev = gpmpc_check_device(p)) return rc_dev;
     if (!p) return GPMPC_E_ARG;
     return gpmpc_moment_match_ex(p, nq, u, S, flags, out_mean, out_var, out_cov, out_l, dmean_du, dmean_dS, dvar_du, dvar_dS,
                                  dcov_du, dcov_dS, workspace, workspace_bytes, stream, p->D);

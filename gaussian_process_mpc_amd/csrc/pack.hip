@@ -174,6 +174,25 @@ static int build_worklist(int Np, int it, int jt, int ds, int npairs, bool xcd_s
     return e == hipSuccess ? 0 : -1;
 }
 
+void gpmpc_read_tuning(gpmpc_tuning* t) {
+    auto geti = [](const char* name, int unset) { const char* ev = getenv(name); return ev ? atoi(ev) : unset; };
+    t->pair_sb = geti("GPMPC_PAIR_SB", -1);
+    t->tiling = geti("GPMPC_TILING", -1);
+    t->tb = geti("GPMPC_PAIR_TB", 0);
+    t->rgroup = geti("GPMPC_RGROUP", 0);
+    t->no_first = getenv("GPMPC_NO_FIRST") ? 1 : 0;
+    t->no_xcd_sort = getenv("GPMPC_NO_XCD_SORT") ? 1 : 0;
+}
+
+extern "C" int gpmpc_pack_reload_tuning(gpmpc_pack* p) {
+    if (!p) return GPMPC_E_ARG;
+    const int keep = p->tune.no_xcd_sort;             // baked into the work list at creation
+    gpmpc_read_tuning(&p->tune);
+    p->tune.no_xcd_sort = keep;
+    if (p->graph_cache) { gpmpc_graph_cache_free(p->graph_cache); p->graph_cache = nullptr; }   // captured under the old plan
+    return GPMPC_OK;
+}
+
 extern "C" int gpmpc_pack_create(gpmpc_pack** out, int n_train, int state_dim, int action_dim) {
     if (!out || n_train < 1 || state_dim < 1 || action_dim < 0) return GPMPC_E_ARG;
     const int D = state_dim + action_dim;
@@ -181,6 +200,8 @@ extern "C" int gpmpc_pack_create(gpmpc_pack** out, int n_train, int state_dim, i
     gpmpc_pack* p = (gpmpc_pack*)calloc(1, sizeof(gpmpc_pack));
     if (!p) return GPMPC_E_ALLOC;
     p->N = n_train; p->Np = ((n_train + 63) / 64) * 64; p->ds = state_dim; p->da = action_dim; p->D = D;
+    gpmpc_read_tuning(&p->tune);
+    if (hipGetDevice(&p->device) != hipSuccess) { free(p); return GPMPC_E_LAUNCH; }
     for (int a = 0; a < state_dim; ++a)
         for (int b = a + 1; b < state_dim; ++b) { p->pair_a[p->npairs] = a; p->pair_b[p->npairs] = b; ++p->npairs; }
     const size_t Np = p->Np;
@@ -206,7 +227,7 @@ extern "C" int gpmpc_pack_create(gpmpc_pack** out, int n_train, int state_dim, i
     for (int mode = 0; mode < 2 && ok; ++mode)
         for (int k = 0; k < 4 && ok; ++k) {
             if (mode == 1 && k >= 2) continue;
-            ok = build_worklist(p->Np, cfg[k][0], cfg[k][1], state_dim, mode ? p->npairs : 0, mode == 0 && k == 0 && !getenv("GPMPC_NO_XCD_SORT"), &p->wl[mode][k]) == 0;
+            ok = build_worklist(p->Np, cfg[k][0], cfg[k][1], state_dim, mode ? p->npairs : 0, mode == 0 && k == 0 && !p->tune.no_xcd_sort, &p->wl[mode][k]) == 0;
         }
     if (!ok) { gpmpc_set_error("gpmpc_pack_create", e); gpmpc_pack_destroy(p); return GPMPC_E_ALLOC; }
     *out = p;
@@ -242,6 +263,7 @@ static int pack_build_impl(gpmpc_pack* p, const double* X_dev, const double* Y_d
                            const double* Ky_inv_dev, const double* lambdas_host, const double* sigma_f_host,
                            void* stream) {
     if (!p || !X_dev || !Y_dev || !lambdas_host || !sigma_f_host) return GPMPC_E_ARG;
+    if (int rc_dev = gpmpc_check_device(p)) return rc_dev;
     if (!Ky_inv_dev && !y_is_beta) return GPMPC_E_ARG;
     hipStream_t s = (hipStream_t)stream;
     for (int a = 0; a < p->ds; ++a) {
@@ -275,6 +297,8 @@ static int pack_build_impl(gpmpc_pack* p, const double* X_dev, const double* Y_d
 // Allocate and fill the cross-covariance weight matrices (needed by the full-covariance rollout and by the
 // analytic cross-covariance Jacobians of gpmpc_moment_match).  Later gpmpc_pack_build* calls keep them current.
 extern "C" int gpmpc_pack_enable_fullcov(gpmpc_pack* p, void* stream) {
+    if (!p) return GPMPC_E_ARG;
+    if (int rc_dev = gpmpc_check_device(p)) return rc_dev;
     if (!p) return GPMPC_E_ARG;
     if (p->fullcov || p->npairs == 0) { p->fullcov = 1; return GPMPC_OK; }
     hipStream_t s = (hipStream_t)stream;

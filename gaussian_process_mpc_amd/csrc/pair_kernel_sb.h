@@ -31,6 +31,14 @@
 #define GPMPC_SB_CU(gw) 1
 #endif
 
+#ifndef GPMPC_SB_TB2_WAVES
+// Waves per SIMD the two-trajectory shape is compiled for.  5 (96 registers; the loop needs 85): with the 7-slot exp the
+// 80-register cap of 6 waves/SIMD made the compiler re-materialise a constant and an address in every iteration and
+// spill; measured on one MI355X (C3): 6 waves 5.31 k rollouts/s, one trajectory per wave at 8 waves 6.07 k, 5 waves 6.24 k
+// (the 9-slot exp it replaces: 5.98-6.02 k at 6 waves) -- gpurun_out/r02_job2, profiles/r02/README.md.
+#define GPMPC_SB_TB2_WAVES 5
+#endif
+
 template <int D, int NS2>
 struct PairSbTraits {
     static constexpr int GW = (D + 1 + NS2 + 1) & ~1;     // doubles per G row (even: rows stay 16-byte aligned)
@@ -40,7 +48,7 @@ struct PairSbTraits {
 // FIRST: horizon step 1, whose state inputs (x0, Sigma_0) are constants: only the derivatives w.r.t. the action dimensions
 // (k >= NS2) are needed, so the w and the state-dimension v accumulations are dropped (8 of 30 VALU instructions at D = 5).
 template <int D, int TB, int NS2, bool GRAD, bool FIRST = false>
-__global__ __launch_bounds__(256, (TB == 2 && D <= 5) ? 6 : 1) void gpmpc_pair_kernel_sb(PairSbArgs A) {
+__global__ __launch_bounds__(256, (TB == 2 && D <= 5) ? GPMPC_SB_TB2_WAVES : 1) void gpmpc_pair_kernel_sb(PairSbArgs A) {
     constexpr int GW = PairSbTraits<D, NS2>::GW;
     constexpr int NM = GRAD ? 1 + 2 * D : 1, NA = GRAD ? 1 + D + NS2 : 1;
     __shared__ double s_red[4 * TB * NM];
@@ -124,6 +132,9 @@ __global__ __launch_bounds__(256, (TB == 2 && D <= 5) ? 6 : 1) void gpmpc_pair_k
                     const auto raw = __builtin_amdgcn_raw_buffer_load_b64(Mrs[r], lane8, (jc - jstart + q) * Np * 8, 0);
                     mij[r][q] = __builtin_bit_cast(double, raw);
                 }
+            // keep the M_ij load at the top of the iteration: left to itself the scheduler may sink it next to its use
+            // (it did with the 7-slot exp: C3 2.18 -> 2.46 ms per launch, the load latency exposed in every iteration)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < CU; ++q) {
 #pragma unroll

@@ -601,69 +601,74 @@ extern "C" int gpmpc_device_count(void) {
     return n;
 }
 
-static int g_timing = 0;
-static double g_pair_ms = 0.0;
-static long long g_pair_launches = 0;
-struct EvPair { hipEvent_t a, b; };
-static EvPair g_pending[4096];
-static int g_npending = 0;
+// Opt-in timing of the pair kernel (bench.py): HIP events around every pair launch on the launch stream, accumulated
+// per class (full kernel / horizon-step-1 variant).  One process-wide record behind a mutex: concurrent rollouts on
+// different streams or host threads may all run with timing on.
+#include <mutex>
+#include <vector>
+struct EvPair { hipEvent_t a, b; int cls; };
+static struct {
+    std::mutex mu;
+    int on = 0;
+    double ms[GPMPC_TIME_CLASSES] = {0.0, 0.0};
+    long long n[GPMPC_TIME_CLASSES] = {0, 0};
+    std::vector<EvPair> pending;
+} g_time;
 
-static void drain_events() {
-    for (int k = 0; k < g_npending; ++k) {
+static void drain_events_locked() {
+    for (const EvPair& ev : g_time.pending) {
         float ms = 0.f;
-        if (hipEventSynchronize(g_pending[k].b) == hipSuccess && hipEventElapsedTime(&ms, g_pending[k].a, g_pending[k].b) == hipSuccess) {
-            g_pair_ms += ms; ++g_pair_launches;
+        if (hipEventSynchronize(ev.b) == hipSuccess && hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) {
+            g_time.ms[ev.cls] += ms; ++g_time.n[ev.cls];
         }
-        (void)hipEventDestroy(g_pending[k].a); (void)hipEventDestroy(g_pending[k].b);
+        (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b);
     }
-    g_npending = 0;
+    g_time.pending.clear();
 }
-extern "C" int gpmpc_timing_enable(int on) { g_timing = on; return GPMPC_OK; }
+static bool timing_on() { std::lock_guard<std::mutex> lk(g_time.mu); return g_time.on != 0; }
+extern "C" int gpmpc_timing_enable(int on) { std::lock_guard<std::mutex> lk(g_time.mu); g_time.on = on; return GPMPC_OK; }
 extern "C" int gpmpc_pair_kernel_time(double* total_ms, long long* launches, int reset) {
-    drain_events();
-    if (total_ms) *total_ms = g_pair_ms;
-    if (launches) *launches = g_pair_launches;
-    if (reset) { g_pair_ms = 0.0; g_pair_launches = 0; }
+    std::lock_guard<std::mutex> lk(g_time.mu);
+    drain_events_locked();
+    if (total_ms) *total_ms = g_time.ms[0] + g_time.ms[1];
+    if (launches) *launches = g_time.n[0] + g_time.n[1];
+    if (reset) for (int c = 0; c < GPMPC_TIME_CLASSES; ++c) { g_time.ms[c] = 0.0; g_time.n[c] = 0; }
+    return GPMPC_OK;
+}
+extern "C" int gpmpc_pair_kernel_time_class(int cls, double* total_ms, long long* launches) {
+    if (cls < 0 || cls >= GPMPC_TIME_CLASSES) return GPMPC_E_ARG;
+    std::lock_guard<std::mutex> lk(g_time.mu);
+    drain_events_locked();
+    if (total_ms) *total_ms = g_time.ms[cls];
+    if (launches) *launches = g_time.n[cls];
     return GPMPC_OK;
 }
 
+// Bracket one launch with events when timing is on.  `launch` enqueues the kernel on s and returns its status.
+template <class F>
+static int timed_launch(int cls, hipStream_t s, F launch) {
+    if (!timing_on()) return launch();
+    EvPair ev; ev.cls = cls;
+    GPMPC_HIP(hipEventCreate(&ev.a));
+    GPMPC_HIP(hipEventCreate(&ev.b));
+    GPMPC_HIP(hipEventRecord(ev.a, s));
+    const int rc = launch();
+    GPMPC_HIP(hipEventRecord(ev.b, s));
+    std::lock_guard<std::mutex> lk(g_time.mu);
+    if (g_time.pending.size() >= 4096) drain_events_locked();
+    g_time.pending.push_back(ev);
+    return rc;
+}
+
 int gpmpc_timed_pair(int D, bool diag, bool grad, int tb, int waves, const PairArgs& a, hipStream_t s) {
-    if (!g_timing) return gpmpc_launch_pair(D, diag, grad, tb, waves, a, s);
-    if (g_npending == 4096) drain_events();
-    EvPair ev;
-    GPMPC_HIP(hipEventCreate(&ev.a));
-    GPMPC_HIP(hipEventCreate(&ev.b));
-    GPMPC_HIP(hipEventRecord(ev.a, s));
-    int rc = gpmpc_launch_pair(D, diag, grad, tb, waves, a, s);
-    GPMPC_HIP(hipEventRecord(ev.b, s));
-    g_pending[g_npending++] = ev;
-    return rc;
+    return timed_launch(GPMPC_TIME_FULL, s, [&] { return gpmpc_launch_pair(D, diag, grad, tb, waves, a, s); });
 }
-
 int gpmpc_timed_pair_sb(int D, bool grad, int tb, int ns2, int waves, const PairSbArgs& a, hipStream_t s) {
-    if (!g_timing) return gpmpc_launch_pair_sb(D, grad, tb, ns2, waves, a, s);
-    if (g_npending == 4096) drain_events();
-    EvPair ev;
-    GPMPC_HIP(hipEventCreate(&ev.a));
-    GPMPC_HIP(hipEventCreate(&ev.b));
-    GPMPC_HIP(hipEventRecord(ev.a, s));
-    int rc = gpmpc_launch_pair_sb(D, grad, tb, ns2, waves, a, s);
-    GPMPC_HIP(hipEventRecord(ev.b, s));
-    g_pending[g_npending++] = ev;
-    return rc;
+    return timed_launch(a.first_step ? GPMPC_TIME_FIRST : GPMPC_TIME_FULL, s,
+                        [&] { return gpmpc_launch_pair_sb(D, grad, tb, ns2, waves, a, s); });
 }
-
 int gpmpc_timed_pair_sbf(int D, bool grad, int ns2, int waves, const PairSbfArgs& a, hipStream_t s) {
-    if (!g_timing) return gpmpc_launch_pair_sbf(D, grad, ns2, waves, a, s);
-    if (g_npending == 4096) drain_events();
-    EvPair ev;
-    GPMPC_HIP(hipEventCreate(&ev.a));
-    GPMPC_HIP(hipEventCreate(&ev.b));
-    GPMPC_HIP(hipEventRecord(ev.a, s));
-    int rc = gpmpc_launch_pair_sbf(D, grad, ns2, waves, a, s);
-    GPMPC_HIP(hipEventRecord(ev.b, s));
-    g_pending[g_npending++] = ev;
-    return rc;
+    return timed_launch(GPMPC_TIME_FULL, s, [&] { return gpmpc_launch_pair_sbf(D, grad, ns2, waves, a, s); });
 }
 
 struct RollPlan { int tiling, tb, waves, nwork, nm, pps, sps, sb, gw, rgroup; size_t off_G; size_t off_pp, off_sp, off_part, off_jac, off_means, off_vars, total; };
@@ -683,20 +688,21 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     r->sb = (sb_ok && (big || mid)) ? 1 : 0;
     const bool many = (long)p->wl[0][1].nwork > 256L * p->ds;        // > 256 one-wave tiles per GP (N >= 1472)
     r->tiling = big ? 0 : (mid ? 2 : (many ? 3 : 1));
-    if (const char* ev = getenv("GPMPC_PAIR_SB")) {          // tuning override: 0 = staged kernel, 1 = scalar broadcast
-        r->sb = (atoi(ev) != 0 && sb_ok) ? 1 : 0;
+    const gpmpc_tuning& tn = p->tune;                        // GPMPC_* overrides, read once at pack creation
+    if (tn.pair_sb >= 0) {                                   // 0 = staged kernel, 1 = scalar broadcast
+        r->sb = (tn.pair_sb != 0 && sb_ok) ? 1 : 0;
         r->tiling = r->sb ? (big ? 0 : 2) : (big ? 0 : (many ? 3 : 1));
     }
-    if (const char* ev = getenv("GPMPC_TILING")) { const int v = atoi(ev); if (v == 0 || ((v == 1 || v == 3) && !r->sb) || (v == 2 && r->sb)) r->tiling = v; }
+    if (tn.tiling >= 0) { const int v = tn.tiling; if (v == 0 || ((v == 1 || v == 3) && !r->sb) || (v == 2 && r->sb)) r->tiling = v; }
     // scalar-broadcast kernel: two trajectories per wave on the big tiling up to D = 5 (two independent dependency chains per
     // lane, one M_ij load for both: C3 +2.6 %, objective-only +14 %; 82 VGPRs); D = 7 (C4) is 2.5 % faster with one
     r->tb = r->sb ? ((big && D <= 5 && B >= 2) ? 2 : 1) : (B >= 2 ? 2 : 1);
-    if (const char* ev = getenv("GPMPC_PAIR_TB")) { const int v = atoi(ev); if (v == 1 || v == 2 || (v == 4 && !r->sb)) r->tb = v; }
+    if (tn.tb) { const int v = tn.tb; if (v == 1 || v == 2 || (v == 4 && !r->sb)) r->tb = v; }
     if (!diag && grad && r->tb > 2) r->tb = 2;
     // Dispatch interleave of the scalar-broadcast kernel (pair_kernel_sb.h): 4 row tiles per trajectory share each fetch
     // of the G rows (C3 fabric reads per launch 757 -> 418 MB by FETCH_SIZE at the same speed; C4 +0.5 %).
     r->rgroup = 4;
-    if (const char* ev = getenv("GPMPC_RGROUP")) { const int v = atoi(ev); if (v >= 1 && v <= 16) r->rgroup = v; }
+    if (tn.rgroup >= 1 && tn.rgroup <= 16) r->rgroup = tn.rgroup;
     if (r->tiling != 0) r->rgroup = 1;
     if (lowprec) { r->sb = 0; r->tiling = 0; r->tb = 1; }      // tolerance-sweep kernels: 256x256 work list, one trajectory per workgroup
     r->waves = p->wl[0][r->tiling].waves;
@@ -782,7 +788,7 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
             PairSbArgs Q;
             Q.M = p->M; Q.XT = p->XT; Q.pp = A.pp; Q.G = A.G; Q.part = A.part; Q.work = P.work;
             Q.Np = p->Np; Q.B = B; Q.ds = p->ds; Q.nwork = r.nwork; Q.pps = r.pps; Q.nm = r.nm; Q.rgroup = r.rgroup;
-            Q.first_step = (t == 1 && !getenv("GPMPC_NO_FIRST")) ? 1 : 0;
+            Q.first_step = (t == 1 && !p->tune.no_first) ? 1 : 0;
             rc = gpmpc_timed_pair_sb(p->D, grad, r.tb, p->ds, r.waves, Q, s);
         } else {
             rc = gpmpc_timed_pair(p->D, true, grad, r.tb, P.colsplit ? 4 : r.waves, P, s);
@@ -876,7 +882,8 @@ extern "C" int gpmpc_rollout(const gpmpc_pack* p, int B, int H, const double* x0
                              const gpmpc_cost_params* cost, unsigned flags, double* out_means, double* out_vars,
                              double* out_cost, double* out_grad, void* workspace, size_t workspace_bytes, void* stream) {
     if (!p || !cost) return GPMPC_E_ARG;
-    if ((flags & GPMPC_USE_GRAPH) && !g_timing && p->built && x0 && U && out_cost && workspace && B >= 1 && H >= 1)
+    if (int rc_dev = gpmpc_check_device(p)) return rc_dev;
+    if ((flags & GPMPC_USE_GRAPH) && !timing_on() && p->built && x0 && U && out_cost && workspace && B >= 1 && H >= 1)
         return graph_rollout(const_cast<gpmpc_pack*>(p), B, H, x0, U, cost, flags, out_means, out_vars, out_cost, out_grad,
                              workspace, workspace_bytes, (hipStream_t)stream);
     return enqueue_rollout(p, B, H, x0, U, cost, flags, out_means, out_vars, out_cost, out_grad, workspace,

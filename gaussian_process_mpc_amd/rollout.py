@@ -67,7 +67,8 @@ class GPPack:
         self.lambdas = np.ascontiguousarray(np.asarray(lambdas, dtype=np.float64).reshape(self.ds, self.D))
         self.sigma_f = np.ascontiguousarray(np.asarray(sigma_f, dtype=np.float64).reshape(self.ds))
         h = ctypes.c_void_p()
-        check(lib().gpmpc_pack_create(ctypes.byref(h), self.N, self.ds, self.da), "gpmpc_pack_create")
+        with torch.cuda.device(self.device):       # the pack's HBM buffers belong to THIS device, whatever is current
+            check(lib().gpmpc_pack_create(ctypes.byref(h), self.N, self.ds, self.da), "gpmpc_pack_create")
         self._h = h
         _, lp = host_doubles(self.lambdas)
         _, sp = host_doubles(self.sigma_f)
@@ -86,7 +87,8 @@ class GPPack:
         if h:
             try:
                 torch.cuda.synchronize(self.device)
-                lib().gpmpc_pack_destroy(h)
+                with torch.cuda.device(self.device):
+                    lib().gpmpc_pack_destroy(h)
             except Exception:
                 pass
             self._h = None
@@ -97,6 +99,12 @@ class GPPack:
         with torch.cuda.device(self.device):
             check(lib().gpmpc_pack_enable_fullcov(self._h, stream_ptr()), "gpmpc_pack_enable_fullcov")
         self.fullcov = True
+        return self
+
+    def reload_tuning(self):
+        """Re-read the GPMPC_* tuning environment variables (read once at pack creation otherwise)."""
+        check(lib().gpmpc_pack_reload_tuning(self._h), "gpmpc_pack_reload_tuning")
+        self._graph_bufs = {}
         return self
 
     @property
@@ -261,12 +269,13 @@ def moment_match(pack, u, S, want_cov=False, want_grad=False, bug_compatible=Fal
 def cost_full(cost, means, covs, U):
     """Risk-sensitive cost for given means (B,H+1,ds), FULL covariances (B,H+1,ds,ds), inputs (B,H,da)
     (C ABI ``gpmpc_cost``; reference src/mpc.py:156-200)."""
-    dev = require_gpu()
+    dev = means.device if isinstance(means, torch.Tensor) and means.is_cuda else require_gpu()
     means, covs, U = _dev(means, dev), _dev(covs, dev), _dev(U, dev)
     if means.dim() == 2:
         means, covs, U = means.unsqueeze(0), covs.unsqueeze(0), U.unsqueeze(0)
     B, H1, ds = means.shape
     out = torch.empty(B, dtype=torch.float64, device=dev)
-    check(lib().gpmpc_cost(B, H1 - 1, ds, U.shape[2], ctypes.byref(cost.c), ptr(means), ptr(covs), ptr(U), ptr(out),
-                           stream_ptr()), "gpmpc_cost")
+    with torch.cuda.device(dev):
+        check(lib().gpmpc_cost(B, H1 - 1, ds, U.shape[2], ctypes.byref(cost.c), ptr(means), ptr(covs), ptr(U), ptr(out),
+                               stream_ptr()), "gpmpc_cost")
     return out

@@ -12,7 +12,10 @@
  *  - All matrices are row-major fp64.  "dev" = device (HBM) pointer, "host" =
  *    host pointer.  The caller owns every buffer; the library never frees or
  *    reallocates caller memory and keeps no global state besides the pack (exceptions: the opt-in timing
- *    counters of gpmpc_timing_enable, process-wide and not thread-safe; GPMPC_* tuning environment variables).
+ *    counters of gpmpc_timing_enable, process-wide behind a mutex; GPMPC_* tuning environment variables, read once
+ *    per pack at gpmpc_pack_create / gpmpc_pack_reload_tuning, never on the per-call path).
+ *  - A pack lives on the HIP device that was current when it was created; every entry point that takes a pack
+ *    returns GPMPC_E_DEVICE if the calling thread's current device differs (it never switches devices itself).
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).
  *    All work is enqueued asynchronously on it; nothing synchronises the
  *    device.  Calls are re-entrant across streams as long as workspaces differ.
@@ -40,6 +43,7 @@ extern "C" {
 #define GPMPC_E_LAUNCH     -3   /* a HIP call or kernel launch failed */
 #define GPMPC_E_WORKSPACE  -4   /* workspace too small */
 #define GPMPC_E_STATE      -5   /* pack not built */
+#define GPMPC_E_DEVICE     -6   /* the calling thread's current HIP device is not the one the pack was created on */
 
 /* flags for gpmpc_rollout / gpmpc_moment_match */
 #define GPMPC_WANT_GRAD      1u   /* also produce d cost / d U (rollout) or input Jacobians (moment_match) */
@@ -74,6 +78,9 @@ const char* gpmpc_last_error(void);     /* thread-local text of the last failing
  * ------------------------------------------------------------------------- */
 int gpmpc_pack_create(gpmpc_pack** out, int n_train, int state_dim, int action_dim);
 int gpmpc_pack_destroy(gpmpc_pack* pack);
+/* Re-read the GPMPC_* tuning environment variables for this pack (they are otherwise read once, at
+ * gpmpc_pack_create) and drop its captured graph.  For A/B runs and tests; no reference counterpart. */
+int gpmpc_pack_reload_tuning(gpmpc_pack* pack);
 
 /* Build K_f, K_y = K_f + noise_var*I for one GP on the device
  * (GaussianProcessRegression.build_Ky_inv_mat, src/gpr.py:163-170; the inverse at :171 is
@@ -197,6 +204,10 @@ int gpmpc_rollout_fullcov(const gpmpc_pack* pack, int B, int H, const double* x0
  * (it synchronises on the recorded events). */
 int gpmpc_timing_enable(int on);
 int gpmpc_pair_kernel_time(double* total_ms, long long* launches, int reset);
+/* The same totals per kernel class: 0 = the full pair kernel, 1 = its horizon-step-1 variant (constant state inputs:
+ * fewer moments, cheaper), so that a roofline figure can be quoted for the dominant kernel alone.  Reset with
+ * gpmpc_pair_kernel_time(..., 1). */
+int gpmpc_pair_kernel_time_class(int kernel_class, double* total_ms, long long* launches);
 
 /* ---------------------------------------------------------------------------
  * GP prediction at test points (GaussianProcessRegression.compute_pred_train_covariance /

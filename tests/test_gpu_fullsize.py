@@ -127,6 +127,87 @@ def test_c3_training_set_permutation_invariance(G, c3):
     np.testing.assert_allclose(b["grad"].cpu().numpy(), a["grad"].cpu().numpy(), rtol=1e-4, atol=1e-8)
 
 
+def test_c3_bench_shape_against_cport(G, c3):
+    """The exact bench.py workload (B = 256 trajectories: 256x256 tiles, two trajectories per wave, dispatch interleave 4,
+    the horizon-step-1 variant and the 19 full launches): first, middle and last trajectory of the batch, whole horizon,
+    held DIRECTLY to the C port -- not through agreement between batch sizes."""
+    from oracle import cport
+    from gaussian_process_mpc_amd.synth import CONFIGS, synth_problem
+    pb, gp, pack = c3
+    cfg = CONFIGS["C3"]
+    big = synth_problem(3, cfg["N"], cfg["ds"], cfg["da"], cfg["H"], cfg["B"])     # bench.py's own batch
+    assert np.array_equal(big["X"], pb["X"])
+    r = G.rollout(pack, big["x0"], big["U"], G.CostParams(cfg["gamma"], big["Q"], big["R"]))
+    assert all(torch.isfinite(v).all() for v in r.values())
+    pick = [0, 127, 255]
+    c = cport.rollout(big, gp.Ky_inv.numpy(), cfg["gamma"], x0=big["x0"][pick], U=big["U"][pick], nthreads=16)
+    np.testing.assert_allclose(r["means"][pick].cpu().numpy(), c["means"], rtol=1e-5, atol=1e-9)       # north star
+    np.testing.assert_allclose(r["vars"][pick].cpu().numpy(), c["vars"], rtol=1e-4)                    # north star
+    np.testing.assert_allclose(r["cost"][pick].cpu().numpy(), c["cost"], rtol=1e-6)
+    np.testing.assert_allclose(r["grad"][pick].cpu().numpy(), c["grad"], rtol=1e-4, atol=1e-7)
+
+
+def test_c5_full_covariance_at_full_size_against_cport(G, c3):
+    """BASELINE config 5 at its size (N = 2048, ds = 4, H = 20, gamma = -1, FULL covariance): two trajectories of a
+    B = 64 batch (the pair_kernel_sbf.h shape of bench.py --config C5: 256x256 tiles, 4 variance + 6 cross units) against
+    the full-covariance C port over the whole horizon: means 1e-5, covariances 1e-4, cost, and the analytic gradient
+    against complex-step directional derivatives."""
+    from oracle import cport
+    from gaussian_process_mpc_amd.synth import CONFIGS, synth_problem
+    pb, gp, pack = c3
+    cfg = CONFIGS["C5"]
+    big = synth_problem(5, cfg["N"], cfg["ds"], cfg["da"], cfg["H"], 64)
+    kinv5 = None
+    if not np.array_equal(big["X"], pb["X"]):                 # config 5 draws its own training set (seed 1005)
+        from oracle import gpmpc_oracle as O
+        gp5 = O.GPBundle(big["X"], big["Y"], big["lambdas"], big["sigma_f"], big["sigma_n"])
+        kinv5 = gp5.Ky_inv.numpy()
+        pack5 = G.GPPack(big["X"], big["Y"], kinv5, big["lambdas"], big["sigma_f"])
+    else:
+        kinv5, pack5 = gp.Ky_inv.numpy(), pack
+    r = G.rollout_fullcov(pack5, big["x0"], big["U"], G.CostParams(cfg["gamma"], big["Q"], big["R"]))
+    assert all(torch.isfinite(v).all() for v in r.values())
+    pick = [0, 63]
+    dirs = np.random.default_rng(55).normal(size=(2, 2, cfg["H"], cfg["da"]))
+    c = cport.rollout_fullcov(big, kinv5, cfg["gamma"], x0=big["x0"][pick], U=big["U"][pick], dirs=dirs, nthreads=16)
+    np.testing.assert_allclose(r["means"][pick].cpu().numpy(), c["means"], rtol=1e-5, atol=1e-9)       # north star
+    np.testing.assert_allclose(r["covs"][pick].cpu().numpy(), c["covs"], rtol=1e-4, atol=1e-6 * np.abs(c["covs"]).max())
+    np.testing.assert_allclose(torch.diagonal(r["covs"][pick], dim1=2, dim2=3).cpu().numpy(),
+                               np.diagonal(c["covs"], axis1=2, axis2=3), rtol=1e-4)                    # north star (variances)
+    np.testing.assert_allclose(r["cost"][pick].cpu().numpy(), c["cost"], rtol=1e-6)
+    g = r["grad"][pick].cpu().numpy()
+    for k in range(2):
+        for d in range(2):
+            np.testing.assert_allclose(float((g[k] * dirs[k, d]).sum()), c["ddir"][k, d], rtol=1e-4, atol=1e-7)
+    assert np.abs(r["covs"][:, 1:, 0, 1].cpu().numpy()).max() > 0
+    del pack5
+    torch.cuda.empty_cache()
+
+
+def test_c4_full_horizon_against_cport(G):
+    """BASELINE config 4 (N = 4096, ds = 6, da = 1, H = 30): the per-GPU bench batch (B = 128: 256x256 tiles, the D = 7 /
+    one-trajectory-per-wave kernel, its horizon-step-1 variant once and the full variant 29 times) with three of its
+    trajectories held to the C port over the WHOLE horizon."""
+    from oracle import cport, gpmpc_oracle as O
+    from gaussian_process_mpc_amd.synth import CONFIGS, synth_problem
+    cfg = CONFIGS["C4"]
+    pb = synth_problem(4, cfg["N"], cfg["ds"], cfg["da"], cfg["H"], 128)
+    torch.set_num_threads(16)
+    gp = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"])
+    kinv = gp.Ky_inv.numpy()
+    pack = G.GPPack(pb["X"], pb["Y"], kinv, pb["lambdas"], pb["sigma_f"])
+    r = G.rollout(pack, pb["x0"], pb["U"], G.CostParams(cfg["gamma"], pb["Q"], pb["R"]))
+    assert all(torch.isfinite(v).all() for v in r.values())
+    pick = [0, 64, 127]
+    c = cport.rollout(pb, kinv, cfg["gamma"], x0=pb["x0"][pick], U=pb["U"][pick], nthreads=16)
+    np.testing.assert_allclose(r["means"][pick].cpu().numpy(), c["means"], rtol=1e-5, atol=1e-9)       # north star
+    np.testing.assert_allclose(r["vars"][pick].cpu().numpy(), c["vars"], rtol=1e-4)                    # north star
+    np.testing.assert_allclose(r["cost"][pick].cpu().numpy(), c["cost"], rtol=1e-6)
+    np.testing.assert_allclose(r["grad"][pick].cpu().numpy(), c["grad"], rtol=1e-4, atol=1e-7)
+    del pack
+    torch.cuda.empty_cache()
+
+
 def test_c4_first_step_against_oracle(G):
     """N=4096, ds=6, da=1 (config 4): first horizon step of two trajectories against the O(N^2) oracle."""
     from oracle import gpmpc_oracle as O

@@ -1,0 +1,131 @@
+"""Every pair-kernel template instance the dispatchers can select for D <= 7 is held to a CPU checker.
+
+The rollout picks its kernel by the amount of work (csrc/step.hip::plan_rollout, csrc/moment.hip::plan_mom):
+
+    staged kernel, 64-row tiles      (pair_kernel.h)      small batches
+    scalar broadcast, 256x64 tiles   (pair_kernel_sb.h)   B * tiles >= 1024, one trajectory per wave
+    scalar broadcast, 256x256 tiles  (pair_kernel_sb.h)   B * tiles >= 3072, two trajectories per wave up to D = 5
+    scalar broadcast, full S         (pair_kernel_sbf.h)  full-covariance rollout / moment matching on large batches
+
+and each is instantiated per (D, state_dim, GRAD, FIRST).  The cases below drive every (state_dim, action_dim) with
+D <= 7 and action_dim in {1, 2} through all shapes by the batch size and compare sampled trajectories with the plain-C
+ports under oracle/cport (pinned to the torch oracle and to the reference's fixtures by tests/test_oracle_golden.py):
+means 1e-5, variances / covariances 1e-4 (BASELINE north star), cost 1e-6, gradient 1e-4.
+Reference: src/dynamics.py:126-191, src/tools/uncertainty_prop.py:296-465, src/mpc.py:156-255.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DIMS = [(1, 1), (1, 2), (2, 1), (2, 2), (3, 1), (3, 2), (4, 1), (4, 2), (5, 1), (5, 2), (6, 1)]
+
+
+@pytest.fixture(scope="module")
+def G():
+    import gaussian_process_mpc_amd as g
+    g.require_gpu()
+    return g
+
+
+def _problem(seed, N, ds, da, H, B):
+    from oracle import gpmpc_oracle as O
+    from gaussian_process_mpc_amd.synth import synth_problem
+    pb = synth_problem(seed, N, ds, da, H, B)
+    gp = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"])
+    return pb, gp.Ky_inv.numpy()
+
+
+@pytest.mark.parametrize("ds,da", DIMS)
+def test_diag_rollout_every_shape_vs_cport(G, ds, da):
+    """Diagonal-covariance rollout: staged / 256x64 / 256x256 kernels (GRAD and objective-only, horizon step 1 and
+    later steps) at every input dimension, against the C port's values and analytic adjoint."""
+    from oracle import cport
+    N, H = 150, 3                                   # Np = 192: 1 row tile, 3 column chunks of the 256x64 work list
+    b_big = 3072 // ds + 3                          # B * ds >= 3072 work items -> 256x256 tiles
+    b_big += 1 - b_big % 2                          # odd on purpose (the last wave of the two-trajectory shape is half empty)
+    b_mid = 1024 // (3 * ds) + 2                    # B * 3 ds >= 1024 -> 256x64 tiles
+    pb, kinv = _problem(40 + 8 * ds + da, N, ds, da, H, b_big)
+    pack = G.GPPack(pb["X"], pb["Y"], kinv, pb["lambdas"], pb["sigma_f"])
+    cost = G.CostParams(-1.0, pb["Q"], pb["R"])
+    for B in (3, b_mid, b_big):
+        r = G.rollout(pack, pb["x0"][:B], pb["U"][:B], cost)
+        assert all(torch.isfinite(v).all() for v in r.values())
+        pick = sorted({0, 1, B // 2, B - 1})
+        c = cport.rollout(pb, kinv, -1.0, x0=pb["x0"][pick], U=pb["U"][pick], nthreads=8)
+        np.testing.assert_allclose(r["means"][pick].cpu().numpy(), c["means"], rtol=1e-5, atol=1e-9, err_msg=f"B={B}")
+        np.testing.assert_allclose(r["vars"][pick].cpu().numpy(), c["vars"], rtol=1e-4, atol=1e-12, err_msg=f"B={B}")
+        np.testing.assert_allclose(r["cost"][pick].cpu().numpy(), c["cost"], rtol=1e-6, err_msg=f"B={B}")
+        np.testing.assert_allclose(r["grad"][pick].cpu().numpy(), c["grad"], rtol=1e-4, atol=1e-7, err_msg=f"B={B}")
+        f = G.rollout(pack, pb["x0"][:B], pb["U"][:B], cost, want_grad=False)       # the GRAD = false instances
+        np.testing.assert_allclose(f["cost"].cpu().numpy(), r["cost"].cpu().numpy(), rtol=1e-9)
+        np.testing.assert_allclose(f["vars"].cpu().numpy(), r["vars"].cpu().numpy(), rtol=1e-7)
+
+
+@pytest.mark.parametrize("ds,da", [(2, 1), (2, 2), (3, 1), (3, 2), (4, 1), (4, 2), (5, 1), (5, 2)])
+def test_fullcov_rollout_every_shape_vs_cport(G, ds, da):
+    """Full-covariance rollout (config 5 semantics): the staged kernel (small batch) and pair_kernel_sbf.h (large batch)
+    at every input dimension up to 7, against the C port: means, covariances, cost, and the analytic gradient held to
+    complex-step directional derivatives of the C port."""
+    from oracle import cport
+    N, H = 110, 3
+    units = ds + ds * (ds - 1) // 2
+    b_big = 2 * (1024 // units) + 5                 # ceil(B / 2) * units >= 1024 -> pair_kernel_sbf.h
+    pb, kinv = _problem(60 + 8 * ds + da, N, ds, da, H, b_big)
+    pb["Q"] = pb["Q"] + 0.02 * (np.ones((ds, ds)) - np.eye(ds))           # couples the off-diagonal covariances into the cost
+    pack = G.GPPack(pb["X"], pb["Y"], kinv, pb["lambdas"], pb["sigma_f"])
+    cost = G.CostParams(-1.0, pb["Q"], pb["R"])
+    rng = np.random.default_rng(ds * 10 + da)
+    for B in (3, b_big):
+        r = G.rollout_fullcov(pack, pb["x0"][:B], pb["U"][:B], cost)
+        assert all(torch.isfinite(v).all() for v in r.values())
+        pick = [0, B - 1]
+        dirs = rng.normal(size=(2, 2, H, da))
+        c = cport.rollout_fullcov(pb, kinv, -1.0, x0=pb["x0"][pick], U=pb["U"][pick], dirs=dirs, nthreads=8)
+        np.testing.assert_allclose(r["means"][pick].cpu().numpy(), c["means"], rtol=1e-5, atol=1e-9, err_msg=f"B={B}")
+        np.testing.assert_allclose(r["covs"][pick].cpu().numpy(), c["covs"], rtol=1e-4, atol=1e-6 * np.abs(c["covs"]).max(),
+                                   err_msg=f"B={B}")
+        np.testing.assert_allclose(r["cost"][pick].cpu().numpy(), c["cost"], rtol=1e-6, err_msg=f"B={B}")
+        g = r["grad"][pick].cpu().numpy()
+        for k in range(2):
+            for d in range(2):
+                np.testing.assert_allclose(float((g[k] * dirs[k, d]).sum()), c["ddir"][k, d], rtol=1e-4, atol=1e-7,
+                                           err_msg=f"B={B} trajectory {pick[k]} direction {d}")
+        f = G.rollout_fullcov(pack, pb["x0"][:B], pb["U"][:B], cost, want_grad=False)
+        np.testing.assert_allclose(f["cost"].cpu().numpy(), r["cost"].cpu().numpy(), rtol=1e-9)
+
+
+@pytest.mark.parametrize("D,ds", [(6, 2), (7, 2), (6, 3)])
+def test_moment_match_full_S_large_D_vs_cport(G, D, ds):
+    """gpmpc_moment_match at D = 6, 7 with a FULL input covariance (the pair kernels' full-moment instances that the
+    rollouts of the cases above do not reach: NS2 = D), small and large query batches, against the C port's single step."""
+    from oracle import cport
+    da = D - ds
+    pb, kinv = _problem(90 + D + ds, 90, ds, da, 1, 1)
+    pack = G.GPPack(pb["X"], pb["Y"], kinv, pb["lambdas"], pb["sigma_f"]).enable_fullcov()
+    rng = np.random.default_rng(D)
+    units = ds + ds * (ds - 1) // 2
+    for nq in (2, 2 * (1024 // units) + 3):
+        u = 0.5 * rng.normal(size=(nq, D))
+        A = rng.normal(size=(nq, D, D))
+        S = 0.02 * A @ np.swapaxes(A, 1, 2) + 0.01 * np.eye(D)
+        r = G.moment_match(pack, u, S, want_cov=True, want_grad=True)
+        assert all(torch.isfinite(v).all() for v in r.values())
+        for q in (0, nq - 1):
+            m, c = cport.moment_match_fullcov(pb["X"], kinv, pb["Y"], pb["lambdas"], pb["sigma_f"], u[q], S[q], nthreads=4)
+            np.testing.assert_allclose(r["mean"][q].cpu().numpy(), m, rtol=1e-5, atol=1e-9)
+            np.testing.assert_allclose(r["cov"][q].cpu().numpy(), c, rtol=1e-4, atol=1e-6 * np.abs(c).max())
+            np.testing.assert_allclose(r["var"][q].cpu().numpy(), np.diag(c), rtol=1e-4)
+        # Jacobians: central differences of the HIP values themselves along one random direction of (u, S)
+        q = nq - 1
+        du = rng.normal(size=D)
+        dS = rng.normal(size=(D, D))
+        dS = 0.5 * (dS + dS.T)
+        eps = 1e-4
+        rp = G.moment_match(pack, u[q] + eps * du, S[q] + eps * dS)
+        rm = G.moment_match(pack, u[q] - eps * du, S[q] - eps * dS)
+        for key, ju, jS in (("mean", "dmean_du", "dmean_dS"), ("var", "dvar_du", "dvar_dS")):
+            fd = (rp[key][0] - rm[key][0]).cpu().numpy() / (2 * eps)
+            an = r[ju][q].cpu().numpy() @ du + np.einsum("akl,kl->a", r[jS][q].cpu().numpy(), dS)
+            np.testing.assert_allclose(an, fd, rtol=2e-4, atol=1e-6 * max(1.0, np.abs(fd).max()), err_msg=key)

@@ -435,9 +435,9 @@ def test_scalar_broadcast_kernels_match_staged(G, golden, monkeypatch):
     S = 0.03 * Aq @ np.swapaxes(Aq, 1, 2) + 0.01 * np.eye(D)
     u[0], S[0] = z[p + "u"], z[p + "S"]
     monkeypatch.setenv("GPMPC_PAIR_SB", "0")
-    a = G.moment_match(pack, u, S, want_cov=True, want_grad=True)
+    a = G.moment_match(pack.reload_tuning(), u, S, want_cov=True, want_grad=True)    # the overrides are read per pack, not per call
     monkeypatch.setenv("GPMPC_PAIR_SB", "1")
-    b = G.moment_match(pack, u, S, want_cov=True, want_grad=True)
+    b = G.moment_match(pack.reload_tuning(), u, S, want_cov=True, want_grad=True)
     for k in a:
         x, y = a[k].cpu().numpy(), b[k].cpu().numpy()
         np.testing.assert_allclose(y, x, rtol=1e-6, atol=1e-9 * max(1.0, np.abs(x).max()), err_msg=k)
@@ -453,9 +453,9 @@ def test_scalar_broadcast_kernels_match_staged(G, golden, monkeypatch):
     cost = G.CostParams(-1.0, pb["Q"] + 0.02 * (1 - np.eye(2)), pb["R"])
     for fn in (G.rollout, G.rollout_fullcov):
         monkeypatch.setenv("GPMPC_PAIR_SB", "0")
-        a = fn(pk, pb["x0"], pb["U"], cost)
+        a = fn(pk.reload_tuning(), pb["x0"], pb["U"], cost)
         monkeypatch.setenv("GPMPC_PAIR_SB", "1")
-        b = fn(pk, pb["x0"], pb["U"], cost)
+        b = fn(pk.reload_tuning(), pb["x0"], pb["U"], cost)
         for k in a:
             x, y = a[k].cpu().numpy(), b[k].cpu().numpy()
             np.testing.assert_allclose(y, x, rtol=1e-6, atol=1e-10, err_msg=f"{fn.__name__}:{k}")

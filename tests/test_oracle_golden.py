@@ -191,6 +191,81 @@ def test_cport_matches_reference_fixture(golden):
         np.testing.assert_allclose(r["grad"], z["grads"][gi], rtol=1e-6, atol=1e-9)
 
 
+@pytest.mark.parametrize("ds,da", [(5, 1), (6, 1), (4, 2), (5, 2), (1, 2)])
+def test_cport_matches_torch_oracle_input_dims(ds, da):
+    """The C port at the input dimensions D = 6, 7 (BASELINE config 4 is ds = 6, da = 1) the GPU instance tests
+    (tests/test_gpu_instances.py) use it for: values and analytic adjoint against the torch oracle's autograd."""
+    from oracle import cport
+    from gaussian_process_mpc_amd.synth import synth_problem
+    pb = synth_problem(17, 70, ds, da, 3, 1)
+    gp = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"])
+    r = cport.rollout(pb, gp.Ky_inv.numpy(), -1.0, nthreads=4)
+    o = O.objective_and_gradient(gp, 3, pb["x0"][0], pb["U"][0], pb["x_ref"], pb["u_ref"], pb["Q"], pb["R"], -1.0, mode="o2")
+    np.testing.assert_allclose(r["means"][0], o["means"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(r["vars"][0], o["vars"], rtol=1e-6)
+    np.testing.assert_allclose(r["cost"][0], o["cost"], rtol=1e-8)
+    np.testing.assert_allclose(r["grad"][0], o["grad"], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("k", range(6))
+def test_cport_fullcov_single_step_matches_reference_fixture(golden, k):
+    """The full-covariance C port (oracle/cport/gpmpc_cpu_fullcov.c), one step at a given (u, S), against the
+    reference's own outputs (g2): mean_prop_torch / variance_prop_torch values and the reference's numpy double loop
+    covariance_prop (the consistent cross term; the reference's torch version is index-transposed for full S)."""
+    from oracle import cport
+    z = golden("g2_adversarial.npz")
+    p = f"c{k}_"
+    sf1, sf2, _ = z[p + "hyp"]
+    lam = np.stack([z[p + "lam1"], z[p + "lam2"]])
+    m, c = cport.moment_match_fullcov(z[p + "X"], np.stack([z[p + "Kinv1"], z[p + "Kinv2"]]),
+                                      np.stack([z[p + "y1"], z[p + "y2"]], axis=1), lam, [sf1, sf2], z[p + "u"], z[p + "S"], nthreads=2)
+    np.testing.assert_allclose(m, z[p + "mu"], rtol=1e-11)
+    np.testing.assert_allclose(np.diag(c), z[p + "var"], rtol=1e-9)
+    _, cu = cport.moment_match_fullcov(z[p + "X"], np.stack([z[p + "unit_Kinv1"], z[p + "unit_Kinv2"]]),
+                                       np.stack([z[p + "y1"], z[p + "y1"]], axis=1), lam, [1.0, 1.0], z[p + "u"], z[p + "S"], nthreads=2)
+    np.testing.assert_allclose(cu[0, 1], z[p + "unit_cov_numpy"], rtol=1e-9)
+    assert cu[0, 1] == cu[1, 0]
+    if z["cases"][k][1] == 0:      # diagonal S: the reference's torch form agrees too
+        np.testing.assert_allclose(cu[0, 1], z[p + "unit_cov_torch"], rtol=1e-9)
+
+
+def test_cport_fullcov_g1_test_suite_geometry(golden):
+    """... and on the reference test-suite geometry (g1: full S, proportional lambdas, where the reference's torch and
+    numpy covariances agree): mean, variance, covariance."""
+    from oracle import cport
+    z = golden("g1_single_step.npz")
+    lam = np.stack([z["lam1"], z["lam2"]])
+    for tag in ("a", "b", "c"):
+        y = z[tag + "_y"]
+        m, c = cport.moment_match_fullcov(z[tag + "_X"], np.stack([z[tag + "_Kinv1"], z[tag + "_Kinv2"]]), np.stack([y, y], axis=1),
+                                          lam, z[tag + "_sf"], z["u"], z["S"], nthreads=2)
+        np.testing.assert_allclose(m, z[tag + "_mu"], rtol=1e-10)
+        np.testing.assert_allclose(np.diag(c), z[tag + "_var"], rtol=1e-7)
+        np.testing.assert_allclose(c[0, 1], z[tag + "_cov"], rtol=1e-7)
+
+
+@pytest.mark.parametrize("ds,da,gamma", [(3, 2, -1.0), (2, 1, 1e-5), (4, 1, 0.0), (5, 2, 0.7)])
+def test_cport_fullcov_matches_torch_oracle(ds, da, gamma):
+    """Whole full-covariance rollouts of the C port against the torch extension oracle (forward_propagate_fullcov /
+    objective_and_gradient_fullcov): means, covariances, cost, and the complex-step directional derivatives of the cost
+    against autograd.  This is what licenses the port as the full-size checker of BASELINE config 5 on the GPU box."""
+    from oracle import cport
+    from gaussian_process_mpc_amd.synth import synth_problem
+    H, B = 3, 2
+    pb = synth_problem(19, 80, ds, da, H, B)
+    pb["Q"] = pb["Q"] + 0.02 * (np.ones((ds, ds)) - np.eye(ds))
+    gp = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"])
+    dirs = np.random.default_rng(3).normal(size=(B, 2, H, da))
+    r = cport.rollout_fullcov(pb, gp.Ky_inv.numpy(), gamma, dirs=dirs, nthreads=4)
+    for b in range(B):
+        o = O.objective_and_gradient_fullcov(gp, H, pb["x0"][b], pb["U"][b], pb["x_ref"], pb["u_ref"], pb["Q"], pb["R"], gamma)
+        np.testing.assert_allclose(r["means"][b], o["means"], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(r["covs"][b], o["covs"], rtol=1e-6, atol=1e-9 * np.abs(o["covs"]).max())
+        np.testing.assert_allclose(r["cost"][b], o["cost"], rtol=1e-9)
+        for d in range(2):
+            np.testing.assert_allclose(r["ddir"][b, d], float((o["grad"] * dirs[b, d]).sum()), rtol=1e-7, atol=1e-10)
+
+
 def test_g8_marginal_likelihood(golden):
     """compute_marginal_likelihood at set hyper-parameters (src/gpr.py:240-251)."""
     d = golden("g8_hyper.npz")
