@@ -19,9 +19,9 @@ from .gpr import GaussianProcessRegression                              # noqa: 
 from .dynamics import Dynamics                                          # noqa: F401
 from .mpc import RiskSensitiveMPC                                       # noqa: F401
 from .uncertainty_prop import mean_prop_torch, variance_prop_torch, covariance_prop_torch  # noqa: F401
-from .simulator import Simulator, PendulumPlant                         # noqa: F401
+from .simulator import Simulator, PendulumPlant, CartPolePlant          # noqa: F401
 from .rollout import GPPack, CostParams, rollout, rollout_fullcov, moment_match   # noqa: F401
 
 __all__ = ["GaussianProcessRegression", "Dynamics", "RiskSensitiveMPC", "mean_prop_torch",
            "variance_prop_torch", "covariance_prop_torch", "GPPack", "CostParams", "rollout",
-           "rollout_fullcov", "moment_match", "Simulator", "PendulumPlant", "lib", "require_gpu"]
+           "rollout_fullcov", "moment_match", "Simulator", "PendulumPlant", "CartPolePlant", "lib", "require_gpu"]

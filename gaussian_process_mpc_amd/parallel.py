@@ -33,7 +33,12 @@ def gather_results(cost, grad, dist, sizes=None):
     Equal shard sizes use one all_gather_into_tensor; ragged shards pad to the largest."""
     world = dist.get_world_size()
     b = cost.shape[0]
-    flat = cost.reshape(b, 1) if grad is None else torch.cat((cost.reshape(b, 1), grad.reshape(b, -1)), dim=1)
+    # explicit width: reshape(0, -1) is ambiguous for the empty block of a rank that owns no trajectory (world > B)
+    gw = 1
+    if grad is not None:
+        for n in grad.shape[1:]:
+            gw *= int(n)
+    flat = cost.reshape(b, 1) if grad is None else torch.cat((cost.reshape(b, 1), grad.reshape(b, gw)), dim=1)
     width = flat.shape[1]
     if sizes is None:
         sizes = [b] * world
@@ -50,7 +55,7 @@ def gather_results(cost, grad, dist, sizes=None):
         out = torch.cat(parts, dim=0)
     rows = torch.cat([out[r * bmax:r * bmax + sizes[r]] for r in range(world)], dim=0) if min(sizes) < bmax else out
     cost_all = rows[:, 0].contiguous()
-    grad_all = None if grad is None else rows[:, 1:].reshape(-1, *grad.shape[1:]).contiguous()
+    grad_all = None if grad is None else rows[:, 1:].reshape(rows.shape[0], *grad.shape[1:]).contiguous()
     return cost_all, grad_all
 
 

@@ -1,6 +1,10 @@
 """Closed loop around the accelerated path: the reference's ``Simulator.run`` (src/simulator.py:37-60) for any
-environment with the gym step API, plus a dependency-free pendulum plant so the loop can run where ``gym`` is not
-installed.  (the caller of the path; rendering / video recording are out of scope.)"""
+environment with the gym step API, plus dependency-free plants -- the update rules of the reference's two
+environments as plain classes -- so the loop can run where ``gym`` / ``pygame`` are not installed.
+(the callers of the path; rendering / video recording are out of scope.)
+The plants are pinned to the reference's own environment classes by tests/golden/g9_closed_loop.npz."""
+import math
+
 import numpy as np
 
 
@@ -45,6 +49,20 @@ class PendulumPlant(object):
         self.state = self.init_state.copy()
         return self.state.copy(), {}
 
+    @staticmethod
+    def step_static(state, u, options):
+        """Stateless update (src/environments/adjustable_pendulum.py:158-178): ``options`` holds g, m, l, dt,
+        max_torque, max_speed; ``u`` is array-like (its first entry is the torque)."""
+        th, thdot = state[0], state[1]
+        g, m, l, dt = options["g"], options["m"], options["l"], options["dt"]
+        u = np.clip(u, -options["max_torque"], options["max_torque"])[0]
+        newthdot = thdot + (3 * g / (2 * l) * np.sin(th) + 3.0 / (m * l ** 2) * u) * dt
+        newthdot = np.clip(newthdot, -options["max_speed"], options["max_speed"])
+        return np.array([th + newthdot * dt, newthdot])
+
+    def options(self):
+        return {"g": self.g, "m": self.m, "l": self.l, "dt": self.dt, "max_torque": self.max_torque, "max_speed": self.max_speed}
+
     def step(self, u):
         th, thdot = self.state
         u = float(np.clip(u, -self.max_torque, self.max_torque)[0])
@@ -54,3 +72,40 @@ class PendulumPlant(object):
                         -self.max_speed, self.max_speed)
         self.state = np.array([th + thdot * self.dt, thdot])
         return self.state.copy(), -cost, False, False, {}
+
+
+class CartPolePlant(object):
+    """The continuous cart-pole of the reference (src/environments/continuous_cartpole.py): semi-implicit Euler update
+    ``stepPhysics`` (:71-87), ``step`` (:89-101: force = force_mag * action, reward 1, never terminates), ``reset``
+    (:129-132: uniform(-0.2, 0.2) start), without gym / pygame.  State (x, x_dot, theta, theta_dot)."""
+
+    def __init__(self, seed=None, init_state=None):
+        self.gravity, self.masscart, self.masspole = 9.8, 1.0, 0.1
+        self.total_mass = self.masspole + self.masscart
+        self.length = 0.5                                # half the pole's length
+        self.polemass_length = self.masspole * self.length
+        self.force_mag, self.tau = 30.0, 0.02
+        self.min_action, self.max_action = -1.0, 1.0
+        self.np_random = np.random.default_rng(seed)
+        self.init_state = None if init_state is None else np.array(init_state, dtype=np.float64)
+        self.state = None
+
+    def stepPhysics(self, force, state=None):
+        x, x_dot, theta, theta_dot = self.state if state is None else state
+        costheta, sintheta = math.cos(theta), math.sin(theta)
+        temp = (force + self.polemass_length * theta_dot * theta_dot * sintheta) / self.total_mass
+        thetaacc = (self.gravity * sintheta - costheta * temp) / \
+            (self.length * (4.0 / 3.0 - self.masspole * costheta * costheta / self.total_mass))
+        xacc = temp - self.polemass_length * thetaacc * costheta / self.total_mass
+        return (x + self.tau * x_dot, x_dot + self.tau * xacc, theta + self.tau * theta_dot, theta_dot + self.tau * thetaacc)
+
+    def step(self, action):
+        a = float(np.asarray(action, dtype=np.float64).reshape(-1)[0])
+        if not (-1 < a < 1):
+            raise AssertionError("action must lie strictly inside (-1, 1)")      # continuous_cartpole.py:92
+        self.state = self.stepPhysics(self.force_mag * a)
+        return np.array(self.state), 1, False, False, {}
+
+    def reset(self):
+        self.state = self.np_random.uniform(low=-0.2, high=0.2, size=(4,)) if self.init_state is None else self.init_state.copy()
+        return np.array(self.state), None

@@ -20,6 +20,13 @@ Fixtures:
   g6_gp.npz            Ky / Ky_inv / K* / predict
   g7_quirks.npz        dtype quirks of the rollout
   g8_hyper.npz         marginal likelihood at set hyper-parameters; update_hyperparams trajectories (Adam)
+  g9_closed_loop.npz   the callers either side of the path: plant updates of the reference's two
+                       environments (cart-pole stepPhysics, pendulum step / step_static) on seeded inputs, and the data
+                       file triple of the README experiment (src/experiments/data/*.npy, stored as arrays)
+
+g9 imports src/environments/*, which need ``gym`` (absent here).  A minimal stand-in module (``gym.Env`` as a bare base
+class, ``spaces.Box`` recording its arguments, ``seeding.np_random``, ``error.DependencyNotInstalled``) is registered
+for that import only; none of the arithmetic captured below goes through it.
 """
 import os
 import sys
@@ -314,10 +321,87 @@ def g8():
     np.savez(os.path.join(OUT, "g8_hyper.npz"), **out)
 
 
+def _gym_stand_in():
+    """Just enough of gym's module tree for ``import src.environments.*`` to succeed (class bodies only reference these
+    names at construction time; no gym arithmetic exists on the plant updates captured by g9)."""
+    gym = types.ModuleType("gym")
+
+    class Env(object):
+        np_random = None
+
+        def reset(self, *, seed=None, options=None):
+            self.np_random = np.random.default_rng(seed)
+
+    class Box(object):
+        def __init__(self, low=None, high=None, shape=None, dtype=None):
+            self.low, self.high, self.shape, self.dtype = low, high, shape, dtype
+
+    class DependencyNotInstalled(Exception):
+        pass
+
+    gym.Env = Env
+    spaces = types.ModuleType("gym.spaces"); spaces.Box = Box
+    logger = types.ModuleType("gym.logger"); logger.warn = lambda *a, **k: None
+    utils = types.ModuleType("gym.utils")
+    seeding = types.ModuleType("gym.utils.seeding"); seeding.np_random = lambda seed=None: (np.random.default_rng(seed), seed)
+    utils.seeding = seeding
+    error = types.ModuleType("gym.error"); error.DependencyNotInstalled = DependencyNotInstalled
+    envs = types.ModuleType("gym.envs")
+    cc = types.ModuleType("gym.envs.classic_control")
+    ccu = types.ModuleType("gym.envs.classic_control.utils")
+    cc.utils = ccu; envs.classic_control = cc
+    gym.spaces, gym.logger, gym.utils, gym.error, gym.envs = spaces, logger, utils, error, envs
+    for name, mod in (("gym", gym), ("gym.spaces", spaces), ("gym.logger", logger), ("gym.utils", utils),
+                      ("gym.utils.seeding", seeding), ("gym.error", error), ("gym.envs", envs),
+                      ("gym.envs.classic_control", cc), ("gym.envs.classic_control.utils", ccu)):
+        sys.modules.setdefault(name, mod)
+
+
+def g9():
+    _gym_stand_in()
+    from src.environments.continuous_cartpole import ContinuousCartPoleEnv
+    from src.environments.adjustable_pendulum import AdjustablePendulumEnv
+    out = {}
+    rng = np.random.default_rng(909)
+    # cart-pole: stepPhysics on explicit states (src/environments/continuous_cartpole.py:71-87) and a step() chain
+    env = ContinuousCartPoleEnv()
+    st = rng.uniform(-1, 1, (12, 4)) * np.array([2.0, 3.0, 0.6, 3.0])
+    fc = rng.uniform(-30, 30, 12)
+    out["cp_states"], out["cp_forces"] = st, fc
+    out["cp_next"] = np.array([env.stepPhysics(float(f), tuple(s)) for s, f in zip(st, fc)])
+    env.state = np.array([0.05, -0.1, 0.08, 0.2])
+    acts = rng.uniform(-0.99, 0.99, 25)
+    chain = []
+    for a in acts:
+        obs, rew, term, trunc, _ = env.step(np.array([a]))
+        chain.append(np.array(obs, dtype=float))
+    out["cp_chain_x0"], out["cp_chain_actions"], out["cp_chain"] = np.array([0.05, -0.1, 0.08, 0.2]), acts, np.array(chain)
+    out["cp_params"] = np.array([env.gravity, env.masscart, env.masspole, env.length, env.force_mag, env.tau])
+    # pendulum: step_static (src/environments/adjustable_pendulum.py:158-178) and step() (:135-156), incl. clipping
+    opts = {"g": 9.81, "m": 1.0, "l": 1.0, "dt": 0.05, "max_torque": 2.0, "max_speed": 8.0}
+    ps = rng.uniform(-1, 1, (12, 2)) * np.array([4.0, 9.0])
+    pu = rng.uniform(-3, 3, (12, 1))
+    out["pd_states"], out["pd_u"] = ps, pu
+    out["pd_static_next"] = np.array([AdjustablePendulumEnv.step_static(s, u, opts) for s, u in zip(ps, pu)])
+    out["pd_opts"] = np.array([opts[k] for k in ("g", "m", "l", "dt", "max_torque", "max_speed")])
+    penv = AdjustablePendulumEnv(g=10.0, max_speed=8, max_torque=2.0, init_state={"th_init": np.pi, "thdot_init": 0.0})
+    obs, _ = penv.reset()
+    pacts = rng.uniform(-2.5, 2.5, (30, 1))
+    pch, prew = [np.array(obs, dtype=float)], []
+    for u in pacts:
+        obs, r, _, _, _ = penv.step(u)
+        pch.append(np.array(obs, dtype=float)); prew.append(float(r))
+    out["pd_chain_actions"], out["pd_chain"], out["pd_chain_reward"] = pacts, np.array(pch), np.array(prew)
+    # the data files of the README experiment (src/experiments/pretrain_uncertainty.py:86-88)
+    for k in ("states", "actions", "next_states"):
+        out["exp_" + k] = np.load(os.path.join(REF, "src", "experiments", "data", k + ".npy"))
+    np.savez(os.path.join(OUT, "g9_closed_loop.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9):
         if only and fn.__name__ not in only:
             continue
         fn()

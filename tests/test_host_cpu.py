@@ -176,3 +176,90 @@ def test_gather_results_gloo_world2(ragged):
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+def _gloo_worker_more_ranks_than_items(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from gaussian_process_mpc_amd.parallel import sharded_rollout
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    H, da = 3, 2
+    fake = lambda x0b, Ub: {"cost": Ub.sum(dim=(1, 2)), "grad": 2.0 * Ub}      # noqa: E731
+    ok = True
+    for n in (1, 2):                                    # fewer trajectories than ranks: some ranks own an empty block
+        Uall = torch.arange(n * H * da, dtype=torch.float64).reshape(n, H, da) / 3.0
+        cs, gs = sharded_rollout(fake, torch.zeros(3), Uall, dist)
+        ok = ok and bool(torch.equal(cs, Uall.sum(dim=(1, 2))) and torch.equal(gs, 2.0 * Uall))
+        cs, gs = sharded_rollout(fake, torch.zeros(3), Uall, dist, want_grad=False)
+        ok = ok and bool(torch.equal(cs, Uall.sum(dim=(1, 2))) and gs is None)
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_sharded_rollout_more_ranks_than_trajectories_gloo_world3():
+    """world > B: the ranks without a trajectory contribute an empty block and must still enter the collective (an
+    ambiguous reshape of the (0, H, da) gradient used to raise on them while the others hung in all_gather)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 400) + 120
+    procs = [ctx.Process(target=_gloo_worker_more_ranks_than_items, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(3))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True), (2, True)]
+
+
+def test_bench_refuses_to_mislabel_the_rank_count():
+    """bench.py --gpus N must run N ranks or fail: (i) with WORLD_SIZE already set to something else it exits non-zero
+    before touching a device; (ii) with no WORLD_SIZE and fewer visible GPUs than N the launcher exits non-zero (here:
+    zero GPUs) instead of printing a 1-GPU line -- the round-1 behaviour the driver would have recorded as `n_gpus: 1`."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and '"n_gpus"' not in r.stdout
+
+
+def test_plants_match_the_reference_environments(golden):
+    """the plant updates either side of the path, as plain classes, against the reference's own
+    environment classes run by tests/golden/gen_golden.py (g9): cart-pole stepPhysics / step
+    (src/environments/continuous_cartpole.py:71-101) and pendulum step_static / step
+    (src/environments/adjustable_pendulum.py:135-178), bit for bit (same operations in the same order)."""
+    from gaussian_process_mpc_amd.simulator import CartPolePlant, PendulumPlant
+    z = golden("g9_closed_loop.npz")
+    cp = CartPolePlant()
+    assert [cp.gravity, cp.masscart, cp.masspole, cp.length, cp.force_mag, cp.tau] == list(z["cp_params"])
+    nxt = np.array([cp.stepPhysics(float(f), tuple(s)) for s, f in zip(z["cp_states"], z["cp_forces"])])
+    assert np.array_equal(nxt, z["cp_next"])
+    cp = CartPolePlant(init_state=z["cp_chain_x0"])
+    cp.reset()
+    chain = []
+    for a in z["cp_chain_actions"]:
+        obs, rew, term, trunc, _ = cp.step(np.array([a]))
+        assert rew == 1 and not term and not trunc
+        chain.append(obs)
+    assert np.array_equal(np.array(chain), z["cp_chain"])
+    with pytest.raises(AssertionError):
+        cp.step(np.array([1.0]))                                  # the reference asserts -1 < action < 1
+    s0, _ = CartPolePlant(seed=3).reset()
+    assert s0.shape == (4,) and np.all(np.abs(s0) <= 0.2)
+    opts = dict(zip(("g", "m", "l", "dt", "max_torque", "max_speed"), z["pd_opts"]))
+    st = np.array([PendulumPlant.step_static(s, u, opts) for s, u in zip(z["pd_states"], z["pd_u"])])
+    assert np.array_equal(st, z["pd_static_next"])
+    pd = PendulumPlant(g=10.0, max_speed=8, max_torque=2.0, init_state=(np.pi, 0.0))
+    obs, _ = pd.reset()
+    states, rewards = [obs], []
+    for u in z["pd_chain_actions"]:
+        obs, r, _, _, _ = pd.step(u)
+        states.append(obs); rewards.append(r)
+    assert np.array_equal(np.array(states), z["pd_chain"])
+    np.testing.assert_allclose(rewards, z["pd_chain_reward"], rtol=1e-15)
+    assert np.array_equal(PendulumPlant.step_static(z["pd_chain"][3], z["pd_chain_actions"][3], pd.options()), z["pd_chain"][4])
