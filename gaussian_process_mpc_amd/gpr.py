@@ -32,6 +32,9 @@ class GaussianProcessRegression(object):
         self._beta = None
         self._adam = None           # (optimizer, host parameters) of update_hyperparams, created on first use
         self._hcache = {}           # host copies of the log-hypers, keyed on tensor identity and version
+        self._built_hypers = None   # (lambdas, sigma_f, noise variance) the current Kf / Ky / Ky_inv were built with
+        self._appends_since_rebuild = 0
+        self.rebuild_every = 64     # incremental appends between two full rebuilds (bounds the accumulated round-off)
 
     # -- hyper-parameters: same expressions as the reference setters (src/gpr.py:51-88), including the
     #    dtype inference of torch.tensor (a Python float / list is float32 before the log).  Like the
@@ -91,12 +94,34 @@ class GaussianProcessRegression(object):
         else:
             self.X_train = torch.cat((self.X_train, x), dim=0)
             self.y_train = torch.cat((self.y_train, y), dim=0)
-        if incremental and num_obs == 1 and self.num_train > 0 and self.Ky_inv is not None:
+        # The O(N^2) append is only valid on matrices built with the CURRENT hyper-parameters (the setters do not
+        # rebuild, src/gpr.py:53; the reference's append always does, so an edit takes effect there), and its round-off
+        # accumulates: fall back to the reference's full rebuild when the hypers changed and every `rebuild_every` appends.
+        if (incremental and num_obs == 1 and self.num_train > 0 and self.Ky_inv is not None
+                and self._built_hypers == self._current_hypers() and self._appends_since_rebuild < self.rebuild_every):
             self._append_one_incremental(x)
             self.num_train += 1
+            self._appends_since_rebuild += 1
             return
         self.num_train += num_obs
         self.build_Ky_inv_mat()
+
+    def _current_hypers(self):
+        return (tuple(float(v) for v in self.get_lambdas()), float(self.get_sigma_f()), self._noise_var())
+
+    def se_kernel(self, x1, x2):
+        """sigma_f^2 exp(-1/2 (x1 - x2)^T Lambda^-1 (x1 - x2)) for two points: 0-dim device tensor (src/gpr.py:124-135),
+        evaluated by the same device kernel as K(X*, X) (C ABI ``gpmpc_predict``)."""
+        a = torch.as_tensor(x1).to(self.device).type(torch.float64).reshape(1, self.x_dim).contiguous()
+        b = torch.as_tensor(x2).to(self.device).type(torch.float64).reshape(1, self.x_dim).contiguous()
+        out = torch.empty((1, 1), dtype=torch.float64, device=self.device)
+        _, lp = host_doubles(self.get_lambdas())
+        nb = lib().gpmpc_predict_workspace_bytes(1, self.x_dim, 1)
+        ws = torch.empty(max(int(nb), 8), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().gpmpc_predict(1, self.x_dim, ptr(b), lp, self.get_sigma_f(), None, None, 0.0, 1, ptr(a), ptr(out), None, None,
+                                      ctypes.c_void_p(ws.data_ptr()), ws.numel(), stream_ptr()), "gpmpc_predict")
+        return out.reshape(())
 
     def _append_one_incremental(self, x_new):
         """self.X_train / y_train already hold the new row (last); Kf, Ky, Ky_inv still have the old size n."""
@@ -141,6 +166,8 @@ class GaussianProcessRegression(object):
         self.Ky_inv = torch.linalg.inv(self.Ky)
         self._beta = None
         self.version += 1
+        self._built_hypers = (tuple(float(v) for v in lam), float(sigma_f), noise)
+        self._appends_since_rebuild = 0
 
     # -- prediction
     def _targets(self):

@@ -53,6 +53,11 @@ def test_gpr_closed_form_kernel(G):
     Ky = np.array([[2.25, k01], [k01, 2.25]]) + float(np.float32(0.3 ** 2)) * np.eye(2)
     np.testing.assert_allclose(gp.Ky.cpu().numpy(), Ky, rtol=1e-14)
     np.testing.assert_allclose(gp.Ky_inv.cpu().numpy(), np.linalg.inv(Ky), rtol=1e-12)
+    # se_kernel (src/gpr.py:124-135): two points -> 0-dim tensor, squeezing (1, D) inputs like the reference
+    k = gp.se_kernel(torch.tensor(X[0:1]), torch.tensor(X[1]))
+    assert k.shape == () and k.is_cuda
+    np.testing.assert_allclose(k.item(), k01, rtol=1e-14)
+    np.testing.assert_allclose(gp.se_kernel(torch.tensor(X[1]), torch.tensor(X[1])).item(), 2.25, rtol=1e-15)
     with_nom = G.GaussianProcessRegression(2, nominal_model=lambda x: x[:, 0:1] * 2.0)
     with_nom.set_lambdas(np.array([2.0, 0.5]))
     with_nom.append_train_data(X, np.array([1.0, -1.0]))
@@ -238,6 +243,84 @@ def test_closed_loop_simulator(G):
     assert all(np.isfinite(h[2]) for h in hist) and all(abs(h[1][0]) <= 2.0 + 1e-9 for h in hist)
 
 
+def test_integration_md_stub_runs_verbatim(G, golden, monkeypatch):
+    """INTEGRATION.md section B documents the ctypes binding a maintainer of the reference would add.  Extract that code
+    block from the file and execute it AS WRITTEN (only GPMPC_LIB points it at the in-tree library), with the mirror's
+    Dynamics / RiskSensitiveMPC objects standing in for the reference's (same attributes), against the reference's own
+    rollout outputs (g3: cost and gradient for every gamma, both start states)."""
+    import os
+    from gaussian_process_mpc_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    sect = text[text.index("## B."):]
+    start = sect.index("```python") + len("```python")
+    code = sect[start:sect.index("```", start)]
+    assert "def build_pack" in code and "def objective_and_gradient" in code
+    monkeypatch.setenv("GPMPC_LIB", _lib.LIB_PATH)
+    ns = {}
+    exec(compile(code, "INTEGRATION.md#B", "exec"), ns)
+    z = golden("g3_rollout_c1.npz")
+    mpc = _mpc_from(G, z, float(z["gammas"][0]))
+    pack = ns["build_pack"](mpc.dynamics)
+    for b in range(z["x0"].shape[0]):
+        mpc.curr_state = torch.tensor(z["x0"][b], device=mpc.device).type(torch.float64)
+        for gi, gamma in enumerate(z["gammas"]):
+            mpc.gamma = float(gamma)
+            c, g = ns["objective_and_gradient"](mpc, pack, z["U"][b].reshape(-1))
+            np.testing.assert_allclose(c, z["costs"][gi, b], rtol=1e-6)
+            np.testing.assert_allclose(g, z["grads"][gi, b], rtol=1e-4, atol=1e-7)
+
+
+def test_readme_experiment_risk_averse_follows_the_data(G, golden):
+    """The experiment behind the reference's README figures (src/experiments/pretrain_uncertainty.py:82-121; its own data
+    files, hyper-parameters lambda = 0.5 / sigma_f = 1 / sigma_n = 1e-5, Q = 2 I, R = 0, H = 6, start (4, -4)), run through
+    the mirror classes and the closed loop of Simulator.run (src/simulator.py:37-60) on the true dynamics s' = s + a.
+    Behavioural properties, not shapes (README.md: risk-averse plans stay close to the training data, risk-neutral ones
+    cut across the region without data): the optimiser lowers the cost; the first risk-averse input climbs the corridor
+    at x = 4 while the risk-neutral one moves diagonally; predicted and realised paths of gamma = -1 stay closer to the
+    training states than those of gamma = 1e-5; the loop makes progress towards the target."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    from readme_uncertainty_experiment import build_mpc, distance_to_data
+    data = golden("g9_closed_loop.npz")
+    np.testing.assert_allclose(data["exp_next_states"], data["exp_states"] + data["exp_actions"], rtol=1e-14)      # s' = s + a
+
+    class AdditivePlant(object):
+        def __init__(self):
+            self.state = np.array([4.0, -4.0])
+
+        def reset(self):
+            self.state = np.array([4.0, -4.0])
+            return self.state.copy(), {}
+
+        def step(self, a):
+            self.state = self.state + np.asarray(a, dtype=float)
+            return self.state.copy(), -float(self.state @ self.state), False, False, {}
+
+    out = {}
+    for gamma in (-1.0, 1e-5):
+        mpc = build_mpc(gamma, data)
+        s0 = np.array([4.0, -4.0])
+        plan = mpc.get_optimal_trajectory(s0)
+        assert plan.shape == (6, 2) and np.all(np.abs(plan) <= 1 + 1e-9)
+        planned = mpc.objective(plan.reshape(-1))
+        assert np.isfinite(planned) and planned < 0.6 * mpc.objective(np.zeros(12))                # the optimiser lowers the cost
+        r = mpc.evaluate_batch(plan[None], s0)
+        means = r["means"][0].cpu().numpy()
+        hist = G.Simulator(mpc, AdditivePlant(), num_iters=4).run()
+        path = np.array([h[0] for h in hist] + [hist[-1][0] + hist[-1][1]])
+        assert mpc.dynamics.gpr_err[0].num_train == 404                                            # one observation per loop step
+        out[gamma] = dict(plan=plan, d_pred=distance_to_data(means[1:], data["exp_states"]).mean(),
+                          d_loop=distance_to_data(path, data["exp_states"]).mean(), path=path)
+        assert np.linalg.norm(path[-1]) < np.linalg.norm(path[0]) - 2.0                            # progress towards the target
+    averse, neutral = out[-1.0], out[1e-5]
+    assert averse["plan"][0, 1] > 0.8 and abs(averse["plan"][0, 0]) < 0.5        # up the corridor at x = 4 first
+    assert neutral["plan"][0, 0] < -0.8 and neutral["plan"][0, 1] > 0.8          # diagonal, across the region without data
+    assert averse["d_pred"] < 0.8 * neutral["d_pred"]
+    assert averse["d_loop"] < 0.8 * neutral["d_loop"]
+
+
 def test_incremental_append_matches_rebuild(G, golden):
     """gpmpc_kinv_append (Schur-complement append, O(N^2)) against the reference-style full rebuild (src/gpr.py:171)."""
     z = golden("g6_gp.npz")
@@ -256,6 +339,44 @@ def test_incremental_append_matches_rebuild(G, golden):
     np.testing.assert_allclose(inc.Ky_inv.cpu().numpy(), z["Ky_inv"], rtol=0, atol=1e-9 * scale)
     f_inc, _ = inc.predict_latent_vars(z["Xp"])
     np.testing.assert_allclose(f_inc, z["f"], rtol=1e-8)
+
+
+def test_incremental_append_drift_and_hyper_change(G):
+    """260 single-observation appends through the O(N^2) path: the periodic full rebuild (every `rebuild_every` appends)
+    bounds the accumulated round-off -- the final inverse agrees with a from-scratch build like a fresh inverse does --
+    and a hyper-parameter edit between appends (the setters do not rebuild, src/gpr.py:53) makes the next append rebuild
+    everything, as the reference's append always does (src/gpr.py:122), instead of mixing old and new hypers."""
+    rng = np.random.default_rng(12)
+    X = rng.uniform(-2, 2, (300, 3))
+    y = np.sin(X).sum(axis=1) + 0.05 * rng.normal(size=300)
+    inc = G.GaussianProcessRegression(3)
+    inc.set_lambdas(np.array([1.5, 2.0, 0.8])); inc.set_sigma_f(np.array(1.2)); inc.set_sigma_n(np.array(1e-2))
+    inc.append_train_data(X[:40], y[:40])
+    rebuilds = 0
+    for i in range(40, 300):
+        v = inc._appends_since_rebuild
+        inc.append_train_data(X[i], float(y[i]), incremental=True)
+        rebuilds += int(inc._appends_since_rebuild < v)
+    assert inc.num_train == 300 and rebuilds == 260 // (inc.rebuild_every + 1)
+    ref = G.GaussianProcessRegression(3)
+    ref.set_lambdas(np.array([1.5, 2.0, 0.8])); ref.set_sigma_f(np.array(1.2)); ref.set_sigma_n(np.array(1e-2))
+    ref.append_train_data(X, y)
+    np.testing.assert_allclose(inc.Ky.cpu().numpy(), ref.Ky.cpu().numpy(), rtol=1e-13, atol=1e-15)
+    eye = torch.eye(300, dtype=torch.float64, device=inc.Ky.device)
+    res_inc = float((inc.Ky @ inc.Ky_inv - eye).abs().max())
+    res_ref = float((ref.Ky @ ref.Ky_inv - eye).abs().max())
+    assert res_inc < 20 * max(res_ref, 1e-12), (res_inc, res_ref)          # cond(Ky) ~ 1e5: both residuals ~1e-11
+    f_inc, _ = inc.predict_latent_vars(X[:20])
+    f_ref, _ = ref.predict_latent_vars(X[:20])
+    np.testing.assert_allclose(f_inc, f_ref, rtol=1e-7, atol=1e-9)
+    # hyper-parameter change, then one incremental append: everything is rebuilt with the new values
+    inc.set_lambdas(np.array([3.0, 3.0, 3.0]))
+    inc.append_train_data(np.array([0.1, 0.2, 0.3]), 0.5, incremental=True)
+    new = G.GaussianProcessRegression(3)
+    new.set_lambdas(np.array([3.0, 3.0, 3.0])); new.set_sigma_f(np.array(1.2)); new.set_sigma_n(np.array(1e-2))
+    new.append_train_data(np.vstack((X, [[0.1, 0.2, 0.3]])), np.append(y, 0.5))
+    assert inc._appends_since_rebuild == 0
+    assert torch.equal(inc.Ky, new.Ky) and torch.equal(inc.Ky_inv, new.Ky_inv)
 
 
 # ---- hyper-parameter training (SURVEY 8f-4): src/gpr.py:173-251, 334-370 -------------------------------------------
