@@ -38,6 +38,7 @@ struct gpmpc_tuning {
     int tb;          // GPMPC_PAIR_TB     1 | 2 | 4 | 0 unset
     int rgroup;      // GPMPC_RGROUP      1..16 | 0 unset
     int no_first;    // GPMPC_NO_FIRST    full moments at horizon step 1 too
+    int fused;       // GPMPC_FUSED       0: head + staged pair kernel per step for small batches | -1 unset (fused step kernel)
     int no_xcd_sort; // GPMPC_NO_XCD_SORT natural tile order of the 256x256 work list (takes effect at pack creation only)
 };
 void gpmpc_read_tuning(gpmpc_tuning* t);

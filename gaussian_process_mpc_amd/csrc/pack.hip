@@ -181,6 +181,7 @@ void gpmpc_read_tuning(gpmpc_tuning* t) {
     t->tb = geti("GPMPC_PAIR_TB", 0);
     t->rgroup = geti("GPMPC_RGROUP", 0);
     t->no_first = getenv("GPMPC_NO_FIRST") ? 1 : 0;
+    t->fused = geti("GPMPC_FUSED", -1);
     t->no_xcd_sort = getenv("GPMPC_NO_XCD_SORT") ? 1 : 0;
 }
 

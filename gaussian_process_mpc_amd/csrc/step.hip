@@ -18,6 +18,7 @@
 //   var = sf^2 - T - mu^2     (no clamp; src/tools/uncertainty_prop.py:399)
 #include "gpmpc_internal.h"
 #include "fast_exp.h"
+#include "step_fused.h"
 #include <cstdlib>
 
 struct RollArgs {
@@ -671,7 +672,7 @@ int gpmpc_timed_pair_sbf(int D, bool grad, int ns2, int waves, const PairSbfArgs
     return timed_launch(GPMPC_TIME_FULL, s, [&] { return gpmpc_launch_pair_sbf(D, grad, ns2, waves, a, s); });
 }
 
-struct RollPlan { int tiling, tb, waves, nwork, nm, pps, sps, sb, gw, rgroup; size_t off_G; size_t off_pp, off_sp, off_part, off_jac, off_means, off_vars, total; };
+struct RollPlan { int tiling, tb, waves, nwork, nm, pps, sps, sb, gw, rgroup, fused; size_t off_G; size_t off_pp, off_sp, off_part, off_partz, off_jac, off_means, off_vars, total; };
 
 static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag, RollPlan* r, bool lowprec = false) {
     const int D = p->D;
@@ -705,6 +706,10 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     if (tn.rgroup >= 1 && tn.rgroup <= 16) r->rgroup = tn.rgroup;
     if (r->tiling != 0) r->rgroup = 1;
     if (lowprec) { r->sb = 0; r->tiling = 0; r->tb = 1; }      // tolerance-sweep kernels: 256x256 work list, one trajectory per workgroup
+    // Small batches on the 64-row work lists: ONE launch per horizon step (step_fused.h) instead of head + staged pair
+    // kernel -- the B = 1 callbacks of a solver loop are pure dependent latency (GPMPC_FUSED=0 keeps the two-kernel form).
+    r->fused = (!r->sb && !lowprec && diag && (r->tiling == 1 || r->tiling == 3) && p->da <= 2 && tn.fused != 0) ? 1 : 0;
+    if (r->fused) r->tb = 1;
     r->waves = p->wl[0][r->tiling].waves;
     r->nwork = p->wl[0][r->tiling].nwork;
     r->nm = gpmpc_num_moments(D, diag, grad);
@@ -714,7 +719,8 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     auto take = [&](size_t n) { size_t o = off; off += (n * sizeof(double) + 255) & ~(size_t)255; return o; };
     r->off_pp = take((size_t)B * p->ds * r->pps);
     r->off_sp = take((size_t)2 * B * p->ds * r->sps);
-    r->off_part = take((size_t)B * r->nwork * r->nm);
+    r->off_part = take((size_t)(r->fused ? 2 : 1) * B * r->nwork * r->nm);     // fused: double-buffered by step parity
+    r->off_partz = take(r->fused ? (size_t)2 * B * r->nwork : 0);
     r->off_jac = take(grad ? (size_t)B * H * 2 * p->ds * (2 * p->ds + p->da) : 0);
     r->gw = gpmpc_sb_gw(D, p->ds);
     r->off_G = take(r->sb ? (size_t)B * p->ds * p->Np * r->gw : 0);
@@ -728,6 +734,21 @@ extern "C" size_t gpmpc_rollout_workspace_bytes(const gpmpc_pack* p, int B, int 
     RollPlan r;
     plan_rollout(p, B, H, (flags & GPMPC_WANT_GRAD) != 0, true, &r, (flags & (GPMPC_FP32_ACCUM | GPMPC_FP32_ALL)) != 0);
     return r.total;
+}
+
+template <int D> int gpmpc_launch_step_fused_D(bool grad, int ns2, const FusedArgs& a, int t, hipStream_t s);   // fused_d*.o
+static int launch_step_fused(int D, bool grad, int ns2, const FusedArgs& a, int t, hipStream_t s) {
+    switch (D) {
+        case 1: return gpmpc_launch_step_fused_D<1>(grad, ns2, a, t, s);
+        case 2: return gpmpc_launch_step_fused_D<2>(grad, ns2, a, t, s);
+        case 3: return gpmpc_launch_step_fused_D<3>(grad, ns2, a, t, s);
+        case 4: return gpmpc_launch_step_fused_D<4>(grad, ns2, a, t, s);
+        case 5: return gpmpc_launch_step_fused_D<5>(grad, ns2, a, t, s);
+        case 6: return gpmpc_launch_step_fused_D<6>(grad, ns2, a, t, s);
+        case 7: return gpmpc_launch_step_fused_D<7>(grad, ns2, a, t, s);
+        case 8: return gpmpc_launch_step_fused_D<8>(grad, ns2, a, t, s);
+    }
+    return GPMPC_E_ARG;
 }
 
 template <int D>
@@ -769,7 +790,24 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
     P.Np = p->Np; P.B = B; P.nunits = p->ds; P.nwork = r.nwork; P.pps = r.pps; P.nm = r.nm;
     P.jside_off = 0; P.ntri = p->ds; P.ns2 = p->ds; P.colsplit = (r.tiling == 1 || r.tiling == 3) ? 1 : 0;
 
-    for (int t = 1; t <= H; ++t) {
+    if (r.fused) {
+        FusedArgs F;
+        memset(&F, 0, sizeof(F));
+        const gpmpc_worklist& wl = p->wl[0][r.tiling];
+        F.XT = p->XT; F.beta = p->beta; F.lam = p->lam; F.sf = p->sf; F.M = p->M; F.work = wl.work_dev;
+        F.N = p->N; F.Np = p->Np; F.nwork = r.nwork;
+        for (int a = 0; a <= p->ds; ++a) F.ustart[a] = wl.ustart_host[a];
+        F.x0 = x0; F.U = U; F.B = B; F.H = H;
+        F.means = A.means; F.vars = A.vars; F.jac = A.jac;
+        F.sp = A.sp; F.part = A.part; F.partz = (double*)(ws + r.off_partz);
+        F.sps = r.sps; F.nm = r.nm;
+        for (int t = 1; t <= H; ++t) {
+            const int rc = timed_launch(GPMPC_TIME_FULL, s, [&] { return launch_step_fused(p->D, grad, p->ds, F, t, s); });
+            if (rc != GPMPC_OK) return rc;
+        }
+        A.part += (size_t)(H & 1) * B * r.nwork * r.nm;      // the tail finishes step H from the parity the last launch wrote
+    }
+    for (int t = 1; t <= H && !r.fused; ++t) {
         switch (p->D) {
             case 1: launch_head<1>(A, t, s); break;
             case 2: launch_head<2>(A, t, s); break;
