@@ -4,4 +4,11 @@
 #ifndef GPMPC_PAIR_D
 #error "compile with -DGPMPC_PAIR_D=<D>"
 #endif
-template int gpmpc_launch_step_fused_D<GPMPC_PAIR_D>(bool, int, const FusedArgs&, int, hipStream_t);
+template int gpmpc_launch_step_fused_D<GPMPC_PAIR_D>(bool, int, int, const FusedArgs&, int, hipStream_t);
+
+#if defined(GPMPC_FUSED_STAMPS) && GPMPC_PAIR_D == 4
+// diagnostic build: the stamps of the D = 4 instances of this translation unit
+extern "C" int gpmpc_debug_stamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_fused_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -3;
+}
+#endif

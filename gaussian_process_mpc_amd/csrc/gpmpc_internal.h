@@ -117,6 +117,23 @@ template <int D> int gpmpc_launch_pair_sbf_D(bool grad, int ns2, int waves, cons
 
 int gpmpc_launch_pair_lowprec(int D, int mode, const PairArgs& a, hipStream_t s);     // lowprec.hip (tolerance sweep)
 
+// Arguments of the fused small-batch step kernel (step_fused.h; instantiated per D in fused_d*.o)
+struct FusedArgs {
+    // pack
+    const double* XT; const double* beta; const double* lam; const double* sf; const double* M; const int* work;
+    int N, Np, nwork;                      // nwork = tile workgroups per trajectory (work items x column pieces per item)
+    int tri64;                             // the work list is the plain 64x64 upper-triangular order: decode items arithmetically
+    int ustart[GPMPC_MAX_DS + 1];          // workgroups of GP a are [ustart[a], ustart[a+1]) (64-row work lists are unit-contiguous)
+    // problem
+    const double* x0; const double* U; int B, H;
+    // outputs / state
+    double* means; double* vars; double* jac;
+    double* sp; double* part; double* partz;
+    int sps, nm;
+};
+template <int D> int gpmpc_launch_step_fused_D(bool grad, int ns2, int q, const FusedArgs& a, int t, hipStream_t s);
+
+
 // Implemented in pair_d*.hip (one translation unit per D so the build parallelises).
 int gpmpc_launch_pair(int D, bool diag, bool grad, int tb, int waves, const PairArgs& a, hipStream_t s);
 template <int D> int gpmpc_launch_pair_D(bool diag, bool grad, int tb, int waves, const PairArgs& a, hipStream_t s);

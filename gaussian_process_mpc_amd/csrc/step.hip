@@ -18,7 +18,6 @@
 //   var = sf^2 - T - mu^2     (no clamp; src/tools/uncertainty_prop.py:399)
 #include "gpmpc_internal.h"
 #include "fast_exp.h"
-#include "step_fused.h"
 #include <cstdlib>
 
 struct RollArgs {
@@ -34,6 +33,8 @@ struct RollArgs {
     double* sp;    // [2][B][ds][sps] per-GP scalars of step t at [t & 1], kept for the finish phase of the next head launch
     double* part;  // [B][nwork][nm]; work items of GP a are [ustart[a], ustart[a+1])
     const int* ustart;
+    int ust_inline;    // ust[] below replaces ustart (the fused path splits tiles into column pieces: its own item ranges)
+    int ust[GPMPC_MAX_DS + 1];
     const int* work;   // [nwork][4] when the items of a unit are NOT contiguous (XCD-sorted list), else null
     double* jac;   // [B][H][2ds][2ds+da] or null
     double* G;     // [B][ds][Np][gw] column rows of the scalar-broadcast pair kernel, or null
@@ -67,9 +68,10 @@ __device__ static void finish_step(const RollArgs& A, int b, int t, int own, dou
             double acc[NMAX];
 #pragma unroll
             for (int m = 0; m < NMAX; ++m) acc[m] = 0.0;
-            const int w0 = A.work ? 0 : A.ustart[a], w1 = A.work ? A.nwork : A.ustart[a + 1];
+            const int w0 = A.ust_inline ? A.ust[a] : (A.work ? 0 : A.ustart[a]);
+            const int w1 = A.ust_inline ? A.ust[a + 1] : (A.work ? A.nwork : A.ustart[a + 1]);
             for (int wi = w0 + lane; wi < w1; wi += 64) {
-                if (A.work && A.work[4 * wi] != a) continue;
+                if (!A.ust_inline && A.work && A.work[4 * wi] != a) continue;
                 const double* q = p + (size_t)wi * nm;
 #pragma unroll
                 for (int m = 0; m < NMAX; ++m) if (m < nm) acc[m] += q[m];
@@ -91,7 +93,9 @@ __device__ static void finish_step(const RollArgs& A, int b, int t, int own, dou
                 const int a = o / nm, m = o - a * nm;
                 const double* p = A.part + (size_t)b * A.nwork * nm + m;
                 double s = 0.0;
-                if (A.work) {
+                if (A.ust_inline) {
+                    for (int wi = A.ust[a] + ch; wi < A.ust[a + 1]; wi += GPMPC_RED_CH) s += p[(size_t)wi * nm];
+                } else if (A.work) {
                     for (int wi = ch; wi < A.nwork; wi += GPMPC_RED_CH) if (A.work[4 * wi] == a) s += p[(size_t)wi * nm];
                 } else {
                     for (int wi = A.ustart[a] + ch; wi < A.ustart[a + 1]; wi += GPMPC_RED_CH) s += p[(size_t)wi * nm];
@@ -672,7 +676,7 @@ int gpmpc_timed_pair_sbf(int D, bool grad, int ns2, int waves, const PairSbfArgs
     return timed_launch(GPMPC_TIME_FULL, s, [&] { return gpmpc_launch_pair_sbf(D, grad, ns2, waves, a, s); });
 }
 
-struct RollPlan { int tiling, tb, waves, nwork, nm, pps, sps, sb, gw, rgroup, fused; size_t off_G; size_t off_pp, off_sp, off_part, off_partz, off_jac, off_means, off_vars, total; };
+struct RollPlan { int tiling, tb, waves, nwork, nm, pps, sps, sb, gw, rgroup, fused, fq; size_t off_G; size_t off_pp, off_sp, off_part, off_partz, off_jac, off_means, off_vars, total; };
 
 static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag, RollPlan* r, bool lowprec = false) {
     const int D = p->D;
@@ -710,6 +714,8 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     // kernel -- the B = 1 callbacks of a solver loop are pure dependent latency (GPMPC_FUSED=0 keeps the two-kernel form).
     r->fused = (!r->sb && !lowprec && diag && (r->tiling == 1 || r->tiling == 3) && p->da <= 2 && tn.fused != 0) ? 1 : 0;
     if (r->fused) r->tb = 1;
+    // a quarter of a tile's columns per workgroup while whole tiles would leave most SIMDs without a wave
+    r->fq = (r->fused && r->tiling == 1 && (long)B * p->wl[0][1].nwork < 256) ? 4 : 1;
     r->waves = p->wl[0][r->tiling].waves;
     r->nwork = p->wl[0][r->tiling].nwork;
     r->nm = gpmpc_num_moments(D, diag, grad);
@@ -719,8 +725,8 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     auto take = [&](size_t n) { size_t o = off; off += (n * sizeof(double) + 255) & ~(size_t)255; return o; };
     r->off_pp = take((size_t)B * p->ds * r->pps);
     r->off_sp = take((size_t)2 * B * p->ds * r->sps);
-    r->off_part = take((size_t)(r->fused ? 2 : 1) * B * r->nwork * r->nm);     // fused: double-buffered by step parity
-    r->off_partz = take(r->fused ? (size_t)2 * B * r->nwork : 0);
+    r->off_part = take((size_t)(r->fused ? 2 * r->fq : 1) * B * r->nwork * r->nm);     // fused: double-buffered by step parity
+    r->off_partz = take(r->fused ? (size_t)2 * r->fq * B * r->nwork : 0);
     r->off_jac = take(grad ? (size_t)B * H * 2 * p->ds * (2 * p->ds + p->da) : 0);
     r->gw = gpmpc_sb_gw(D, p->ds);
     r->off_G = take(r->sb ? (size_t)B * p->ds * p->Np * r->gw : 0);
@@ -736,17 +742,16 @@ extern "C" size_t gpmpc_rollout_workspace_bytes(const gpmpc_pack* p, int B, int 
     return r.total;
 }
 
-template <int D> int gpmpc_launch_step_fused_D(bool grad, int ns2, const FusedArgs& a, int t, hipStream_t s);   // fused_d*.o
-static int launch_step_fused(int D, bool grad, int ns2, const FusedArgs& a, int t, hipStream_t s) {
+static int launch_step_fused(int D, bool grad, int ns2, int q, const FusedArgs& a, int t, hipStream_t s) {
     switch (D) {
-        case 1: return gpmpc_launch_step_fused_D<1>(grad, ns2, a, t, s);
-        case 2: return gpmpc_launch_step_fused_D<2>(grad, ns2, a, t, s);
-        case 3: return gpmpc_launch_step_fused_D<3>(grad, ns2, a, t, s);
-        case 4: return gpmpc_launch_step_fused_D<4>(grad, ns2, a, t, s);
-        case 5: return gpmpc_launch_step_fused_D<5>(grad, ns2, a, t, s);
-        case 6: return gpmpc_launch_step_fused_D<6>(grad, ns2, a, t, s);
-        case 7: return gpmpc_launch_step_fused_D<7>(grad, ns2, a, t, s);
-        case 8: return gpmpc_launch_step_fused_D<8>(grad, ns2, a, t, s);
+        case 1: return gpmpc_launch_step_fused_D<1>(grad, ns2, q, a, t, s);
+        case 2: return gpmpc_launch_step_fused_D<2>(grad, ns2, q, a, t, s);
+        case 3: return gpmpc_launch_step_fused_D<3>(grad, ns2, q, a, t, s);
+        case 4: return gpmpc_launch_step_fused_D<4>(grad, ns2, q, a, t, s);
+        case 5: return gpmpc_launch_step_fused_D<5>(grad, ns2, q, a, t, s);
+        case 6: return gpmpc_launch_step_fused_D<6>(grad, ns2, q, a, t, s);
+        case 7: return gpmpc_launch_step_fused_D<7>(grad, ns2, q, a, t, s);
+        case 8: return gpmpc_launch_step_fused_D<8>(grad, ns2, q, a, t, s);
     }
     return GPMPC_E_ARG;
 }
@@ -795,17 +800,20 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
         memset(&F, 0, sizeof(F));
         const gpmpc_worklist& wl = p->wl[0][r.tiling];
         F.XT = p->XT; F.beta = p->beta; F.lam = p->lam; F.sf = p->sf; F.M = p->M; F.work = wl.work_dev;
-        F.N = p->N; F.Np = p->Np; F.nwork = r.nwork;
-        for (int a = 0; a <= p->ds; ++a) F.ustart[a] = wl.ustart_host[a];
+        const int nwg = r.nwork * r.fq;                     // tile workgroups per trajectory
+        F.N = p->N; F.Np = p->Np; F.nwork = nwg;
+        F.tri64 = (r.tiling == 1) ? 1 : 0;                  // 64x64 list: items decoded arithmetically (no dependent load)
+        for (int a = 0; a <= p->ds; ++a) { F.ustart[a] = wl.ustart_host[a] * r.fq; A.ust[a] = F.ustart[a]; }
+        A.ust_inline = 1; A.nwork = nwg;
         F.x0 = x0; F.U = U; F.B = B; F.H = H;
         F.means = A.means; F.vars = A.vars; F.jac = A.jac;
         F.sp = A.sp; F.part = A.part; F.partz = (double*)(ws + r.off_partz);
         F.sps = r.sps; F.nm = r.nm;
         for (int t = 1; t <= H; ++t) {
-            const int rc = timed_launch(GPMPC_TIME_FULL, s, [&] { return launch_step_fused(p->D, grad, p->ds, F, t, s); });
+            const int rc = timed_launch(GPMPC_TIME_FULL, s, [&] { return launch_step_fused(p->D, grad, p->ds, r.fq, F, t, s); });
             if (rc != GPMPC_OK) return rc;
         }
-        A.part += (size_t)(H & 1) * B * r.nwork * r.nm;      // the tail finishes step H from the parity the last launch wrote
+        A.part += (size_t)(H & 1) * B * nwg * r.nm;          // the tail finishes step H from the parity the last launch wrote
     }
     for (int t = 1; t <= H && !r.fused; ++t) {
         switch (p->D) {

@@ -7,111 +7,256 @@
 // in-kernel hand-off (release fence + ticket + acquire fence) costs what a kernel boundary costs (MI355X: ~1.7 us per
 // fence).  Instead every workgroup of launch t recomputes the cheap part of the old head itself -- the Z0 sums of step
 // t-1, hence the input variances of step t -- from a compact array the previous launch wrote, and the rest of the head
-// (mean sums over the N points, Jacobian rows of step t-1) runs in ds extra workgroups of the SAME launch, beside the
-// tiles instead of before them.  Nothing inside a launch depends on another workgroup of that launch.
+// runs in 2 ds extra workgroups of the SAME launch, beside the tiles instead of before them.  Nothing inside a launch
+// depends on another workgroup of that launch.
 //
-//   grid = (nwork + ds, B) x 256 threads
-//   blockIdx.x <  nwork : tile (unit a, 64 rows x 64|128 columns) of the N^2 sum of step t      (pair_kernel.h, staged form)
-//   blockIdx.x >= nwork : GP a: finish step t-1 (means / vars / Jacobian rows), mean sums of step t (step.hip::prep_step)
+//   grid = (nwg + 2 ds, B) x 256 threads
+//   blockIdx.x <  nwg          : piece of a tile (GP a, 64 rows x 64|128 columns) of the N^2 sum of step t (pair_kernel.h, staged
+//                                form).  Q = 4 while whole tiles would leave most SIMDs without a wave: a workgroup then takes
+//                                16 of a tile's 64 columns, 4 per wave (a workgroup is confined to one CU: more waves per
+//                                workgroup do not spread the column loop, more workgroups do); else Q = 1, 16 columns per wave
+//   nwg      <= .. < nwg + ds  : GP a: mean sums of step t over the N points                     (step.hip::prep_step)
+//   nwg + ds <= ..             : GP a: outputs and Jacobian rows of step t-1                     (step.hip::finish_step);
+//                                nothing in the next launch waits for these, only the tail kernel does
+//
+// Inside a workgroup every global load that depends on nothing computed in this launch is issued FIRST, into registers
+// (tile rows and columns, weights, the previous step's Z0 partials and scalars, the exp table, whose LDS write is
+// deferred), so that the chain is one memory round trip, then arithmetic.  In-kernel timeline of an earlier form
+// (s_memtime, N = 512, 16-wave workgroups): 16.8 k cycles per launch, of which 3.4 k waited on the table copy, 2.6 k on
+// the Z0 partials and 5.5 k in the reduction of the 16 waves of a workgroup (tools/fused_stamps.py, profiles/r02/README.md).
 //
 // Reference restated: Dynamics.forward_propagate_torch (src/dynamics.py:145-189), mean_prop_torch / variance_prop_torch
 // (src/tools/uncertainty_prop.py:296-399), exactly as step.hip / pair_kernel.h do; the closed forms are in step.hip.
-// State between launches (double-buffered by step parity): sp [2][B][ds][sps], part [2][B][nwork][nm], partz [2][B][nwork].
+// State between launches (double-buffered by step parity): sp [2][B][ds][sps], part [2][B][nwg][nm], partz [2][B][nwg].
 #pragma once
 #include "gpmpc_internal.h"
 #include "fast_exp.h"
 
-struct FusedArgs {
-    // pack
-    const double* XT; const double* beta; const double* lam; const double* sf; const double* M; const int* work;
-    int N, Np, nwork;
-    int ustart[GPMPC_MAX_DS + 1];          // items of GP a are [ustart[a], ustart[a+1]) (64-row work lists are unit-contiguous)
-    // problem
-    const double* x0; const double* U; int B, H;
-    // outputs / state
-    double* means; double* vars; double* jac;
-    double* sp; double* part; double* partz;
-    int sps, nm;
-};
+// Item q of the 64x64 upper-triangular list of one unit (pack.hip::build_worklist: row tile r, then column tile c >= r;
+// T tiles per side): r is the largest row with start(r) = r T - r (r - 1) / 2 <= q.  Saves the dependent load of the item.
+__device__ __forceinline__ void gpmpc_tri_decode(int q, int T, int* r_out, int* c_out) {
+    const float tt = 2.0f * T + 1.0f;
+    int r = (int)((tt - sqrtf(tt * tt - 8.0f * (float)q)) * 0.5f);
+    r = r < 0 ? 0 : (r > T - 1 ? T - 1 : r);
+    while (r > 0 && r * T - r * (r - 1) / 2 > q) --r;
+    while (r + 1 < T && (r + 1) * T - (r + 1) * r / 2 <= q) ++r;
+    *r_out = r;
+    *c_out = r + (q - (r * T - r * (r - 1) / 2));
+}
+
+// Diagnostic build only (-DGPMPC_FUSED_STAMPS): s_memtime stamps of the phases of one tile workgroup and of the mean-sum
+// workgroup of GP 0 at horizon step 5, read back with gpmpc_debug_stamps (tools/fused_stamps.py).  The product build
+// executes no stamp.
+#ifdef GPMPC_FUSED_STAMPS
+static __device__ unsigned long long g_fused_stamps[64];
+#define GPMPC_STAMP(slot) do { if (t == 5 && blockIdx.y == 0 && tid == 0 && (blockIdx.x == 0 || (int)blockIdx.x == A.nwork)) \
+    g_fused_stamps[(blockIdx.x == 0 ? 0 : 16) + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GPMPC_STAMP(slot) do { } while (0)
+#endif
+
+// The tile pieces of this kernel evaluate 4..16 columns per wave: copying the 16 KB exp table into LDS per workgroup (7 MB
+// per launch at N = 512, most of the burst every workgroup opens with) costs more than the ~12 extra fp64 instructions per
+// pair of the table-free exp.  GPMPC_FUSED_TABLE=1 restores the table (A/B).
+#ifndef GPMPC_FUSED_TABLE
+#define GPMPC_FUSED_TABLE 0
+#endif
+#define GPMPC_FUSED_PZ 4        // Z0 partials of one GP prefetched per thread: covers 256 * 4 workgroups per GP
 
 // layout of sp (doubles), as step.hip: 0 c | 1 mu | 2 sf2 | 3 A[D] | 3+D scale[D] | 3+2D dmu_du[D] | 3+3D dmu_ds[D]
-template <int D, int NS2, bool GRAD>
+template <int D, int NS2, bool GRAD, int Q>
 __global__ __launch_bounds__(256) void k_step_fused(FusedArgs A, int t) {
     constexpr int DS = NS2, DA = D - NS2, NM = GRAD ? 1 + 2 * D : 1, DP = (D + 1) & ~1;
-    constexpr int NV = 1 + 2 * D;
+    constexpr int NV = 1 + 2 * D, NT = 256, CW = 16 / Q, NCOL = 64 / Q;            // NCOL columns of a chunk per workgroup
+    constexpr int TABN = GPMPC_EXP_N / NT; (void)TABN;
+#if GPMPC_FUSED_TABLE
     __shared__ double s_tab[GPMPC_EXP_N];
-    __shared__ __attribute__((aligned(16))) double s_hj[64 * DP];
-    __shared__ double s_red[16 * NV > 4 * NM ? 16 * NV : 4 * NM];
+#endif
+    __shared__ __attribute__((aligned(16))) double s_hj[NCOL * DP];
+    __shared__ double s_red[16 * NV];
     __shared__ double s_out[NV];
-    __shared__ double s_z4[GPMPC_MAX_DS * 4];
-    __shared__ double s_mu[GPMPC_MAX_DS], s_var[GPMPC_MAX_DS], s_z0[GPMPC_MAX_DS], s_c[GPMPC_MAX_DS], s_sf2[GPMPC_MAX_DS];
-    __shared__ double s_lam[GPMPC_MAX_DS * D], s_uact[DA > 0 ? DA : 1], s_spp[4 * D];
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const bool is_mean = (int)blockIdx.x >= A.nwork;
+    __shared__ double s_zw[GPMPC_MAX_DS];
+    __shared__ double s_mu[GPMPC_MAX_DS], s_var[GPMPC_MAX_DS], s_z0[GPMPC_MAX_DS], s_c[GPMPC_MAX_DS];
+    __shared__ double s_spp[4 * D];
+    __shared__ double s_uin[D], s_sin[D], s_sck[D], s_cv[D];     // input moments of step t and the pair transform h = sc (u - x)
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int role = (int)blockIdx.x < A.nwork ? 0 : ((int)blockIdx.x < A.nwork + DS ? 1 : 2);     // tile | mean sums | finish
     const int Np = A.Np, pprev = (t - 1) & 1, pcur = t & 1;
-    const int am = (int)blockIdx.x - A.nwork;                      // GP of a mean workgroup
+    const int am = role == 1 ? (int)blockIdx.x - A.nwork : (int)blockIdx.x - A.nwork - DS;         // GP of a non-tile workgroup
 
-    // ---- phase 0: every load that depends on nothing computed in this launch is issued first ----------------------
-    int unit = 0, i0 = 0, j0 = 0, j1 = 0;
-    double xrow[D], xcol[D], mpre[16];
-    if (!is_mean) {
-        const int4 wk = reinterpret_cast<const int4*>(A.work)[blockIdx.x];
-        unit = wk.x; i0 = wk.y; j0 = wk.z; j1 = wk.w;
-        gpmpc_exp_table_to_lds(s_tab);
+    // All kernel arguments used below are read HERE, unconditionally (the empty asm is an unconditional use): left to
+    // itself the compiler loads each field inside the branch that first needs it, one s_load + s_waitcnt after the other
+    // (ten dependent scalar round trips, ~3 k cycles of the 4.8 k this phase took before).
+    asm volatile("" ::"s"(A.XT), "s"(A.beta), "s"(A.lam), "s"(A.sf), "s"(A.M), "s"(A.work), "s"(A.x0), "s"(A.U));
+    asm volatile("" ::"s"(A.means), "s"(A.vars), "s"(A.jac), "s"(A.sp), "s"(A.part), "s"(A.partz), "s"(A.Np), "s"(A.nwork),
+                 "s"(A.tri64), "s"(A.B), "s"(A.H), "s"(A.sps), "s"(A.nm));
+    int ust[DS + 1];
+#pragma unroll
+    for (int a = 0; a <= DS; ++a) { ust[a] = A.ustart[a]; asm volatile("" ::"s"(ust[a])); }
+    GPMPC_STAMP(0);
+#ifdef GPMPC_FUSED_STAMPS
+    {   // diagnostic: latency of ONE read-only load (length-scales), ONE load of data the previous launch wrote (partz), alone
+        const double probe1 = __builtin_nontemporal_load(A.lam);
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(probe1));
+        GPMPC_STAMP(8);
+        const double probe2 = __builtin_nontemporal_load(A.partz + ((size_t)((t - 1) & 1) * A.B + blockIdx.y) * A.nwork);
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(probe2));
+        GPMPC_STAMP(9);
+        const double probe3 = __builtin_nontemporal_load(A.M + 64 * (size_t)A.Np + tid);
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(probe3));
+        GPMPC_STAMP(10);
+    }
+#endif
+    // ---- phase 0: every load that depends on nothing computed in this launch, issued back to back into registers.
+    //      Per-thread conditions are turned into clamped addresses + selects: a load under a divergent branch is
+    //      followed by its own s_waitcnt, which serialises the round trips. ---------------------------------------------------
+    int unit = 0, i0 = 0, j0 = 0, j1 = 0, jq = 0;
+    double xrow[D], xcol[D], mpre[CW];
+#if GPMPC_FUSED_TABLE
+    double tabreg[TABN];
+#endif
+    if (role == 0) {
+        const int item = (int)blockIdx.x / Q;
+        jq = ((int)blockIdx.x - item * Q) * NCOL;                                     // this workgroup's columns of every chunk
+        if (A.tri64) {
+            const int T = Np >> 6, per = T * (T + 1) / 2;
+            unit = item / per;
+            int r, c;
+            gpmpc_tri_decode(item - unit * per, T, &r, &c);
+            i0 = r << 6; j0 = c << 6; j1 = j0 + 64;
+        } else {
+            const int* wk = A.work + 4 * item;                                        // uniform address: scalar loads
+            unit = wk[0]; i0 = wk[1]; j0 = wk[2]; j1 = wk[3];
+        }
+    }
+    const int a_own = role == 0 ? unit : am;                        // the GP whose length-scales this workgroup needs
+    // Load-instruction diet: a CU's vector memory path moves 64 B per clock, so every wave-wide load costs ~8 cycles of it
+    // whatever it fetches; with 120 of them per workgroup (4 waves x 30) the opening burst took 3.7 k cycles (in-kernel
+    // stamps), against ~500 for one load alone.  Per-dimension scalars are therefore loaded by wave 0 only, and the Z0
+    // partials of GP a by wave a % 4 only (which then reduces them without a cross-wave combine).
+    const int kd = lane < D ? lane : D - 1, kg = lane < DS ? lane : DS - 1;
+    double lam_k = 0.0, sp_c = 0.0, sp_mu = 0.0, sp_sf2 = 0.0, u_act = 0.0, spp_v = 0.0;
+    if (w == 0) {                                                   // wave-uniform branch: no exec masking, no wait
+        lam_k = A.lam[a_own * D + kd];
+        if (t > 1) {
+            const double* sp = A.sp + (((size_t)pprev * A.B + b) * DS + kg) * A.sps;
+            sp_c = sp[0]; sp_mu = sp[1]; sp_sf2 = sp[2];
+        } else {
+            sp_mu = A.x0[(size_t)b * DS + kg];
+        }
+        if (DA > 0) u_act = A.U[((size_t)b * A.H + (t - 1)) * DA + (lane >= DS && lane < D ? lane - DS : 0)];
+    }
+    if (role == 2 && t > 1 && GRAD && w == 1)                       // A, scale, dmu_du, dmu_ds of step t-1 (4 D <= 32 values)
+        spp_v = A.sp[(((size_t)pprev * A.B + b) * DS + am) * A.sps + 3 + (lane < 4 * D ? lane : 4 * D - 1)];
+    // Z0 partials of step t-1: wave a % 4 fetches those of GP a, GPMPC_FUSED_PZ per lane up front (covers 256 workgroups
+    // per GP, i.e. every configuration with column pieces; more are looped over in phase 1)
+    double pzr[(DS + 3) / 4][GPMPC_FUSED_PZ];
+    const double* pz = A.partz + ((size_t)pprev * A.B + b) * A.nwork;
+    if (t > 1) {
+#pragma unroll
+        for (int g = 0; g < (DS + 3) / 4; ++g) {
+            const int a = w + 4 * g;                                // wave-uniform
+            if (a < DS) {
+#pragma unroll
+                for (int r = 0; r < GPMPC_FUSED_PZ; ++r) {
+                    const int wi = ust[a < DS ? a : 0] + lane + r * 64;
+                    const int we = ust[a < DS ? a + 1 : 1];
+                    const double v = pz[wi < we ? wi : ust[a < DS ? a : 0]];           // clamped: always a valid address
+                    pzr[g][r] = wi < we ? v : 0.0;
+                }
+            }
+        }
+    }
+    if (role == 0) {
 #pragma unroll
         for (int k = 0; k < D; ++k) xrow[k] = A.XT[(size_t)k * Np + i0 + lane];      // the 4 waves share the tile's 64 rows
         const int jfirst = (j0 + 63 < i0) ? j0 + 64 : j0;                             // first column chunk that carries weight
-        if (tid < 64) {
+        if (w == 0) {                                                                 // the columns are staged by wave 0
+            const int jcol = jfirst + jq + (lane < NCOL ? lane : 0);
 #pragma unroll
-            for (int k = 0; k < D; ++k) xcol[k] = A.XT[(size_t)k * Np + jfirst + tid];
+            for (int k = 0; k < D; ++k) xcol[k] = A.XT[(size_t)k * Np + jcol];
         }
-        const double* Mc = A.M + (size_t)unit * Np * Np + (size_t)jfirst * Np + i0 + lane;
+        const double* Mc = A.M + (size_t)unit * Np * Np + (size_t)(jfirst + jq) * Np + i0 + lane;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) mpre[q] = Mc[(size_t)(w * 16 + q) * Np];
+        for (int q = 0; q < CW; ++q) mpre[q] = Mc[(size_t)(w * CW + q) * Np];
     }
-    if (tid < DS * D) s_lam[tid] = A.lam[tid];
-    if (DA > 0 && tid < DA) s_uact[tid] = A.U[((size_t)b * A.H + (t - 1)) * DA + tid];
-    double sp_c = 0.0, sp_mu = 0.0, sp_sf2 = 0.0;
-    if (t > 1 && tid < DS) {
-        const double* sp = A.sp + (((size_t)pprev * A.B + b) * DS + tid) * A.sps;
-        sp_c = sp[0]; sp_mu = sp[1]; sp_sf2 = sp[2];
+#if GPMPC_FUSED_TABLE
+    if (role == 0) {
+#pragma unroll
+        for (int r = 0; r < TABN; ++r) tabreg[r] = gpmpc_exp2_table[tid + r * NT];   // LDS write deferred: see below
     }
-    if (is_mean && t > 1 && GRAD && tid < 4 * D)                                     // A, scale, dmu_du, dmu_ds of step t-1
-        s_spp[tid] = A.sp[(((size_t)pprev * A.B + b) * DS + am) * A.sps + 3 + tid];
+#endif
+    // mean sums: this thread's first points (the loop below loads the ones beyond)
+    constexpr int PF = 2;
+    double xpt[PF][D], bpt[PF], sf_a = 0.0;
+    if (role == 1) {
+#pragma unroll
+        for (int r = 0; r < PF; ++r) {
+            const int i = tid + r * NT, ic = i < Np ? i : 0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) xpt[r][k] = A.XT[(size_t)k * Np + ic];
+            const double bv = A.beta[(size_t)am * Np + ic];
+            bpt[r] = i < Np ? bv : 0.0;
+        }
+        sf_a = A.sf[am];
+    }
+    GPMPC_STAMP(1);
 
-    // ---- phase 1: mean and variance of step t-1 for ALL GPs, identically in every workgroup ------------------------
-    if (t == 1) {
-        if (tid < DS) { s_mu[tid] = A.x0[(size_t)b * DS + tid]; s_var[tid] = GPMPC_INIT_VAR; }
-    } else {
-        const double* pz = A.partz + ((size_t)pprev * A.B + b) * A.nwork;
+    // ---- phase 1: mean and variance of step t-1 for ALL GPs, identically in every workgroup; thread k < D goes straight on
+    //      to the scalars of ITS input dimension, so that one barrier publishes everything ----------------------------------
+    if (role == 2 && t > 1 && GRAD && w == 1 && lane < 4 * D) s_spp[lane] = spp_v;
+    if (t > 1) {
 #pragma unroll
-        for (int a = 0; a < DS; ++a) {
-            double s = 0.0;
-            for (int wi = A.ustart[a] + tid; wi < A.ustart[a + 1]; wi += 256) s += pz[wi];
-            s = wave_sum(s);
-            if (lane == 0) s_z4[a * 4 + w] = s;
+        for (int g = 0; g < (DS + 3) / 4; ++g) {
+            const int a = w + 4 * g;
+            if (a < DS) {                                           // wave-uniform: wave a % 4 owns GP a's Z0 sum, fixed order
+                double s = 0.0;
+#pragma unroll
+                for (int r = 0; r < GPMPC_FUSED_PZ; ++r) s += pzr[g][r];
+                for (int wi = ust[a < DS ? a : 0] + lane + GPMPC_FUSED_PZ * 64; wi < ust[a < DS ? a + 1 : 1]; wi += 64) s += pz[wi];
+                s = wave_sum(s);
+                if (lane == 0) s_zw[a] = s;
+            }
         }
         __syncthreads();
-        if (tid < DS) {
-            const double z0 = (s_z4[tid * 4] + s_z4[tid * 4 + 1]) + (s_z4[tid * 4 + 2] + s_z4[tid * 4 + 3]);
-            s_mu[tid] = sp_mu; s_z0[tid] = z0; s_c[tid] = sp_c; s_sf2[tid] = sp_sf2;
-            s_var[tid] = sp_sf2 - sp_c * z0 - sp_mu * sp_mu;          // no clamp (src/tools/uncertainty_prop.py:399)
-        }
     }
+    GPMPC_STAMP(2);
+    if (tid < D) {
+        const int k = tid;
+        double uk, sk;
+        if (k < DS) {
+            if (t == 1) { uk = sp_mu; sk = GPMPC_INIT_VAR; }
+            else {
+                const int kk = k < DS ? k : 0;
+                const double z0 = s_zw[kk];
+                uk = sp_mu;
+                sk = sp_sf2 - sp_c * z0 - sp_mu * sp_mu;          // no clamp (src/tools/uncertainty_prop.py:399)
+                s_z0[kk] = z0; s_c[kk] = sp_c;
+            }
+            s_mu[k < DS ? k : 0] = uk; s_var[k < DS ? k : 0] = sk;
+        } else {
+            uk = u_act; sk = GPMPC_ACTION_VAR;                    // src/dynamics.py:162
+        }
+        s_uin[k] = uk; s_sin[k] = sk;
+        const double sc = sqrt(0.125 / (0.5 * lam_k + sk));       // (thread k < D sits in wave 0, which loaded lam_k, sp_*, u_act)
+        s_sck[k] = sc;
+        s_cv[k] = sc * uk;
+    }
+#if GPMPC_FUSED_TABLE
+    if (role == 0) {
+#pragma unroll
+        for (int r = 0; r < TABN; ++r) s_tab[tid + r * NT] = tabreg[r];
+    }
+#endif
     __syncthreads();
+    GPMPC_STAMP(3);
 
-    if (!is_mean) {
-        // ---- tile of the N^2 sum of step t (staged form of pair_kernel.h: diagonal S, one trajectory, column split) ----
-        const int a = unit;
+    if (role == 0) {
+        // ---- piece of a tile of the N^2 sum of step t (staged form of pair_kernel.h: diagonal S, one trajectory) ------------
         double hi[D], sck[D], cv[D];
 #pragma unroll
-        for (int k = 0; k < D; ++k) {
-            const double uk = k < DS ? s_mu[k < DS ? k : 0] : s_uact[k >= DS ? k - DS : 0];
-            const double sk = k < DS ? s_var[k < DS ? k : 0] : GPMPC_ACTION_VAR;
-            sck[k] = sqrt(0.125 / (0.5 * s_lam[a * D + k] + sk));     // same expression as the mean workgroup stores in sp
-            cv[k] = sck[k] * uk;
-            hi[k] = fma(-sck[k], xrow[k], cv[k]);
-        }
+        for (int k = 0; k < D; ++k) { sck[k] = s_sck[k]; cv[k] = s_cv[k]; hi[k] = fma(-sck[k], xrow[k], cv[k]); }
         double acc[NM];
 #pragma unroll
         for (int m = 0; m < NM; ++m) acc[m] = 0.0;
@@ -119,31 +264,36 @@ __global__ __launch_bounds__(256) void k_step_fused(FusedArgs A, int t) {
         bool first = true;
         for (int jc = j0; jc < j1; jc += 64) {
             if (jc + 63 < i0) continue;                               // upper-triangular M: nothing left of the diagonal chunk
-            __syncthreads();
-            if (tid < 64) {
+            if (!first) __syncthreads();                              // the previous chunk's s_hj has been consumed
+            if (tid < NCOL) {
                 double x[D];
 #pragma unroll
-                for (int k = 0; k < D; ++k) x[k] = first ? xcol[k] : A.XT[(size_t)k * Np + jc + tid];
+                for (int k = 0; k < D; ++k) x[k] = first ? xcol[k] : A.XT[(size_t)k * Np + jc + jq + tid];
 #pragma unroll
                 for (int k = 0; k < D; ++k) s_hj[tid * DP + k] = fma(-sck[k], x[k], cv[k]);
             }
             if (!first) {                                             // the first chunk's weights were fetched in phase 0
-                const double* __restrict__ Mc = Ma + (size_t)jc * Np + i0 + lane;
+                const double* __restrict__ Mc = Ma + (size_t)(jc + jq) * Np + i0 + lane;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) mpre[q] = Mc[(size_t)(w * 16 + q) * Np];
+                for (int q = 0; q < CW; ++q) mpre[q] = Mc[(size_t)(w * CW + q) * Np];
             }
             first = false;
             __syncthreads();
+            GPMPC_STAMP(4);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const double* hj = &s_hj[(w * 16 + q) * DP];
+            for (int q = 0; q < CW; ++q) {
+                const double* hj = &s_hj[(w * CW + q) * DP];
                 double m[D], sq[D];
 #pragma unroll
                 for (int k = 0; k < D; ++k) { m[k] = hi[k] + hj[k]; sq[k] = m[k] * m[k]; }
                 double s = sq[0];
 #pragma unroll
                 for (int k = 1; k < D; ++k) s += sq[k];
+#if GPMPC_FUSED_TABLE
                 const double P = mpre[q] * gpmpc_exp_neg(s, s_tab);
+#else
+                const double P = mpre[q] * exp(-s);
+#endif
                 acc[0] += P;
                 if (GRAD) {
 #pragma unroll
@@ -154,93 +304,103 @@ __global__ __launch_bounds__(256) void k_step_fused(FusedArgs A, int t) {
                 }
             }
         }
-        __syncthreads();
+        GPMPC_STAMP(5);
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
             const double s = wave_sum(acc[m]);
             if (lane == 0) s_red[w * NM + m] = s;
         }
         __syncthreads();
+        GPMPC_STAMP(6);
         if (tid < NM) {
             const double s = (s_red[tid] + s_red[NM + tid]) + (s_red[2 * NM + tid] + s_red[3 * NM + tid]);
             A.part[(((size_t)pcur * A.B + b) * A.nwork + blockIdx.x) * A.nm + tid] = s;
             if (tid == 0) A.partz[((size_t)pcur * A.B + b) * A.nwork + blockIdx.x] = s;
         }
+        GPMPC_STAMP(7);
         return;
     }
 
-    // ---- GP `am`: finish step t-1 (outputs + Jacobian rows), then the mean sums of step t ----------------------------
     const int a = am;
-    if (t == 1) {
-        if (a == 0 && tid < DS) {
-            A.means[((size_t)b * (A.H + 1)) * DS + tid] = s_mu[tid];
-            A.vars[((size_t)b * (A.H + 1)) * DS + tid] = GPMPC_INIT_VAR;
-        }
-    } else {
-        if (GRAD) {
-            // moments 1..NM-1 of GP a: thread = (moment, channel), 16 channels stride the items; fixed-order combine
-            const int ch = tid & 15;
-            for (int m = tid >> 4; m < NM; m += 16) {
-                const double* p = A.part + (((size_t)pprev * A.B + b) * A.nwork) * A.nm + m;
-                double s = 0.0;
-                for (int wi = A.ustart[a] + ch; wi < A.ustart[a + 1]; wi += 16) s += p[(size_t)wi * A.nm];
-                s_red[m * 16 + ch] = s;
+    if (role == 2) {
+        // ---- GP a: outputs and Jacobian rows of step t-1 (step.hip::finish_step) ---------------------------------------
+        if (t == 1) {
+            if (a == 0 && tid < DS) {
+                A.means[((size_t)b * (A.H + 1)) * DS + tid] = s_mu[tid];
+                A.vars[((size_t)b * (A.H + 1)) * DS + tid] = GPMPC_INIT_VAR;
             }
-            __syncthreads();
-            if (tid < NM) {
-                double s = 0.0;
-                for (int c = 0; c < 16; ++c) s += s_red[tid * 16 + c];
-                s_out[tid] = s;
-            }
-            __syncthreads();
+            return;
         }
         if (tid == 0) {
-            const double mu = s_mu[a], var = s_var[a];
-            A.means[((size_t)b * (A.H + 1) + (t - 1)) * DS + a] = mu;
-            A.vars[((size_t)b * (A.H + 1) + (t - 1)) * DS + a] = var;
+            A.means[((size_t)b * (A.H + 1) + (t - 1)) * DS + a] = s_mu[a];
+            A.vars[((size_t)b * (A.H + 1) + (t - 1)) * DS + a] = s_var[a];
         }
-        if (GRAD && tid < D) {
+        if (!GRAD) return;
+        // moments 1..NM-1 of GP a: thread = (moment, channel), 16 channels stride the items; fixed-order combine
+        const int ch = tid & 15;
+        for (int m = tid >> 4; m < NM; m += NT / 16) {
+            const double* p = A.part + (((size_t)pprev * A.B + b) * A.nwork) * A.nm + m;
+            double s = 0.0;
+            for (int wi = A.ustart[a] + ch; wi < A.ustart[a + 1]; wi += 16) s += p[(size_t)wi * A.nm];
+            s_red[m * 16 + ch] = s;
+        }
+        __syncthreads();
+        if (tid < NM) {
+            double s = 0.0;
+            for (int c = 0; c < 16; ++c) s += s_red[tid * 16 + c];
+            s_out[tid] = s;
+        }
+        __syncthreads();
+        if (tid < D) {
             const int k = tid, nc = 2 * DS + DA;
             const double c = s_c[a], mu = s_mu[a], T = c * s_z0[a];  // the Z0 sum every workgroup of this launch uses
             const double Ak = s_spp[k], sc = s_spp[D + k], dmu_du = s_spp[2 * D + k], dmu_ds = s_spp[3 * D + k];
-            const double dT_du = -4.0 * sc * c * s_out[1 + k];
+            const double dT_du = -4.0 * sc * c * s_out[GRAD ? 1 + k : 0];
             const double dv_du = -dT_du - 2.0 * mu * dmu_du;
             double* jm = A.jac + (((size_t)b * A.H + (t - 2)) * 2 * DS + a) * nc;          // row of mu_a (step t-1)
             double* jv = A.jac + (((size_t)b * A.H + (t - 2)) * 2 * DS + DS + a) * nc;     // row of var_a
             if (k < DS) {
-                const double dT_ds = Ak * (c * s_out[1 + D + (k < NS2 ? k : 0)] - 0.5 * T);
+                const double dT_ds = Ak * (c * s_out[GRAD ? 1 + D + (k < NS2 ? k : 0) : 0] - 0.5 * T);
                 const double dv_ds = -dT_ds - 2.0 * mu * dmu_ds;
                 jm[k] = dmu_du; jm[DS + k] = dmu_ds;
                 jv[k] = dv_du;  jv[DS + k] = dv_ds;
-            } else {
+            } else {            // action input: its variance is a constant
                 jm[2 * DS + (k - DS)] = dmu_du;
                 jv[2 * DS + (k - DS)] = dv_du;
             }
         }
-        __syncthreads();
+        return;
     }
-    // mean sums of step t for GP a (step.hip::prep_step without the pair-kernel parameters)
-    __shared__ double s_B[D], s_A[D], s_sc[D], s_r1[D], s_r2[D], s_u[D];
+
+    // ---- GP a: mean sums of step t over the N points (step.hip::prep_step without the pair-kernel parameters) ---------
+    __shared__ double s_B[D], s_A[D], s_r1[D], s_r2[D];
     if (tid < D) {
         const int k = tid;
-        const double uk = k < DS ? s_mu[k < DS ? k : 0] : s_uact[k >= DS ? k - DS : 0];
-        const double sk = k < DS ? s_var[k < DS ? k : 0] : GPMPC_ACTION_VAR;
-        const double lam = s_lam[a * D + k];
-        s_u[k] = uk;
+        const double sk = s_sin[k], lam = lam_k;                    // wave 0 holds the length-scales
         s_B[k] = 1.0 / (sk + lam);
         s_A[k] = 1.0 / (0.5 * lam + sk);
-        s_sc[k] = sqrt(0.125 / (0.5 * lam + sk));
         s_r1[k] = sk / lam + 1.0;
         s_r2[k] = 2.0 * sk / lam + 1.0;
     }
     __syncthreads();
+    GPMPC_STAMP(4);
     double u[D], Bk[D];
 #pragma unroll
-    for (int k = 0; k < D; ++k) { u[k] = s_u[k]; Bk[k] = s_B[k]; }
+    for (int k = 0; k < D; ++k) { u[k] = s_uin[k]; Bk[k] = s_B[k]; }
     double v[NV];
 #pragma unroll
     for (int m = 0; m < NV; ++m) v[m] = 0.0;
-    for (int i = tid; i < Np; i += 256) {
+#pragma unroll
+    for (int r = 0; r < PF; ++r) {                                 // prefetched points (zero weight past Np)
+        double d[D], q = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) { d[k] = u[k] - xpt[r][k]; q = fma(Bk[k] * d[k], d[k], q); }
+        const double p = bpt[r] * exp(-0.5 * q);
+        v[0] += p;
+#pragma unroll
+        for (int k = 0; k < D; ++k) { v[1 + k] = fma(p, d[k], v[1 + k]); v[1 + D + k] = fma(p * d[k], d[k], v[1 + D + k]); }
+    }
+    for (int i = tid + PF * NT; i < Np; i += NT) {
         double d[D], q = 0.0;
 #pragma unroll
         for (int k = 0; k < D; ++k) { d[k] = u[k] - A.XT[(size_t)k * Np + i]; q = fma(Bk[k] * d[k], d[k], q); }
@@ -249,10 +409,12 @@ __global__ __launch_bounds__(256) void k_step_fused(FusedArgs A, int t) {
 #pragma unroll
         for (int k = 0; k < D; ++k) { v[1 + k] = fma(p, d[k], v[1 + k]); v[1 + D + k] = fma(p * d[k], d[k], v[1 + D + k]); }
     }
+    GPMPC_STAMP(5);
     block_sum<NV>(v, s_red, s_out);
+    GPMPC_STAMP(6);
     if (tid < D) {
         const int k = tid;
-        const double sf = A.sf[a], sf2 = sf * sf;
+        const double sf2 = sf_a * sf_a;
         double detm = 1.0, detv = 1.0;
         for (int l = 0; l < D; ++l) { detm *= s_r1[l]; detv *= s_r2[l]; }
         const double cm = sf2 / sqrt(detm), c = 1.0 / sqrt(detv);
@@ -260,33 +422,36 @@ __global__ __launch_bounds__(256) void k_step_fused(FusedArgs A, int t) {
         double* sp = A.sp + (((size_t)pcur * A.B + b) * DS + a) * A.sps;
         if (k == 0) { sp[0] = c; sp[1] = mu; sp[2] = sf2; }
         const double Bq = s_B[k];
-        sp[3 + k] = s_A[k]; sp[3 + D + k] = s_sc[k];
+        sp[3 + k] = s_A[k]; sp[3 + D + k] = s_sck[k];
         sp[3 + 2 * D + k] = -Bq * cm * s_out[1 + k];
         sp[3 + 3 * D + k] = -0.5 * mu * Bq + 0.5 * Bq * Bq * cm * s_out[1 + D + k];
     }
+    GPMPC_STAMP(7);
 }
 
-template <int D, int NS2, bool GRAD>
+template <int D, int NS2, bool GRAD, int Q>
 static int launch_step_fused_one(const FusedArgs& a, int t, hipStream_t s) {
-    hipLaunchKernelGGL((k_step_fused<D, NS2, GRAD>), dim3(a.nwork + NS2, a.B), dim3(256), 0, s, a, t);
+    hipLaunchKernelGGL((k_step_fused<D, NS2, GRAD, Q>), dim3(a.nwork + 2 * NS2, a.B), dim3(256), 0, s, a, t);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { gpmpc_set_error("fused step kernel launch", e); return GPMPC_E_LAUNCH; }
     return GPMPC_OK;
 }
 
-// ns2 = state_dim: D - ns2 in {0, 1, 2} action dimensions
+// ns2 = state_dim: D - ns2 in {0, 1, 2} action dimensions; q = 1 (whole tiles) or 4 (a quarter of a tile's columns per workgroup)
 template <int D>
-int gpmpc_launch_step_fused_D(bool grad, int ns2, const FusedArgs& a, int t, hipStream_t s) {
-    if (a.nm != (grad ? 1 + 2 * D : 1)) return GPMPC_E_ARG;
-#define GPMPC_FUSED_CASE(GR)                                                                                       \
-    if (grad == GR) {                                                                                              \
-        if (ns2 == D) return launch_step_fused_one<D, D, GR>(a, t, s);                                             \
-        if (D >= 2 && ns2 == D - 1) return launch_step_fused_one<D, (D >= 2 ? D - 1 : D), GR>(a, t, s);            \
-        if (D >= 3 && ns2 == D - 2) return launch_step_fused_one<D, (D >= 3 ? D - 2 : D), GR>(a, t, s);            \
+int gpmpc_launch_step_fused_D(bool grad, int ns2, int q, const FusedArgs& a, int t, hipStream_t s) {
+    if (a.nm != (grad ? 1 + 2 * D : 1) || (q != 1 && q != 4)) return GPMPC_E_ARG;
+#define GPMPC_FUSED_CASE(GR, QV)                                                                                   \
+    if (grad == GR && q == QV) {                                                                                   \
+        if (ns2 == D) return launch_step_fused_one<D, D, GR, QV>(a, t, s);                                         \
+        if (D >= 2 && ns2 == D - 1) return launch_step_fused_one<D, (D >= 2 ? D - 1 : D), GR, QV>(a, t, s);        \
+        if (D >= 3 && ns2 == D - 2) return launch_step_fused_one<D, (D >= 3 ? D - 2 : D), GR, QV>(a, t, s);        \
         return GPMPC_E_ARG;                                                                                        \
     }
-    GPMPC_FUSED_CASE(true)
-    GPMPC_FUSED_CASE(false)
+    GPMPC_FUSED_CASE(true, 1)
+    GPMPC_FUSED_CASE(true, 4)
+    GPMPC_FUSED_CASE(false, 1)
+    GPMPC_FUSED_CASE(false, 4)
 #undef GPMPC_FUSED_CASE
     return GPMPC_E_ARG;
 }

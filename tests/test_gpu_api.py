@@ -313,7 +313,9 @@ def test_readme_experiment_risk_averse_follows_the_data(G, golden):
         assert mpc.dynamics.gpr_err[0].num_train == 404                                            # one observation per loop step
         out[gamma] = dict(plan=plan, d_pred=distance_to_data(means[1:], data["exp_states"]).mean(),
                           d_loop=distance_to_data(path, data["exp_states"]).mean(), path=path)
-        assert np.linalg.norm(path[-1]) < np.linalg.norm(path[0]) - 2.0                            # progress towards the target
+        # progress towards the target: 4 steps of |a| <= 1 along the corridor alone (risk-averse) shorten |s| by 1.66; the
+        # variances carry percent-level round-off at sigma_n = 1e-5, so the exact path depends on the summation order
+        assert np.linalg.norm(path[-1]) < np.linalg.norm(path[0]) - 1.2
     averse, neutral = out[-1.0], out[1e-5]
     assert averse["plan"][0, 1] > 0.8 and abs(averse["plan"][0, 0]) < 0.5        # up the corridor at x = 4 first
     assert neutral["plan"][0, 0] < -0.8 and neutral["plan"][0, 1] > 0.8          # diagonal, across the region without data

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Phase timeline of the fused small-batch step kernel (diagnostic build, see csrc/step_fused.h):
+    make -C gaussian_process_mpc_amd/csrc clean && make -C gaussian_process_mpc_amd/csrc -j8 EXTRA=-DGPMPC_FUSED_STAMPS
+    python tools/fused_stamps.py        (C2 sizes: D = 4)"""
+import ctypes, sys
+import numpy as np, torch
+sys.path.insert(0, ".")
+import gaussian_process_mpc_amd as g
+from gaussian_process_mpc_amd.synth import CONFIGS, synth_problem
+from oracle import gpmpc_oracle as O
+cfg = CONFIGS["C2"]
+pb = synth_problem(2, cfg["N"], cfg["ds"], cfg["da"], cfg["H"], 1)
+gp = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"])
+pack = g.GPPack(pb["X"], pb["Y"], gp.Ky_inv.numpy(), pb["lambdas"], pb["sigma_f"])
+cost = g.CostParams(-1.0, pb["Q"], pb["R"])
+for _ in range(50):
+    g.rollout(pack, pb["x0"], pb["U"], cost, want_traj=False, graph=True)
+torch.cuda.synchronize()
+buf = (ctypes.c_ulonglong * 64)()
+assert g.lib().gpmpc_debug_stamps(buf) == 0
+st = np.array(list(buf), dtype=np.int64)
+names_tile = ["start", "loads issued", "z0 reduced", "scalars published", "chunk staged", "columns done", "tile reduced", "written"]
+names_mean = ["start", "loads issued", "z0 reduced", "scalars published", "B/A published", "N loop done", "block sum done", "sp written"]
+for off, names, tag in ((0, names_tile, "tile workgroup 0"), (16, names_mean, "mean-sum workgroup of GP 0")):
+    t = st[off:off + 8]
+    print(tag)
+    for k in range(1, 8):
+        print(f"  {names[k]:22s} +{t[k] - t[k-1]:6d} cycles   (t = {t[k] - t[0]:6d})")
+print("probes (tile wg): lam load %d cycles, partz load %d cycles, M load %d cycles" % (st[8] - st[0], st[9] - st[8], st[10] - st[9]))
+print("probes (mean wg): lam load %d cycles, partz load %d cycles, M load %d cycles" % (st[24] - st[16], st[25] - st[24], st[26] - st[25]))
