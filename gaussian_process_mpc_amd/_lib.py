@@ -67,6 +67,7 @@ SIGNATURES = {
     "gpmpc_cost": (_i, [_i, _i, _i, _i, ctypes.POINTER(CostParamsC), _vp, _vp, _vp, _vp, _vp]),
     "gpmpc_rollout_workspace_bytes": (_sz, [_vp, _i, _i, _u]),
     "gpmpc_rollout": (_i, [_vp, _i, _i, _vp, _vp, ctypes.POINTER(CostParamsC), _u, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "gpmpc_objective_gradient": (_i, [_vp, _i, _dp, _dp, ctypes.POINTER(CostParamsC), _u, _dp, _vp]),
     "gpmpc_rollout_fullcov_workspace_bytes": (_sz, [_vp, _i, _i, _u]),
     "gpmpc_rollout_fullcov": (_i, [_vp, _i, _i, _vp, _vp, ctypes.POINTER(CostParamsC), _u, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gpmpc_timing_enable": (_i, [_i]),

@@ -63,6 +63,7 @@ struct gpmpc_pack {
     double lam_host[GPMPC_MAX_DS][GPMPC_MAX_D];
     double sf_host[GPMPC_MAX_DS];
     void* graph_cache;         // captured rollout (GPMPC_USE_GRAPH), owned by step.hip
+    void* cb_cache;            // buffers + captured graph of gpmpc_objective_gradient (solver callbacks), owned by step.hip
     gpmpc_worklist wl[2][4];   // [0: variance units only | 1: + cross units][0: 256x256 tiles | 1: 64x64 | 2: 256x64 | 3: 64x128]
 };
 
@@ -149,6 +150,7 @@ static inline int gpmpc_check_device(const gpmpc_pack* p) {
 // pair-kernel timing classes (gpmpc_pair_kernel_time_class): the horizon-step-1 variant is cheaper than the full kernel
 enum { GPMPC_TIME_FULL = 0, GPMPC_TIME_FIRST = 1, GPMPC_TIME_CLASSES = 2 };
 void gpmpc_graph_cache_free(void* cache);
+void gpmpc_cb_cache_free(void* cache);
 #define GPMPC_HIP(call)                                              \
     do {                                                             \
         hipError_t e_ = (call);                                      \

@@ -191,6 +191,7 @@ extern "C" int gpmpc_pack_reload_tuning(gpmpc_pack* p) {
     gpmpc_read_tuning(&p->tune);
     p->tune.no_xcd_sort = keep;
     if (p->graph_cache) { gpmpc_graph_cache_free(p->graph_cache); p->graph_cache = nullptr; }   // captured under the old plan
+    if (p->cb_cache) { gpmpc_cb_cache_free(p->cb_cache); p->cb_cache = nullptr; }
     return GPMPC_OK;
 }
 
@@ -244,6 +245,7 @@ extern "C" int gpmpc_pack_destroy(gpmpc_pack* p) {
     if (p->lam) (void)hipFree(p->lam);
     if (p->sf) (void)hipFree(p->sf);
     gpmpc_graph_cache_free(p->graph_cache);
+    gpmpc_cb_cache_free(p->cb_cache);
     if (p->pair_ab_dev) (void)hipFree(p->pair_ab_dev);
     for (int mode = 0; mode < 2; ++mode)
         for (int k = 0; k < 4; ++k) {
@@ -312,6 +314,7 @@ extern "C" int gpmpc_pack_enable_fullcov(gpmpc_pack* p, void* stream) {
     p->M = Mnew;
     p->fullcov = 1;
     gpmpc_graph_cache_free(p->graph_cache); p->graph_cache = nullptr;    // p->M moved
+    gpmpc_cb_cache_free(p->cb_cache); p->cb_cache = nullptr;
     if (p->built) {
         hipLaunchKernelGGL(k_pack_cross, dim3((p->Np + 255) / 256, p->Np, p->npairs), dim3(256), 0, s, p->beta, p->XT, p->lam,
                            p->sf, p->pair_ab_dev, p->N, p->Np, p->D, p->ds, p->M + (size_t)p->ds * p->Np * p->Np);

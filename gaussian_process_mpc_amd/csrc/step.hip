@@ -924,6 +924,104 @@ static int graph_rollout(gpmpc_pack* p, int B, int H, const double* x0, const do
     return GPMPC_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Solver callback: objective + gradient of ONE candidate, host in / host out (src/mpc.py:202-255)
+// ---------------------------------------------------------------------------
+// Everything between Ipopt's x and the (cost, gradient) it gets back is ONE hipGraph owned by the pack:
+//   memcpy H2D [x0 | U] from pinned staging -> the H + 1 kernels of the rollout -> memcpy D2H [cost | grad] into pinned staging
+// so that a callback costs the host one hipGraphLaunch and one stream synchronisation.
+struct gpmpc_cb_cache {
+    hipStream_t stream; hipEvent_t ev_in; hipGraphExec_t exec; int valid;
+    int H; unsigned flags; gpmpc_cost_params cost;
+    double* h_in;  double* h_out;      // pinned: [ds + H da] and [1 + H da]
+    double* d_in;  double* d_out;      // device mirrors
+    void* ws; size_t ws_bytes; int cap_H;
+};
+
+void gpmpc_cb_cache_free(void* c) {
+    gpmpc_cb_cache* g = (gpmpc_cb_cache*)c;
+    if (!g) return;
+    if (g->stream) (void)hipStreamSynchronize(g->stream);
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->ev_in) (void)hipEventDestroy(g->ev_in);
+    if (g->h_in) (void)hipHostFree(g->h_in);
+    if (g->h_out) (void)hipHostFree(g->h_out);
+    if (g->d_in) (void)hipFree(g->d_in);
+    if (g->d_out) (void)hipFree(g->d_out);
+    if (g->ws) (void)hipFree(g->ws);
+    if (g->stream) (void)hipStreamDestroy(g->stream);
+    free(g);
+}
+
+extern "C" int gpmpc_objective_gradient(gpmpc_pack* p, int H, const double* x0_host, const double* U_host,
+                                        const gpmpc_cost_params* cost, unsigned flags, double* out_host, void* stream) {
+    if (!p || !x0_host || !U_host || !cost || !out_host || H < 1) return GPMPC_E_ARG;
+    if (!p->built) return GPMPC_E_STATE;
+    if (int rc_dev = gpmpc_check_device(p)) return rc_dev;
+    if (timing_on()) return GPMPC_E_STATE;                 // per-kernel events cannot be recorded inside a captured graph
+    flags &= GPMPC_WANT_GRAD;
+    const bool grad = (flags & GPMPC_WANT_GRAD) != 0;
+    const int nin = p->ds + H * p->da, nout = 1 + (grad ? H * p->da : 0);
+    gpmpc_cb_cache* g = (gpmpc_cb_cache*)p->cb_cache;
+    if (!g) {
+        g = (gpmpc_cb_cache*)calloc(1, sizeof(gpmpc_cb_cache));
+        if (!g) return GPMPC_E_ALLOC;
+        p->cb_cache = g;
+        GPMPC_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+        GPMPC_HIP(hipEventCreateWithFlags(&g->ev_in, hipEventDisableTiming));
+    }
+    if (H > g->cap_H) {                                   // (re)allocate for the longer horizon
+        (void)hipStreamSynchronize(g->stream);
+        if (g->exec) { (void)hipGraphExecDestroy(g->exec); g->exec = nullptr; }
+        g->valid = 0;
+        if (g->h_in) (void)hipHostFree(g->h_in);
+        if (g->h_out) (void)hipHostFree(g->h_out);
+        if (g->d_in) (void)hipFree(g->d_in);
+        if (g->d_out) (void)hipFree(g->d_out);
+        if (g->ws) (void)hipFree(g->ws);
+        g->h_in = g->h_out = g->d_in = g->d_out = nullptr; g->ws = nullptr; g->cap_H = 0;
+        const size_t bin = sizeof(double) * (p->ds + (size_t)H * p->da), bout = sizeof(double) * (1 + (size_t)H * p->da);
+        if (hipHostMalloc((void**)&g->h_in, bin, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void**)&g->h_out, bout, hipHostMallocDefault) != hipSuccess ||
+            hipMalloc((void**)&g->d_in, bin) != hipSuccess || hipMalloc((void**)&g->d_out, bout) != hipSuccess)
+            return GPMPC_E_ALLOC;
+        g->ws_bytes = gpmpc_rollout_workspace_bytes(p, 1, H, GPMPC_WANT_GRAD);
+        if (hipMalloc(&g->ws, g->ws_bytes) != hipSuccess) return GPMPC_E_ALLOC;
+        g->cap_H = H;
+    }
+    if (!g->valid || g->H != H || g->flags != flags || memcmp(&g->cost, cost, sizeof(*cost)) != 0) {
+        (void)hipStreamSynchronize(g->stream);
+        if (g->exec) { (void)hipGraphExecDestroy(g->exec); g->exec = nullptr; }
+        g->valid = 0;
+        hipGraph_t graph = nullptr;
+        GPMPC_HIP(hipStreamBeginCapture(g->stream, hipStreamCaptureModeThreadLocal));
+        hipError_t e1 = hipMemcpyAsync(g->d_in, g->h_in, sizeof(double) * nin, hipMemcpyHostToDevice, g->stream);
+        int rc = enqueue_rollout(p, 1, H, g->d_in, g->d_in + p->ds, cost, flags, nullptr, nullptr, g->d_out,
+                                 grad ? g->d_out + 1 : nullptr, g->ws, g->ws_bytes, g->stream);
+        hipError_t e2 = hipMemcpyAsync(g->h_out, g->d_out, sizeof(double) * nout, hipMemcpyDeviceToHost, g->stream);
+        hipError_t e = hipStreamEndCapture(g->stream, &graph);
+        if (rc != GPMPC_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (e1 != hipSuccess || e2 != hipSuccess || e != hipSuccess) {
+            gpmpc_set_error("gpmpc_objective_gradient capture", e != hipSuccess ? e : (e1 != hipSuccess ? e1 : e2));
+            if (graph) (void)hipGraphDestroy(graph);
+            return GPMPC_E_LAUNCH;
+        }
+        e = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) { gpmpc_set_error("hipGraphInstantiate", e); return GPMPC_E_LAUNCH; }
+        g->H = H; g->flags = flags; g->cost = *cost; g->valid = 1;
+    }
+    memcpy(g->h_in, x0_host, sizeof(double) * p->ds);
+    memcpy(g->h_in + p->ds, U_host, sizeof(double) * (size_t)H * p->da);
+    // ordered behind whatever the caller's stream did to the pack (build / append), then one launch and one wait
+    GPMPC_HIP(hipEventRecord(g->ev_in, (hipStream_t)stream));
+    GPMPC_HIP(hipStreamWaitEvent(g->stream, g->ev_in, 0));
+    GPMPC_HIP(hipGraphLaunch(g->exec, g->stream));
+    GPMPC_HIP(hipStreamSynchronize(g->stream));
+    memcpy(out_host, g->h_out, sizeof(double) * nout);
+    return GPMPC_OK;
+}
+
 extern "C" int gpmpc_rollout(const gpmpc_pack* p, int B, int H, const double* x0, const double* U,
                              const gpmpc_cost_params* cost, unsigned flags, double* out_means, double* out_vars,
                              double* out_cost, double* out_grad, void* workspace, size_t workspace_bytes, void* stream) {

@@ -43,13 +43,23 @@ class Dynamics(object):
     # -- device pack -----------------------------------------------------------------------
     def _key(self):
         # what forward_propagate_torch reads at call time in the reference (src/dynamics.py:150, :170-173):
-        # Ky_inv, exp(log_lambdas), y_train, sigma_f of every GP, X_train of GP 0
-        return tuple((g.version, g.num_train, tuple(g.get_lambdas().tolist()), g.get_sigma_f()) for g in self.gpr_err)
+        # Ky_inv, exp(log_lambdas), y_train, sigma_f of every GP, X_train of GP 0.  Tensors are keyed by OBJECT and
+        # autograd version (the key holds the references, so an id cannot be reused by a later tensor): this runs on
+        # every solver callback, and exp / tolist of the hyper-parameters per call cost as much as a small rollout.
+        return [(g.version, g.num_train, g.log_lambdas, g.log_lambdas._version, g.log_sigma_f, g.log_sigma_f._version)
+                for g in self.gpr_err]
+
+    @staticmethod
+    def _same_key(a, b):
+        if a is None or b is None or len(a) != len(b):
+            return False
+        return all(x[0] == y[0] and x[1] == y[1] and x[2] is y[2] and x[3] == y[3] and x[4] is y[4] and x[5] == y[5]
+                   for x, y in zip(a, b))
 
     def pack(self):
         """The device-resident constants of the rollout, rebuilt only when data or hypers changed."""
         key = self._key()
-        if self._pack is None or key != self._pack_key:
+        if self._pack is None or not self._same_key(key, self._pack_key):
             g0 = self.gpr_err[0]
             if g0.num_train == 0:
                 raise RuntimeError("no training data")

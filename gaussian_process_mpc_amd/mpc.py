@@ -132,11 +132,12 @@ class RiskSensitiveMPC:
                 self.curr_cost = float(r["cost"][0].item())
                 self.curr_grad = r["grad"][0].cpu().numpy()
             else:
-                # B = 1 is launch-latency bound: replay the 2H+1 launches as one hipGraph; cost and gradient come back
-                # in one device-to-host copy
-                r = rollout(pack, cs, x.reshape(self.horizon, self.input_dim), cp, want_grad=True, want_traj=False,
-                            graph=True)
-                cg = r["cost_grad"].cpu().numpy()
+                # B = 1 is pure latency: upload, the H + 1 kernels and the download are ONE captured hipGraph owned by the
+                # pack (C ABI gpmpc_objective_gradient) -- one launch and one wait per callback pair
+                if held[0] is not cs or getattr(self, "_cs_host_version", None) != cs._version:
+                    self._cs_host = cs.detach().cpu().numpy().astype(np.float64).reshape(-1)
+                    self._cs_host_version = cs._version
+                cg = pack.objective_gradient(self._cs_host, x.reshape(self.horizon, self.input_dim), cp)
                 self.curr_cost = float(cg[0])
                 self.curr_grad = cg[1:].reshape(self.horizon, self.input_dim).copy()
             self.curr_u = x.reshape(self.horizon, self.input_dim)

@@ -101,6 +101,22 @@ class GPPack:
         self.fullcov = True
         return self
 
+    def objective_gradient(self, x0_host, U_host, cost, want_grad=True):
+        """One solver callback (C ABI ``gpmpc_objective_gradient``; reference src/mpc.py:202-255): host arrays in, host
+        array out.  x0_host (ds,), U_host (H, da) float64 numpy -> numpy [cost, d cost / d U (H*da)].  Synchronous."""
+        x0 = np.ascontiguousarray(x0_host, dtype=np.float64).reshape(-1)
+        U = np.ascontiguousarray(U_host, dtype=np.float64).reshape(-1, self.da)
+        if x0.shape[0] != self.ds or cost.ds != self.ds or cost.da != self.da:
+            raise ValueError("shape mismatch between pack, x0, U and cost parameters")
+        H = U.shape[0]
+        out = np.empty(1 + (H * self.da if want_grad else 0), dtype=np.float64)
+        dp = ctypes.POINTER(ctypes.c_double)
+        with torch.cuda.device(self.device):
+            check(lib().gpmpc_objective_gradient(self._h, H, x0.ctypes.data_as(dp), U.ctypes.data_as(dp), ctypes.byref(cost.c),
+                                                 _lib.WANT_GRAD if want_grad else 0, out.ctypes.data_as(dp), stream_ptr()),
+                  "gpmpc_objective_gradient")
+        return out
+
     def reload_tuning(self):
         """Re-read the GPMPC_* tuning environment variables (read once at pack creation otherwise)."""
         check(lib().gpmpc_pack_reload_tuning(self._h), "gpmpc_pack_reload_tuning")

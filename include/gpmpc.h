@@ -198,6 +198,16 @@ int gpmpc_rollout_fullcov(const gpmpc_pack* pack, int B, int H, const double* x0
                           double* out_means, double* out_covs, double* out_cost, double* out_grad,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* The solver callback pair RiskSensitiveMPC.objective(x) / gradient(x) (src/mpc.py:202-255) for ONE candidate, host in and
+ * host out like the cyipopt callbacks themselves: x0_host [ds] current state, U_host [H][da] the candidate (Ipopt's x),
+ * out_host [1 + H da] = cost, then d cost / d U row-major (flags = GPMPC_WANT_GRAD; 0: cost only, out_host [1]).
+ * SYNCHRONOUS: returns when out_host is filled.  The pack owns the staging buffers (pinned host + device) and one
+ * captured hipGraph -- upload, the H + 1 kernels of the diagonal-covariance rollout, download -- so a callback costs
+ * the host one graph launch and one stream wait; a changed horizon / cost parameter set re-captures.  `stream`: the
+ * stream the pack was last built on (the call is ordered behind it).  Not re-entrant per pack. */
+int gpmpc_objective_gradient(gpmpc_pack* pack, int H, const double* x0_host, const double* U_host,
+                             const gpmpc_cost_params* cost_host, unsigned flags, double* out_host, void* stream);
+
 /* Kernel-level timing of the dominant (pair) kernel for bench.py: when enabled, every
  * gpmpc_rollout brackets its pair-kernel launches with HIP events on the launch stream.
  * gpmpc_pair_kernel_time returns accumulated milliseconds and launch count since the last reset

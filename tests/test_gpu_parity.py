@@ -418,6 +418,35 @@ def test_graph_replay_matches_eager(G, golden):
     assert torch.equal(e["cost"], g["cost"]) and torch.equal(e["grad"], g["grad"])
 
 
+def test_objective_gradient_callback_entry(G, golden):
+    """gpmpc_objective_gradient (host in / host out, one captured graph per pack: upload + rollout + download) returns
+    exactly the bits of gpmpc_rollout for the same candidate, across new inputs, a new start state, a changed cost
+    (re-capture), a changed horizon (re-allocation) and the objective-only form; and the reference's own values (g4)."""
+    z = golden("g4_rollout_c2.npz")
+    pack = _pack_from(G, z)
+    H = z["U"].shape[1]
+    for gamma in (-1.0, 1e-5):
+        cost = _cost_from(G, z, gamma)
+        for rep in range(3):
+            for b in range(2):
+                U = z["U"][b] * (1 + 0.1 * rep)
+                e = G.rollout(pack, z["x0"][b], U, cost, want_traj=False)
+                cg = pack.objective_gradient(z["x0"][b], U, cost)
+                assert cg.shape == (1 + H * U.shape[1],)
+                assert cg[0] == e["cost"][0].item() and np.array_equal(cg[1:], e["grad"][0].cpu().numpy().reshape(-1)), (gamma, rep, b)
+    gi = list(z["gammas"]).index(-1.0) if -1.0 in list(z["gammas"]) else 0
+    cg = pack.objective_gradient(z["x0"][0], z["U"][0], _cost_from(G, z, float(z["gammas"][gi])))
+    np.testing.assert_allclose(cg[0], z["costs"][gi, 0], rtol=1e-6)
+    np.testing.assert_allclose(cg[1:].reshape(z["grads"][gi, 0].shape), z["grads"][gi, 0], rtol=1e-4, atol=1e-7)
+    cost = _cost_from(G, z, -1.0)
+    short = pack.objective_gradient(z["x0"][1], z["U"][1][:5], cost)                   # shorter horizon: re-capture
+    e = G.rollout(pack, z["x0"][1], z["U"][1][:5], cost, want_traj=False)
+    assert short[0] == e["cost"][0].item() and np.array_equal(short[1:], e["grad"][0].cpu().numpy().reshape(-1))
+    only = pack.objective_gradient(z["x0"][1], z["U"][1], cost, want_grad=False)
+    assert only.shape == (1,)
+    np.testing.assert_allclose(only[0], G.rollout(pack, z["x0"][1], z["U"][1], cost, want_grad=False)["cost"][0].item(), rtol=1e-12)
+
+
 def test_scalar_broadcast_kernels_match_staged(G, golden, monkeypatch):
     """The scalar-broadcast pair kernels (pair_kernel_sb.h / pair_kernel_sbf.h: expanded exponent, row-grouped moments)
     take over once the grid fills the chip; force both forms on the same large batch and compare them with each other
