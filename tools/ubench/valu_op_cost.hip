@@ -31,7 +31,16 @@ __global__ __launch_bounds__(256) void k(double* out, unsigned long long* stamps
     if (OP == 9) asm volatile("v_add_f64 %0, %0, %1" : "+v"(f[i]) : "v"(b));                                        \
     if (OP == 10) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(n[i]) : "v"(n[(i + 1) & 15]));                 \
     if (OP == 11) asm volatile("v_max_i32 %0, %0, %1" : "+v"(n[i]) : "v"(n[(i + 1) & 15]));                         \
-    if (OP == 12) asm volatile("v_mov_b64 %0, %1" : "=v"(f[i]) : "v"(a));
+    if (OP == 12) asm volatile("v_mov_b64 %0, %1" : "=v"(f[i]) : "v"(a));                                           \
+    if (OP == 13) asm volatile("v_add_u32 %0, %0, %1" : "+v"(n[i]) : "v"(n[(i + 1) & 15]));                         \
+    if (OP == 14) asm volatile("v_add_u32 %0, 0xffd00000, %0" : "+v"(n[i]));                                        \
+    if (OP == 15) asm volatile("v_mul_u32_u24 %0, 8, %0" : "+v"(n[i]));                                             \
+    if (OP == 16) asm volatile("v_bfe_u32 %0, %0, 3, 11" : "+v"(n[i]));                                             \
+    if (OP == 17) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(n[i]) : "v"(n[(i + 1) & 15]));                         \
+    if (OP == 18) asm volatile("v_lshlrev_b32 %0, %1, %0" : "+v"(n[i]) : "v"(n[(i + 1) & 15] & 3));                 \
+    if (OP == 19) asm volatile("v_lshrrev_b32 %0, 3, %0" : "+v"(n[i]));                                             \
+    if (OP == 20) asm volatile("v_and_or_b32 %0, %0, %2, %1" : "+v"(n[i]) : "v"(n[(i + 1) & 15]), "v"(0x3ff8));              \
+    if (OP == 21) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(n[i]) : "v"(n[(i + 1) & 15]));
             REP16(ONE)
 #undef ONE
         }
@@ -69,5 +78,8 @@ int main() {
     run<1>("v_rndne_f64", r); run<2>("v_fract_f64", r); run<3>("v_cvt_i32_f64", r); run<4>("v_ldexp_f64", r);
     run<5>("v_and_b32", r); run<6>("v_lshlrev_b32", r); run<7>("v_ashrrev_i32", r); run<10>("v_lshl_add_u32", r);
     run<11>("v_max_i32", r); run<12>("v_mov_b64", r);
+    run<13>("v_add_u32", r); run<14>("v_add_u32 lit", r); run<15>("v_mul_u32_u24", r); run<16>("v_bfe_u32", r);
+    run<17>("v_xor_b32", r); run<18>("v_lshlrev_b32 v", r); run<19>("v_lshrrev_b32", r); run<20>("v_and_or_b32", r);
+    run<21>("v_sub_u32", r);
     return 0;
 }
