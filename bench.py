@@ -46,6 +46,11 @@ def parse_args():
     ap.add_argument("--forward-only", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay each rollout as one hipGraph (small batches)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the PCIe-inclusive and objective-only side measurements (profiling passes: only the timed workload runs)")
+    ap.add_argument("--kinv-cache", default="",
+                    help="file to load the inverse kernel matrices from / save them to (profiling passes: rocprofv3 --pmc crashes "
+                         "inside rocSOLVER's 4096^2 LU, so an unprofiled run writes the file and the profiled runs read it)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="rehearsal only: allow more ranks than visible GPUs (ranks share cards; use --backend gloo)")
     return ap.parse_args()
@@ -68,9 +73,15 @@ def spawn_ranks(args):
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        # rank 0's stdout is filtered down to the JSON line (gloo prints connection banners on stdout)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
     rc = 0
     try:
+        for line in procs[0].stdout:
+            if line.lstrip().startswith("{"):
+                sys.stdout.write(line)
+                sys.stdout.flush()
         for p in procs:
             code = p.wait()
             rc = rc or code
@@ -253,7 +264,12 @@ def run_rank(args):
 
     # GP pack: rank 0 inverts, everyone receives the same bits
     if rank == 0:
-        kinv = build_kinv(pb, device)
+        if args.kinv_cache and os.path.exists(args.kinv_cache):
+            kinv = torch.load(args.kinv_cache, map_location=device)
+        else:
+            kinv = build_kinv(pb, device)
+            if args.kinv_cache:
+                torch.save(kinv.cpu(), args.kinv_cache)
     else:
         kinv = torch.empty((ds, N, N), dtype=torch.float64, device=device)
     if world > 1:
@@ -363,7 +379,7 @@ def run_rank(args):
             },
             "pack_build_ms": pack_ms,
         }
-        if world == 1 and not args.graph:
+        if world == 1 and not args.graph and not args.no_extras:
             # PCIe-inclusive rate, outside the timed region: U from pinned host memory in, [cost | grad] back out, per step
             Uh = torch.as_tensor(pb["U"][lo:hi]).pin_memory()
             Ud = torch.empty_like(U)
@@ -377,7 +393,7 @@ def run_rank(args):
                     gr.cpu()
             torch.cuda.synchronize()
             out["pcie_inclusive_rollouts_per_s"] = max(2, min(args.steps, 5)) * B / (time.perf_counter() - tp)
-        if world == 1 and want_grad and not fullcov:
+        if world == 1 and want_grad and not fullcov and not args.no_extras:
             # objective-only rate beside the headline, outside the timed region
             for _ in range(2):
                 g.rollout(pack, x0, U, cost, want_grad=False, want_traj=False)

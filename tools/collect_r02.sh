@@ -22,7 +22,7 @@ python bench.py --gpus 2 --oversubscribe --backend gloo --steps 3 --warmup 1 --n
 python tools/callback_latency.py 2>/dev/null | tail -2 > $O/callback_latency.txt
 for f in $O/bench_*.json; do python - "$f" <<'PY'
 import json, sys
-d = json.load(open(sys.argv[1])); r = d["roofline"]
+d = json.loads([l for l in open(sys.argv[1]) if l.lstrip().startswith("{")][-1]); r = d["roofline"]
 g = lambda v, n=3: None if v is None or v != v else round(v, n)
 print(sys.argv[1].split("/")[-1], g(d["value"], 1), d["unit"], "ms/step", g(d["ms_per_step"]), "kernel ms", g(r["avg_launch_ms"], 4),
       "frac", g(r["frac"]), "slots", g(r["frac_survey_8d_slots"]), "traffic", r["traffic"], "n_gpus", d["n_gpus"])
