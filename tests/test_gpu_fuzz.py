@@ -1,0 +1,106 @@
+"""Seeded random sweeps of the rollout entry points against the plain-C checkers (oracle/cport, pinned to the torch oracle
+and to the reference's fixtures on the CPU): ragged N around the 64-row padding, every state / action dimension, short and
+long horizons, batch sizes on both sides of the kernel-selection thresholds, all cost regimes (risk-averse, risk-seeking,
+the reference's risk-neutral stand-in 1e-5 and the analytic gamma = 0 limit).  Tolerances: the north star (means 1e-5,
+variances 1e-4) + cost 1e-6 + gradient 1e-4.  Plus: accuracy at smaller noise levels tracks the oracle's own
+self-consistency (the variance is a cancelling N^2 sum: sum|terms| / |var| ~ 1 / sigma_n^2)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    import gaussian_process_mpc_amd as g
+    g.require_gpu()
+    return g
+
+
+def _case(rng):
+    N = int(rng.choice([1, 2, 17, 63, 64, 65, 100, 129, 200, 257, 320, 449]))
+    ds = int(rng.integers(1, 7))
+    da = int(rng.integers(1, 3))
+    if ds + da > 8:
+        ds = 8 - da
+    H = int(rng.integers(1, 8))
+    B = int(rng.choice([1, 2, 3, 5, 8, 33, 120, 700]))
+    gamma = float(rng.choice([-1.0, 1e-5, 0.0, 0.5]))
+    return N, ds, da, H, B, gamma
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_diagonal_rollout_vs_cport(G, seed):
+    from oracle import cport, gpmpc_oracle as O
+    from gaussian_process_mpc_amd.synth import synth_problem
+    rng = np.random.default_rng(1000 + seed)
+    N, ds, da, H, B, gamma = _case(rng)
+    pb = synth_problem(200 + seed, N, ds, da, H, B)
+    pb["Q"] = pb["Q"] + 0.01 * (np.ones((ds, ds)) - np.eye(ds))             # a general Q (the C port handles it)
+    kinv = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"]).Ky_inv.numpy()
+    pack = G.GPPack(pb["X"], pb["Y"], kinv, pb["lambdas"], pb["sigma_f"])
+    r = G.rollout(pack, pb["x0"], pb["U"], G.CostParams(gamma, pb["Q"], pb["R"]))
+    pick = sorted({0, B // 2, B - 1})
+    c = cport.rollout(pb, kinv, gamma, x0=pb["x0"][pick], U=pb["U"][pick], nthreads=8)
+    tag = f"N={N} ds={ds} da={da} H={H} B={B} gamma={gamma}"
+    np.testing.assert_allclose(r["means"][pick].cpu().numpy(), c["means"], rtol=1e-5, atol=1e-9, err_msg=tag)
+    np.testing.assert_allclose(r["vars"][pick].cpu().numpy(), c["vars"], rtol=1e-4, atol=1e-12, err_msg=tag)
+    np.testing.assert_allclose(r["cost"][pick].cpu().numpy(), c["cost"], rtol=1e-6, atol=1e-12, err_msg=tag)
+    np.testing.assert_allclose(r["grad"][pick].cpu().numpy(), c["grad"], rtol=1e-4, atol=1e-7, err_msg=tag)
+    if B == 1:                                          # the solver-callback entry returns the same bits
+        cg = pack.objective_gradient(pb["x0"][0], pb["U"][0], G.CostParams(gamma, pb["Q"], pb["R"]))
+        assert cg[0] == r["cost"][0].item() and np.array_equal(cg[1:], r["grad"][0].cpu().numpy().reshape(-1)), tag
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_fullcov_rollout_vs_cport(G, seed):
+    from oracle import cport, gpmpc_oracle as O
+    from gaussian_process_mpc_amd.synth import synth_problem
+    rng = np.random.default_rng(3000 + seed)
+    N = int(rng.choice([3, 40, 64, 65, 130, 200]))
+    ds = int(rng.integers(1, 6))
+    da = int(rng.integers(1, 3))
+    H = int(rng.integers(1, 5))
+    B = int(rng.choice([1, 2, 5, 40, 260]))
+    gamma = float(rng.choice([-1.0, 1e-5, 0.0, 0.5]))
+    pb = synth_problem(400 + seed, N, ds, da, H, B)
+    pb["Q"] = pb["Q"] + 0.02 * (np.ones((ds, ds)) - np.eye(ds))
+    kinv = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"]).Ky_inv.numpy()
+    pack = G.GPPack(pb["X"], pb["Y"], kinv, pb["lambdas"], pb["sigma_f"])
+    r = G.rollout_fullcov(pack, pb["x0"], pb["U"], G.CostParams(gamma, pb["Q"], pb["R"]))
+    pick = sorted({0, B - 1})
+    dirs = rng.normal(size=(len(pick), 1, H, da))
+    c = cport.rollout_fullcov(pb, kinv, gamma, x0=pb["x0"][pick], U=pb["U"][pick], dirs=dirs, nthreads=8)
+    tag = f"N={N} ds={ds} da={da} H={H} B={B} gamma={gamma}"
+    np.testing.assert_allclose(r["means"][pick].cpu().numpy(), c["means"], rtol=1e-5, atol=1e-9, err_msg=tag)
+    np.testing.assert_allclose(r["covs"][pick].cpu().numpy(), c["covs"], rtol=1e-4, atol=1e-6 * max(np.abs(c["covs"]).max(), 1e-30), err_msg=tag)
+    np.testing.assert_allclose(r["cost"][pick].cpu().numpy(), c["cost"], rtol=1e-6, atol=1e-12, err_msg=tag)
+    g = r["grad"][pick].cpu().numpy()
+    for k in range(len(pick)):
+        np.testing.assert_allclose(float((g[k] * dirs[k, 0]).sum()), c["ddir"][k, 0], rtol=1e-4, atol=1e-7, err_msg=tag)
+
+
+@pytest.mark.parametrize("sigma_n", [1e-2, 1e-3, 1e-4])
+def test_accuracy_tracks_the_oracles_own_self_consistency(G, sigma_n):
+    """At smaller noise levels no fp64 evaluation of the variance is reproducible to 1e-4 (cond(Ky) ~ 1 / sigma_n^2): the
+    reference's own op order (N^3 trace) and the elementwise sum disagree with each other.  The HIP path must agree with
+    the oracle as well as the oracle's two evaluation orders agree with each other (a factor 10 of slack, and never
+    worse than the north-star tolerance at the benchmark's sigma_n = 1e-2)."""
+    from oracle import gpmpc_oracle as O
+    from gaussian_process_mpc_amd.synth import synth_problem
+    N, ds, da, H = 400, 3, 1, 3
+    pb = synth_problem(77, N, ds, da, H, 2, sigma_n=sigma_n)
+    gp = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"])
+    pack = G.GPPack(pb["X"], pb["Y"], gp.Ky_inv.numpy(), pb["lambdas"], pb["sigma_f"])
+    r = G.rollout(pack, pb["x0"], pb["U"], G.CostParams(1e-5, pb["Q"], pb["R"]), want_grad=False)
+    worst_hip, worst_self = 0.0, 0.0
+    for b in range(2):
+        a = O.objective_and_gradient(gp, H, pb["x0"][b], pb["U"][b], pb["x_ref"], pb["u_ref"], pb["Q"], pb["R"], 1e-5, mode="faithful", want_grad=False)
+        o = O.objective_and_gradient(gp, H, pb["x0"][b], pb["U"][b], pb["x_ref"], pb["u_ref"], pb["Q"], pb["R"], 1e-5, mode="o2", want_grad=False)
+        worst_self = max(worst_self, np.abs(a["vars"][1:] / o["vars"][1:] - 1).max())
+        worst_hip = max(worst_hip, np.abs(r["vars"][b, 1:].cpu().numpy() / o["vars"][1:] - 1).max())
+        np.testing.assert_allclose(r["means"][b].cpu().numpy(), o["means"], rtol=1e-5 if sigma_n >= 1e-3 else 1e-3, atol=1e-8)
+    assert worst_hip <= max(10 * worst_self, 1e-9), (sigma_n, worst_hip, worst_self)
+    if sigma_n == 1e-2:
+        assert worst_hip < 1e-4
