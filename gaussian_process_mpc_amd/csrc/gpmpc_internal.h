@@ -180,6 +180,18 @@ __device__ __forceinline__ double wave_sum(double v) {
     return (gpmpc_readlane_f64(v, 0) + gpmpc_readlane_f64(v, 16)) + (gpmpc_readlane_f64(v, 32) + gpmpc_readlane_f64(v, 48));
 }
 
+// First half of wave_sum: every lane ends up with the sum of ITS ROW of 16 lanes (rows 0-15, 16-31, 32-47, 48-63).  The pair
+// kernels store the four row sums and let the final cross-wave combine add 16 values instead of 4: that drops the 8
+// v_readlane + 3 v_add_f64 of the second half (11 of 23 instructions per reduced value; the end-of-tile reduction of
+// 22 values per wave was 2.4 % of a C3 launch).
+__device__ __forceinline__ double wave_row_sum(double v) {
+    v += gpmpc_dpp_f64<0xB1>(v);        // quad_perm [1,0,3,2]
+    v += gpmpc_dpp_f64<0x4E>(v);        // quad_perm [2,3,0,1]
+    v += gpmpc_dpp_f64<0x141>(v);       // row_half_mirror
+    v += gpmpc_dpp_f64<0x140>(v);       // row_mirror
+    return v;
+}
+
 // Sum NV per-thread values over the workgroup (<= 16 waves).  Result in out[0..NV) (LDS), visible to all
 // threads after return.  scratch: LDS, >= 16*NV doubles.  Deterministic summation order.
 template <int NV>

@@ -225,7 +225,8 @@ extern "C" int gpmpc_pack_create(gpmpc_pack** out, int n_train, int state_dim, i
     // 256x64: scalar-broadcast kernel for small batches of a large N (enough workgroups to fill the chip at B = 1).
     // 64x128: staged kernel for B = 1 of a large N (fewer partial sums to reduce per step: N = 2048 1.30 -> 1.18 ms per
     // rollout; N <= 512 is 10 % slower on it and stays on 64x64).
-    const int cfg[4][2] = {{256, 256}, {64, 64}, {256, 64}, {64, 128}};
+    int cfg[4][2] = {{256, 256}, {64, 64}, {256, 64}, {64, 128}};
+    if (const char* ev = getenv("GPMPC_JT0")) { const int v = atoi(ev); if (v >= 64 && v % 64 == 0) cfg[0][1] = v; }   // A/B: column extent of the large tiles
     for (int mode = 0; mode < 2 && ok; ++mode)
         for (int k = 0; k < 4 && ok; ++k) {
             if (mode == 1 && k >= 2) continue;

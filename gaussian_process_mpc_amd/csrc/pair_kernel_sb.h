@@ -51,7 +51,7 @@ template <int D, int TB, int NS2, bool GRAD, bool FIRST = false>
 __global__ __launch_bounds__(256, (TB == 2 && D <= 5) ? GPMPC_SB_TB2_WAVES : 1) void gpmpc_pair_kernel_sb(PairSbArgs A) {
     constexpr int GW = PairSbTraits<D, NS2>::GW;
     constexpr int NM = GRAD ? 1 + 2 * D : 1, NA = GRAD ? 1 + D + NS2 : 1;
-    __shared__ double s_red[4 * TB * NM];
+    __shared__ double s_red[16 * TB * NM];        // [wave][row of 16 lanes][trajectory][moment]
     __shared__ double s_tab[GPMPC_EXP_N];
     gpmpc_exp_table_to_lds(s_tab);
 
@@ -179,10 +179,11 @@ __global__ __launch_bounds__(256, (TB == 2 && D <= 5) ? GPMPC_SB_TB2_WAVES : 1) 
                 }
             }
         }
+        // one moment at a time (reducing all of them first keeps NM more doubles live: 60 -> 70 VGPRs at D = 7, a wave per SIMD lost)
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
-            const double s = wave_sum(z[m]);
-            if (lane == 0) s_red[(w * TB + tb) * NM + m] = s;
+            const double s = wave_row_sum(z[m]);                          // every lane: the sum of its row of 16 lanes
+            if ((lane & 15) == 0) s_red[((w * 4 + (lane >> 4)) * TB + tb) * NM + m] = s;
         }
     }
     __syncthreads();
@@ -190,8 +191,11 @@ __global__ __launch_bounds__(256, (TB == 2 && D <= 5) ? GPMPC_SB_TB2_WAVES : 1) 
         const int tb = idx / NM, m = idx - tb * NM;
         const int b = bg * TB + tb;
         if (b < A.B) {
-            double s = 0.0;
-            for (int ww = 0; ww < (int)(blockDim.x >> 6); ++ww) s += s_red[(ww * TB + tb) * NM + m];
+            double s = 0.0;                       // fixed order: waves, each as (row 0 + row 1) + (row 2 + row 3)
+            for (int ww = 0; ww < (int)(blockDim.x >> 6); ++ww) {
+                const double* r4 = &s_red[(ww * 4 * TB + tb) * NM + m];
+                s += (r4[0] + r4[TB * NM]) + (r4[2 * TB * NM] + r4[3 * TB * NM]);
+            }
             A.part[((size_t)b * A.nwork + wi) * A.nm + m] = s;
         }
     }

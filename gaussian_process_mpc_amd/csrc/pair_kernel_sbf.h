@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void gpmpc_pair_kernel_sbf(PairSbfArgs A) {
     constexpr int NW = NS2 * (NS2 + 1) / 2;
     constexpr int GW = (D + 1 + NW + 1) & ~1;
     constexpr int NM = GRAD ? 1 + D + D * (D + 1) / 2 : 1, NA = GRAD ? 1 + D + NW : 1;
-    __shared__ double s_red[4 * NM];
+    __shared__ double s_red[16 * NM];             // [wave][row of 16 lanes][moment]
     __shared__ double s_tab[GPMPC_EXP_N];
     gpmpc_exp_table_to_lds(s_tab);
 
@@ -108,13 +108,16 @@ __global__ __launch_bounds__(256) void gpmpc_pair_kernel_sbf(PairSbfArgs A) {
     }
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
-        const double s = wave_sum(z[m]);
-        if (lane == 0) s_red[w * NM + m] = s;
+        const double s = wave_row_sum(z[m]);                              // see gpmpc_internal.h
+        if ((lane & 15) == 0) s_red[(w * 4 + (lane >> 4)) * NM + m] = s;
     }
     __syncthreads();
     for (int m = tid; m < NM; m += blockDim.x) {
         double s = 0.0;
-        for (int ww = 0; ww < (int)(blockDim.x >> 6); ++ww) s += s_red[ww * NM + m];
+        for (int ww = 0; ww < (int)(blockDim.x >> 6); ++ww) {
+            const double* r4 = &s_red[ww * 4 * NM + m];
+            s += (r4[0] + r4[NM]) + (r4[2 * NM] + r4[3 * NM]);
+        }
         A.part[((size_t)b * A.nwork + wi) * A.nm + m] = s;
     }
 }
