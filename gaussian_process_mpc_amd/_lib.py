@@ -56,6 +56,7 @@ SIGNATURES = {
     "gpmpc_pack_create": (_i, [ctypes.POINTER(_vp), _i, _i, _i]),
     "gpmpc_pack_destroy": (_i, [_vp]),
     "gpmpc_pack_reload_tuning": (_i, [_vp]),
+    "gpmpc_pack_graph_captures": (ctypes.c_longlong, [_vp]),
     "gpmpc_build_ky": (_i, [_i, _i, _vp, _dp, _d, _d, _vp, _vp, _vp]),
     "gpmpc_pack_build": (_i, [_vp, _vp, _vp, _vp, _dp, _dp, _vp]),
     "gpmpc_pack_build_beta": (_i, [_vp, _vp, _vp, _vp, _dp, _dp, _vp]),

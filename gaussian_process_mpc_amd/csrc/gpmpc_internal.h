@@ -192,6 +192,28 @@ __device__ __forceinline__ double wave_row_sum(double v) {
     return v;
 }
 
+// The same for workgroups of exactly 4 waves (256 threads), with the cheaper row sums: scratch >= 16*NV doubles
+// ([wave][row of 16 lanes][value]); fixed summation order.
+template <int NV>
+__device__ __forceinline__ void block_sum4_rows(const double (&v)[NV], double* scratch, double* out) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const double s = wave_row_sum(v[k]);
+        if ((lane & 15) == 0) scratch[(w * 4 + (lane >> 4)) * NV + k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double s = 0;
+        for (int ww = 0; ww < 4; ++ww) {
+            const double* r4 = &scratch[ww * 4 * NV + threadIdx.x];
+            s += (r4[0] + r4[NV]) + (r4[2 * NV] + r4[3 * NV]);
+        }
+        out[threadIdx.x] = s;
+    }
+    __syncthreads();
+}
+
 // Sum NV per-thread values over the workgroup (<= 16 waves).  Result in out[0..NV) (LDS), visible to all
 // threads after return.  scratch: LDS, >= 16*NV doubles.  Deterministic summation order.
 template <int NV>

@@ -869,21 +869,34 @@ struct gpmpc_graph_key {
     const void *x0, *U, *means, *vars, *cost_out, *grad, *ws; size_t ws_bytes;
     gpmpc_cost_params cost;
 };
+// A few captured rollouts per pack (least recently used is replaced): a caller alternating two shapes -- objective-only and
+// objective+gradient calls, two horizons, two batch sizes -- replays both instead of re-capturing on every call.
+#define GPMPC_GRAPH_SLOTS 4
 struct gpmpc_graph_cache {
-    hipStream_t stream; hipEvent_t ev_in, ev_out; hipGraphExec_t exec; int valid; gpmpc_graph_key key;
+    hipStream_t stream; hipEvent_t ev_in, ev_out;
+    hipGraphExec_t exec[GPMPC_GRAPH_SLOTS]; int valid[GPMPC_GRAPH_SLOTS]; unsigned long long used[GPMPC_GRAPH_SLOTS];
+    gpmpc_graph_key key[GPMPC_GRAPH_SLOTS];
+    unsigned long long tick; long long captures;
 };
 
 void gpmpc_graph_cache_free(void* c) {
     gpmpc_graph_cache* g = (gpmpc_graph_cache*)c;
     if (!g) return;
-    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->stream) (void)hipStreamSynchronize(g->stream);
+    for (int k = 0; k < GPMPC_GRAPH_SLOTS; ++k) if (g->exec[k]) (void)hipGraphExecDestroy(g->exec[k]);
     if (g->ev_in) (void)hipEventDestroy(g->ev_in);
     if (g->ev_out) (void)hipEventDestroy(g->ev_out);
     if (g->stream) (void)hipStreamDestroy(g->stream);
     free(g);
 }
 
-// Replay the 2H+1 launches of a rollout as ONE hipGraph on a stream owned by the pack (the caller's stream may be the
+// number of graph captures this pack has done so far (tests: alternating shapes must not re-capture)
+extern "C" long long gpmpc_pack_graph_captures(const gpmpc_pack* p) {
+    const gpmpc_graph_cache* g = p ? (const gpmpc_graph_cache*)p->graph_cache : nullptr;
+    return g ? g->captures : 0;
+}
+
+// Replay the launches of a rollout as ONE hipGraph on a stream owned by the pack (the caller's stream may be the
 // legacy default stream, which cannot be captured); ordered against the caller's stream with two events.
 static int graph_rollout(gpmpc_pack* p, int B, int H, const double* x0, const double* U, const gpmpc_cost_params* cost,
                          unsigned flags, double* out_means, double* out_vars, double* out_cost, double* out_grad,
@@ -901,9 +914,19 @@ static int graph_rollout(gpmpc_pack* p, int B, int H, const double* x0, const do
     memset(&k, 0, sizeof(k));
     k.B = B; k.H = H; k.flags = flags; k.x0 = x0; k.U = U; k.means = out_means; k.vars = out_vars; k.cost_out = out_cost;
     k.grad = out_grad; k.ws = workspace; k.ws_bytes = workspace_bytes; k.cost = *cost;
-    if (!g->valid || memcmp(&k, &g->key, sizeof(k)) != 0) {
-        if (g->exec) { (void)hipGraphExecDestroy(g->exec); g->exec = nullptr; }
-        g->valid = 0;
+    int slot = -1, lru = 0;
+    for (int q = 0; q < GPMPC_GRAPH_SLOTS; ++q) {
+        if (g->valid[q] && memcmp(&k, &g->key[q], sizeof(k)) == 0) { slot = q; break; }
+        if (!g->valid[q]) { if (g->valid[lru]) lru = q; }
+        else if (g->valid[lru] && g->used[q] < g->used[lru]) lru = q;
+    }
+    if (slot < 0) {
+        slot = lru;
+        if (g->exec[slot]) {                               // its last replay may still be running
+            (void)hipStreamSynchronize(g->stream);
+            (void)hipGraphExecDestroy(g->exec[slot]); g->exec[slot] = nullptr;
+        }
+        g->valid[slot] = 0;
         hipGraph_t graph = nullptr;
         GPMPC_HIP(hipStreamBeginCapture(g->stream, hipStreamCaptureModeThreadLocal));
         int rc = enqueue_rollout(p, B, H, x0, U, cost, flags, out_means, out_vars, out_cost, out_grad, workspace,
@@ -911,14 +934,15 @@ static int graph_rollout(gpmpc_pack* p, int B, int H, const double* x0, const do
         hipError_t e = hipStreamEndCapture(g->stream, &graph);
         if (rc != GPMPC_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
         if (e != hipSuccess) { gpmpc_set_error("hipStreamEndCapture", e); return GPMPC_E_LAUNCH; }
-        e = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
+        e = hipGraphInstantiate(&g->exec[slot], graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
         if (e != hipSuccess) { gpmpc_set_error("hipGraphInstantiate", e); return GPMPC_E_LAUNCH; }
-        g->key = k; g->valid = 1;
+        g->key[slot] = k; g->valid[slot] = 1; ++g->captures;
     }
+    g->used[slot] = ++g->tick;
     GPMPC_HIP(hipEventRecord(g->ev_in, user));
     GPMPC_HIP(hipStreamWaitEvent(g->stream, g->ev_in, 0));
-    GPMPC_HIP(hipGraphLaunch(g->exec, g->stream));
+    GPMPC_HIP(hipGraphLaunch(g->exec[slot], g->stream));
     GPMPC_HIP(hipEventRecord(g->ev_out, g->stream));
     GPMPC_HIP(hipStreamWaitEvent(user, g->ev_out, 0));
     return GPMPC_OK;

@@ -307,13 +307,17 @@ __global__ __launch_bounds__(256) void k_step_fused(FusedArgs A, int t) {
         GPMPC_STAMP(5);
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
-            const double s = wave_sum(acc[m]);
-            if (lane == 0) s_red[w * NM + m] = s;
+            const double s = wave_row_sum(acc[m]);                   // rows of 16 lanes; the combine below adds 16 values
+            if ((lane & 15) == 0) s_red[(w * 4 + (lane >> 4)) * NM + m] = s;
         }
         __syncthreads();
         GPMPC_STAMP(6);
         if (tid < NM) {
-            const double s = (s_red[tid] + s_red[NM + tid]) + (s_red[2 * NM + tid] + s_red[3 * NM + tid]);
+            double s = 0.0;
+            for (int ww = 0; ww < 4; ++ww) {
+                const double* r4 = &s_red[ww * 4 * NM + tid];
+                s += (r4[0] + r4[NM]) + (r4[2 * NM] + r4[3 * NM]);
+            }
             A.part[(((size_t)pcur * A.B + b) * A.nwork + blockIdx.x) * A.nm + tid] = s;
             if (tid == 0) A.partz[((size_t)pcur * A.B + b) * A.nwork + blockIdx.x] = s;
         }
@@ -410,7 +414,7 @@ __global__ __launch_bounds__(256) void k_step_fused(FusedArgs A, int t) {
         for (int k = 0; k < D; ++k) { v[1 + k] = fma(p, d[k], v[1 + k]); v[1 + D + k] = fma(p * d[k], d[k], v[1 + D + k]); }
     }
     GPMPC_STAMP(5);
-    block_sum<NV>(v, s_red, s_out);
+    block_sum4_rows<NV>(v, s_red, s_out);
     GPMPC_STAMP(6);
     if (tid < D) {
         const int k = tid;

@@ -196,7 +196,9 @@ def rollout(pack, x0, U, cost, want_grad=True, want_traj=True, graph=False, prec
                 buf["grad"] = cg[B:].view(B, H, da)
             if want_traj:
                 buf["means"], buf["vars"] = e(B, H + 1, pack.ds), e(B, H + 1, pack.ds)
-            pack._graph_bufs = {key: buf}                    # one captured shape at a time
+            if len(pack._graph_bufs) >= 4:                   # the library keeps 4 captured shapes per pack
+                pack._graph_bufs.pop(next(iter(pack._graph_bufs)))
+            pack._graph_bufs[key] = buf
         buf["x0"].copy_(x0)
         if U_host is not None:
             # the previous copy out of the pinned buffer has completed: every graph call is followed by a synchronising

@@ -47,10 +47,10 @@ extern "C" {
 
 /* flags for gpmpc_rollout / gpmpc_moment_match */
 #define GPMPC_WANT_GRAD      1u   /* also produce d cost / d U (rollout) or input Jacobians (moment_match) */
-#define GPMPC_USE_GRAPH      4u   /* gpmpc_rollout: replay the 2H+1 launches as one hipGraph.  The caller promises that
-                                     all pointer arguments (inputs, outputs, workspace) are the same buffers on every
-                                     call with this flag; a changed argument re-captures.  For launch-latency-bound
-                                     small batches (B = 1 solver loops). */
+#define GPMPC_USE_GRAPH      4u   /* gpmpc_rollout: replay the launches of the rollout as one hipGraph.  The caller promises
+                                     that the pointer arguments (inputs, outputs, workspace) are the same buffers on every
+                                     call of one shape with this flag; a changed argument captures anew (4 shapes are kept
+                                     per pack).  For launch-latency-bound small batches (B = 1 solver loops). */
 #define GPMPC_FP32_ACCUM     8u   /* gpmpc_rollout, objective only: N^2 products and their sum in fp32 (exponent / exp in fp64) */
 #define GPMPC_FP32_ALL      16u   /* gpmpc_rollout, objective only: transformed points, exponent, exp and sum in fp32.
                                      Both exist for the fp64-vs-fp32 tolerance sweep of BASELINE config 3: the variance is a
@@ -81,6 +81,9 @@ int gpmpc_pack_destroy(gpmpc_pack* pack);
 /* Re-read the GPMPC_* tuning environment variables for this pack (they are otherwise read once, at
  * gpmpc_pack_create) and drop its captured graph.  For A/B runs and tests; no reference counterpart. */
 int gpmpc_pack_reload_tuning(gpmpc_pack* pack);
+/* Number of hipGraph captures gpmpc_rollout(GPMPC_USE_GRAPH) has done for this pack (up to 4 captured call shapes are
+ * kept per pack, least recently used replaced).  Diagnostic; no reference counterpart. */
+long long gpmpc_pack_graph_captures(const gpmpc_pack* pack);
 
 /* Build K_f, K_y = K_f + noise_var*I for one GP on the device
  * (GaussianProcessRegression.build_Ky_inv_mat, src/gpr.py:163-170; the inverse at :171 is

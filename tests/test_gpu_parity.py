@@ -416,6 +416,17 @@ def test_graph_replay_matches_eager(G, golden):
     e = G.rollout(pack, z["x0"][0], z["U"][0], cost2)
     g = G.rollout(pack, z["x0"][0], z["U"][0], cost2, graph=True)
     assert torch.equal(e["cost"], g["cost"]) and torch.equal(e["grad"], g["grad"])
+    # a caller alternating two shapes (objective-only / objective+gradient, as a line search does) replays both: the
+    # pack keeps several captured graphs, nothing is re-captured after the first round
+    from gaussian_process_mpc_amd._lib import lib
+    pack2 = _pack_from(G, z)
+    for rep in range(4):
+        a = G.rollout(pack2, z["x0"][0], z["U"][0], cost, graph=True, want_traj=False)
+        b = G.rollout(pack2, z["x0"][0], z["U"][0], cost, graph=True, want_traj=False, want_grad=False)
+        assert abs(a["cost"][0].item() - b["cost"][0].item()) <= 1e-9 * abs(a["cost"][0].item())
+        if rep == 0:
+            first = lib().gpmpc_pack_graph_captures(pack2.handle)
+    assert first == 2 and lib().gpmpc_pack_graph_captures(pack2.handle) == 2
 
 
 def test_objective_gradient_callback_entry(G, golden):
