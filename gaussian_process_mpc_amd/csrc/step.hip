@@ -689,7 +689,9 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     const bool sb_ok = diag && p->da <= 2;
     // (N = 2048: 256x256 wins from B ~ 24 on: B = 16 3.4 k vs 3.7 k rollouts/s on 256x64, B = 32 4.6 k vs 4.3 k)
     const bool big = sb_ok ? (long)B * p->wl[0][0].nwork >= 3072 : (long)((B + 1) / 2) * p->wl[0][0].nwork >= 1024;
-    const bool mid = !big && sb_ok && (long)B * p->wl[0][2].nwork >= 1024;
+    // (round 2: 2048 instead of 1024 work items -- below that the one-launch-per-step kernel of step_fused.h wins: N = 2048,
+    // B = 2: 1.03 vs 1.19 ms per rollout; N = 1536, B = 4: 1.07 vs 1.23; N = 1024, B = 4: 0.67 vs 1.01)
+    const bool mid = !big && sb_ok && (long)B * p->wl[0][2].nwork >= 2048;
     r->sb = (sb_ok && (big || mid)) ? 1 : 0;
     const bool many = (long)p->wl[0][1].nwork > 256L * p->ds;        // > 256 one-wave tiles per GP (N >= 1472)
     r->tiling = big ? 0 : (mid ? 2 : (many ? 3 : 1));
@@ -712,7 +714,10 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     if (lowprec) { r->sb = 0; r->tiling = 0; r->tb = 1; }      // tolerance-sweep kernels: 256x256 work list, one trajectory per workgroup
     // Small batches on the 64-row work lists: ONE launch per horizon step (step_fused.h) instead of head + staged pair
     // kernel -- the B = 1 callbacks of a solver loop are pure dependent latency (GPMPC_FUSED=0 keeps the two-kernel form).
-    r->fused = (!r->sb && !lowprec && diag && (r->tiling == 1 || r->tiling == 3) && p->da <= 2 && tn.fused != 0) ? 1 : 0;
+    // (every workgroup of the fused kernel re-reduces the Z0 partials of ALL work items: quadratic in their number, fine up to
+    // a few thousand -- N = 2048 has 2112 --, 16x off at the 6336 items of N = 4096, which keeps the two-kernel form)
+    r->fused = (!r->sb && !lowprec && diag && (r->tiling == 1 || r->tiling == 3) && p->da <= 2 && tn.fused != 0 &&
+                p->wl[0][r->tiling].nwork <= 4096) ? 1 : 0;
     if (r->fused) r->tb = 1;
     // a quarter of a tile's columns per workgroup while whole tiles would leave most SIMDs without a wave
     r->fq = (r->fused && r->tiling == 1 && (long)B * p->wl[0][1].nwork < 256) ? 4 : 1;

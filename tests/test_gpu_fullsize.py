@@ -240,3 +240,26 @@ def test_c3_full_horizon_against_cport(G, c3):
     np.testing.assert_allclose(r["vars"].cpu().numpy(), c["vars"], rtol=1e-4)                    # north star
     np.testing.assert_allclose(r["cost"].cpu().numpy(), c["cost"], rtol=1e-6)
     np.testing.assert_allclose(r["grad"].cpu().numpy(), c["grad"], rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("cid", ["C1", "C2"])
+def test_small_configs_exact_workload_against_cport(G, cid):
+    """BASELINE configs 1 and 2 as bench.py runs them -- B = 1, the whole horizon, their own gamma, through the one-launch-
+    per-step path, as a captured graph AND through the solver-callback entry gpmpc_objective_gradient -- against the C port
+    (config 2 was only held to the reference at N = 128 through g4 before)."""
+    from oracle import cport, gpmpc_oracle as O
+    from gaussian_process_mpc_amd.synth import CONFIGS, synth_problem
+    cfg = CONFIGS[cid]
+    pb = synth_problem(int(cid[1]), cfg["N"], cfg["ds"], cfg["da"], cfg["H"], 1)
+    kinv = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"]).Ky_inv.numpy()
+    pack = G.GPPack(pb["X"], pb["Y"], kinv, pb["lambdas"], pb["sigma_f"])
+    cost = G.CostParams(cfg["gamma"], pb["Q"], pb["R"])
+    c = cport.rollout(pb, kinv, cfg["gamma"], nthreads=8)
+    for graph in (False, True):
+        r = G.rollout(pack, pb["x0"], pb["U"], cost, graph=graph)
+        np.testing.assert_allclose(r["means"].cpu().numpy(), c["means"], rtol=1e-5, atol=1e-9)       # north star
+        np.testing.assert_allclose(r["vars"].cpu().numpy(), c["vars"], rtol=1e-4)                    # north star
+        np.testing.assert_allclose(r["cost"].cpu().numpy(), c["cost"], rtol=1e-6)
+        np.testing.assert_allclose(r["grad"].cpu().numpy(), c["grad"], rtol=1e-4, atol=1e-7)
+    cg = pack.objective_gradient(pb["x0"][0], pb["U"][0], cost)
+    assert cg[0] == r["cost"][0].item() and np.array_equal(cg[1:], r["grad"][0].cpu().numpy().reshape(-1))

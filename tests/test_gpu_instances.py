@@ -2,8 +2,8 @@
 
 The rollout picks its kernel by the amount of work (csrc/step.hip::plan_rollout, csrc/moment.hip::plan_mom):
 
-    staged kernel, 64-row tiles      (pair_kernel.h)      small batches
-    scalar broadcast, 256x64 tiles   (pair_kernel_sb.h)   B * tiles >= 1024, one trajectory per wave
+    one launch per step, 64-row tiles (step_fused.h)      small batches (the staged pair_kernel.h with GPMPC_FUSED=0 / full S)
+    scalar broadcast, 256x64 tiles   (pair_kernel_sb.h)   B * tiles >= 2048, one trajectory per wave
     scalar broadcast, 256x256 tiles  (pair_kernel_sb.h)   B * tiles >= 3072, two trajectories per wave up to D = 5
     scalar broadcast, full S         (pair_kernel_sbf.h)  full-covariance rollout / moment matching on large batches
 
@@ -45,7 +45,7 @@ def test_diag_rollout_every_shape_vs_cport(G, ds, da):
     N, H = 150, 3                                   # Np = 192: 1 row tile, 3 column chunks of the 256x64 work list
     b_big = 3072 // ds + 3                          # B * ds >= 3072 work items -> 256x256 tiles
     b_big += 1 - b_big % 2                          # odd on purpose (the last wave of the two-trajectory shape is half empty)
-    b_mid = 1024 // (3 * ds) + 2                    # B * 3 ds >= 1024 -> 256x64 tiles
+    b_mid = 2048 // (3 * ds) + 2                    # B * 3 ds >= 2048 -> 256x64 tiles
     pb, kinv = _problem(40 + 8 * ds + da, N, ds, da, H, b_big)
     pack = G.GPPack(pb["X"], pb["Y"], kinv, pb["lambdas"], pb["sigma_f"])
     cost = G.CostParams(-1.0, pb["Q"], pb["R"])
