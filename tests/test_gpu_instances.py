@@ -129,3 +129,30 @@ def test_moment_match_full_S_large_D_vs_cport(G, D, ds):
             fd = (rp[key][0] - rm[key][0]).cpu().numpy() / (2 * eps)
             an = r[ju][q].cpu().numpy() @ du + np.einsum("akl,kl->a", r[jS][q].cpu().numpy(), dS)
             np.testing.assert_allclose(an, fd, rtol=2e-4, atol=1e-6 * max(1.0, np.abs(fd).max()), err_msg=key)
+
+
+@pytest.mark.parametrize("ds,da", [(1, 1), (2, 2), (4, 1), (6, 1), (5, 2)])
+def test_two_kernel_small_batch_form_vs_cport(G, ds, da, monkeypatch):
+    """GPMPC_FUSED=0 keeps the round-1 form for small batches (head kernel + staged pair_kernel.h per step; also what a
+    64-row work list with more than 4096 items falls back to): its diagonal-S gradient instances (one and two trajectories
+    per workgroup) against the C port, and against the default one-launch-per-step path on the same inputs."""
+    from oracle import cport
+    N, H = 150, 3
+    pb, kinv = _problem(120 + 8 * ds + da, N, ds, da, H, 5)
+    cost = G.CostParams(-1.0, pb["Q"], pb["R"])
+    fused = G.GPPack(pb["X"], pb["Y"], kinv, pb["lambdas"], pb["sigma_f"])
+    monkeypatch.setenv("GPMPC_FUSED", "0")
+    two = G.GPPack(pb["X"], pb["Y"], kinv, pb["lambdas"], pb["sigma_f"])            # tuning is read at pack creation
+    monkeypatch.delenv("GPMPC_FUSED")
+    c = cport.rollout(pb, kinv, -1.0, nthreads=8)
+    for B in (1, 2, 5):
+        r = G.rollout(two, pb["x0"][:B], pb["U"][:B], cost)
+        f = G.rollout(fused, pb["x0"][:B], pb["U"][:B], cost)
+        np.testing.assert_allclose(r["means"].cpu().numpy(), c["means"][:B], rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(r["vars"].cpu().numpy(), c["vars"][:B], rtol=1e-4, atol=1e-12)
+        np.testing.assert_allclose(r["cost"].cpu().numpy(), c["cost"][:B], rtol=1e-6)
+        np.testing.assert_allclose(r["grad"].cpu().numpy(), c["grad"][:B], rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(f["cost"].cpu().numpy(), r["cost"].cpu().numpy(), rtol=1e-8)
+        assert not torch.equal(f["vars"], r["vars"]) or N < 64        # two different kernels really ran
+        o = G.rollout(two, pb["x0"][:B], pb["U"][:B], cost, want_grad=False)
+        np.testing.assert_allclose(o["cost"].cpu().numpy(), r["cost"].cpu().numpy(), rtol=1e-9)
