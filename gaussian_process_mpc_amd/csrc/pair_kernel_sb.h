@@ -11,8 +11,10 @@
 // The column rows G[j] = [h_j1..h_jD | q_j N/ln2 | h_j1^2..h_jNS2^2] are written once per (trajectory, GP, step) by the head
 // kernel (step.hip) and read here through wave-uniform addresses, i.e. as SCALAR loads into SGPRs that the fp64 VALU
 // instructions take as their one scalar operand: no LDS staging, no barrier in the loop, no per-lane h_j registers.
-// Per pair the VALU issues 1 + D (exponent) + 9 (table exp) + 1 (M_ij e) + 1 + D + NS2 (r, v, w) fp64 instructions:
-// 26 for D = 5, NS2 = 4 against 35 for the staged form, whose adds/squares of m are gone.  The exponent is the
+// Per pair the VALU issues 1 + D (exponent) + 7 (table exp, fast_exp.h) + 1 (M_ij e) + 1 + D + NS2 (r, v, w) fp64-rate
+// instructions + 3 integer ones: 24 + 3 for D = 5, NS2 = 4 (30 + 3 for D = 7, NS2 = 6) against 35 for the staged form, whose
+// adds/squares of m are gone.  At the measured 4.4 / 2.5 cycles per wave64 instruction (tools/ubench/valu_op_cost.hip)
+// that is 115 (141) issue cycles per pair, and the kernel runs at ~95 % of it.  The exponent is the
 // expanded form the reference itself uses (:380-389, u A u + X A X^T - ...), here centred on u (h = sc (u - x)), so
 // its absolute error is ~1e-16 (q_i + q_j) instead of ~1e-16 |m|^2; still fp64 throughout.
 // fp64 MFMA cannot help here: on MI355X it shares the fp64 VALU's issue capacity (profiles/r01/ubench_mfma_f64_overlap.txt).
@@ -202,8 +204,9 @@ __global__ __launch_bounds__(256, (TB == 2 && D <= 5) ? GPMPC_SB_TB2_WAVES : 1) 
 }
 
 // `rows` = rows per tile of the work list (64 or 256) = threads per workgroup.
-// TB = 1 (59 VGPRs, 8 waves/SIMD at D = 5) is the fastest shape on MI355X: occupancy hides the scalar-load and
-// table-read latencies (C3: 2.20 ms per launch; TB 2: 2.41 with the 10-slot exp; two rows per lane: 2.65; staged pair_kernel.h TB 2: 2.82).
+// Shapes measured on C3 (round 2, 7-slot exp): two trajectories per wave compiled for 5 waves/SIMD 2.00 ms per launch, one
+// per wave at 8 waves/SIMD 2.05, two per wave squeezed into the 80 registers of 6 waves/SIMD 2.36 (profiles/r02); D = 7
+// (C4) runs one trajectory per wave: 63 VGPRs, 8 waves/SIMD -- a 64th-register crossing costs 3 % there.
 template <int D, int TB, int NS2, bool GRAD, bool FIRST = false>
 static int launch_pair_sb_one(int rows, const PairSbArgs& a, hipStream_t s) {
     dim3 grid(((a.B + TB - 1) / TB) * a.nwork), block(rows);
