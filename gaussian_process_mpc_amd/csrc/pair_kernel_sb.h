@@ -37,7 +37,9 @@
 // Waves per SIMD the two-trajectory shape is compiled for.  5 (96 registers; the loop needs 85): with the 7-slot exp the
 // 80-register cap of 6 waves/SIMD made the compiler re-materialise a constant and an address in every iteration and
 // spill; measured on one MI355X (C3): 6 waves 5.31 k rollouts/s, one trajectory per wave at 8 waves 6.07 k, 5 waves 6.24 k
-// (the 9-slot exp it replaces: 5.98-6.02 k at 6 waves) -- gpurun_out/r02_job2, profiles/r02/README.md.
+// (the 9-slot exp it replaces: 5.98-6.02 k at 6 waves) -- profiles/r02/README.md.  The interleaving of the two trajectories'
+// dependency chains is what the shape is for: with a sched_barrier between them the loop fits 80 registers (6 waves)
+// but runs 8 % slower, 20 % slower at 5 waves.
 #define GPMPC_SB_TB2_WAVES 5
 #endif
 
