@@ -424,7 +424,14 @@ def run_rank(args):
                 "gpu_over_c_port": (value / res["cport"]) if res.get("cport") else None,
             }
         assert out["n_gpus"] == args.gpus
-        print(json.dumps(out), flush=True)
+
+        def _clean(v):                       # strict JSON: no NaN / Infinity (graph replay has no per-kernel timing)
+            if isinstance(v, dict):
+                return {k: _clean(x) for k, x in v.items()}
+            if isinstance(v, float) and (v != v or v in (float("inf"), float("-inf"))):
+                return None
+            return v
+        print(json.dumps(_clean(out), allow_nan=False), flush=True)
     if world > 1:
         dist.destroy_process_group()
     return 0
