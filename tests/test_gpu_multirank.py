@@ -43,3 +43,16 @@ def test_two_ranks_on_one_card_match_the_single_process_batch(tmp_path):
         assert np.array_equal(z[tag + "_grad"], r["grad"].cpu().numpy()), tag
         assert z[tag + "_grad"].shape == (B, 5, 1)
     assert torch.isfinite(r["cost"]).all()
+
+
+def test_rccl_backend_code_path_world1():
+    """The one-GPU box cannot run two RCCL ranks, but it can run ONE: initialise the "nccl" (= RCCL) backend the way bench.py
+    does and drive the RCCL branches of the sharding layer (all_gather_into_tensor of [cost|grad], the inverse-matrix
+    broadcast, the max-reduce and barrier of the timing bracket) on real device tensors."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run([sys.executable, os.path.join(HERE, "_nccl_world1_worker.py"), str(port)], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "rccl world-1 ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
