@@ -239,7 +239,10 @@ __global__ __launch_bounds__(256) void k_step_fused(FusedArgs A, int t) {
             uk = u_act; sk = GPMPC_ACTION_VAR;                    // src/dynamics.py:162
         }
         s_uin[k] = uk; s_sin[k] = sk;
-        const double sc = sqrt(0.125 / (0.5 * lam_k + sk));       // (thread k < D sits in wave 0, which loaded lam_k, sp_*, u_act)
+        // sqrt(0.125 / x) as rsqrt(8 x): v_rsq_f64 + refinement instead of a division and a square root, which were ~900
+        // cycles of dependent latency on the critical path of every launch (thread k < D sits in wave 0, which loaded
+        // lam_k, sp_*, u_act); tile and mean-sum workgroups run this same expression, the finish workgroups read it from sp
+        const double sc = rsqrt(8.0 * (0.5 * lam_k + sk));
         s_sck[k] = sc;
         s_cv[k] = sc * uk;
     }
