@@ -687,8 +687,13 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     //   64x64 / 64x128 tiles, staged kernel      everything smaller (too few waves to hide the scalar loads); the rows
     //                                            of a tile are shared by 4 waves that split its columns
     const bool sb_ok = diag && p->da <= 2;
-    // (N = 2048: 256x256 wins from B ~ 24 on: B = 16 3.4 k vs 3.7 k rollouts/s on 256x64, B = 32 4.6 k vs 4.3 k)
-    const bool big = sb_ok ? (long)B * p->wl[0][0].nwork >= 3072 : (long)((B + 1) / 2) * p->wl[0][0].nwork >= 1024;
+    // 256x256 tiles once they give enough workgroups (profiles/r02/batch_size_map.txt): with two trajectories per wave
+    // (D <= 5) from ~2800 on -- N = 2048: B = 32 5.28 k rollouts/s vs 5.45 k on 256x64, B = 48 equal, B = 64 6.02 k vs 5.76 k;
+    // N = 1024: B = 96 18.5 k vs 19.2 k, B = 128 20.5 k vs 20.0 k --, with one per wave (D >= 6) from ~1500 on -- N = 4096, ds = 6:
+    // ahead at every batch size from B = 2 (295 vs 282 rollouts/s) on.
+    const bool tb2 = D <= 5 && B >= 2;
+    const long wg0 = (long)(tb2 ? (B + 1) / 2 : B) * p->wl[0][0].nwork;
+    const bool big = sb_ok ? wg0 >= (tb2 ? 2800 : 1500) : (long)((B + 1) / 2) * p->wl[0][0].nwork >= 1024;
     // (round 2: 2048 instead of 1024 work items -- below that the one-launch-per-step kernel of step_fused.h wins: N = 2048,
     // B = 2: 1.03 vs 1.19 ms per rollout; N = 1536, B = 4: 1.07 vs 1.23; N = 1024, B = 4: 0.67 vs 1.01)
     const bool mid = !big && sb_ok && (long)B * p->wl[0][2].nwork >= 2048;

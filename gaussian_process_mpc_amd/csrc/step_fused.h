@@ -61,6 +61,9 @@ static __device__ unsigned long long g_fused_stamps[64];
 #ifndef GPMPC_FUSED_TABLE
 #define GPMPC_FUSED_TABLE 0
 #endif
+#ifndef GPMPC_FUSED_UNROLL
+#define GPMPC_FUSED_UNROLL 4    // columns of the evaluation loop in flight per wave (16 = all of a whole tile's share)
+#endif
 #define GPMPC_FUSED_PZ 4        // Z0 partials of one GP prefetched per thread: covers 256 * 4 workgroups per GP
 
 // layout of sp (doubles), as step.hip: 0 c | 1 mu | 2 sf2 | 3 A[D] | 3+D scale[D] | 3+2D dmu_du[D] | 3+3D dmu_ds[D]
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(256) void k_step_fused(FusedArgs A, int t) {
             first = false;
             __syncthreads();
             GPMPC_STAMP(4);
-#pragma unroll
+#pragma unroll GPMPC_FUSED_UNROLL
             for (int q = 0; q < CW; ++q) {
                 const double* hj = &s_hj[(w * CW + q) * DP];
                 double m[D], sq[D];

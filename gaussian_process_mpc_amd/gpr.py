@@ -35,6 +35,10 @@ class GaussianProcessRegression(object):
         self._built_hypers = None   # (lambdas, sigma_f, noise variance) the current Kf / Ky / Ky_inv were built with
         self._appends_since_rebuild = 0
         self.rebuild_every = 64     # incremental appends between two full rebuilds (bounds the accumulated round-off)
+        # "lu": torch.linalg.inv, the reference's own call (src/gpr.py:171) and the default, so that Ky_inv carries the
+        # reference's round-off.  "cholesky": potrf + potri (SURVEY 8 f1 as sketched): a third of the flops and a symmetric
+        # result, but NOT the reference's numerics -- the variances move by ~1e-5 relative at sigma_n = 1e-5.
+        self.inverse = "lu"
 
     # -- hyper-parameters: same expressions as the reference setters (src/gpr.py:51-88), including the
     #    dtype inference of torch.tensor (a Python float / list is float32 before the log).  Like the
@@ -163,7 +167,12 @@ class GaussianProcessRegression(object):
         with torch.cuda.device(self.device):
             check(lib().gpmpc_build_ky(n, self.x_dim, ptr(X), lp, sigma_f, noise, ptr(self.Kf), ptr(self.Ky),
                                        stream_ptr()), "gpmpc_build_ky")
-        self.Ky_inv = torch.linalg.inv(self.Ky)
+        if self.inverse == "lu":
+            self.Ky_inv = torch.linalg.inv(self.Ky)
+        elif self.inverse == "cholesky":
+            self.Ky_inv = torch.cholesky_inverse(torch.linalg.cholesky(self.Ky))
+        else:
+            raise ValueError("GaussianProcessRegression.inverse must be 'lu' or 'cholesky', got %r" % (self.inverse,))
         self._beta = None
         self.version += 1
         self._built_hypers = (tuple(float(v) for v in lam), float(sigma_f), noise)

@@ -67,6 +67,34 @@ def test_gpr_closed_form_kernel(G):
     np.testing.assert_allclose(f[:, 0], Kf @ with_nom.Ky_inv.cpu().numpy() @ resid + 2.0 * X[:, 0], rtol=1e-12)
 
 
+def test_gpr_cholesky_inverse_option(G, golden):
+    """inverse="cholesky" (potrf + potri, SURVEY 8 f1 as sketched) is an opt-in: same matrices, a symmetric inverse that
+    agrees with the reference's LU inverse to round-off x condition number, and the default stays LU."""
+    z = golden("g6_gp.npz")
+    gps = []
+    for mode in ("lu", "cholesky"):
+        gp = G.GaussianProcessRegression(3)
+        assert gp.inverse == "lu"
+        gp.inverse = mode
+        gp.set_lambdas(z["lam"])
+        gp.set_sigma_f(1.4)
+        gp.set_sigma_n(0.2)
+        gp.append_train_data(z["X"], z["y"])
+        gps.append(gp)
+    lu, ch = (g.Ky_inv.cpu().numpy() for g in gps)
+    np.testing.assert_allclose(lu, z["Ky_inv"], rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(ch, z["Ky_inv"], rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(ch, ch.T, rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(ch @ z["Ky"], np.eye(64), atol=1e-10)
+    f_lu, _ = gps[0].predict_latent_vars(z["Xp"])
+    f_ch, _ = gps[1].predict_latent_vars(z["Xp"])
+    np.testing.assert_allclose(f_ch, f_lu, rtol=1e-9)
+    bad = G.GaussianProcessRegression(3)
+    bad.inverse = "qr"
+    with pytest.raises(ValueError):
+        bad.append_train_data(z["X"][:4], z["y"][:4])
+
+
 @pytest.mark.parametrize("tag", ["a", "c"])
 def test_prop_torch_mirrors(G, golden, tag):
     """mean_prop_torch / variance_prop_torch / covariance_prop_torch called like the reference's tests

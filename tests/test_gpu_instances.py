@@ -4,7 +4,7 @@ The rollout picks its kernel by the amount of work (csrc/step.hip::plan_rollout,
 
     one launch per step, 64-row tiles (step_fused.h)      small batches (the staged pair_kernel.h with GPMPC_FUSED=0 / full S)
     scalar broadcast, 256x64 tiles   (pair_kernel_sb.h)   B * tiles >= 2048, one trajectory per wave
-    scalar broadcast, 256x256 tiles  (pair_kernel_sb.h)   B * tiles >= 3072, two trajectories per wave up to D = 5
+    scalar broadcast, 256x256 tiles  (pair_kernel_sb.h)   >= 2800 workgroups of two trajectories per wave (D <= 5), >= 1500 of one
     scalar broadcast, full S         (pair_kernel_sbf.h)  full-covariance rollout / moment matching on large batches
 
 and each is instantiated per (D, state_dim, GRAD, FIRST).  The cases below drive every (state_dim, action_dim) with
@@ -43,7 +43,7 @@ def test_diag_rollout_every_shape_vs_cport(G, ds, da):
     later steps) at every input dimension, against the C port's values and analytic adjoint."""
     from oracle import cport
     N, H = 150, 3                                   # Np = 192: 1 row tile, 3 column chunks of the 256x64 work list
-    b_big = 3072 // ds + 3                          # B * ds >= 3072 work items -> 256x256 tiles
+    b_big = 5600 // ds + 3                          # ceil(B / 2) * ds >= 2800 workgroups (D <= 5; B * ds >= 1500 above) -> 256x256 tiles
     b_big += 1 - b_big % 2                          # odd on purpose (the last wave of the two-trajectory shape is half empty)
     b_mid = 2048 // (3 * ds) + 2                    # B * 3 ds >= 2048 -> 256x64 tiles
     pb, kinv = _problem(40 + 8 * ds + da, N, ds, da, H, b_big)

@@ -197,7 +197,7 @@ def test_large_batch_shape_vs_oracle(G, N, ds, da, H):
     from oracle import gpmpc_oracle as O
     from gaussian_process_mpc_amd.synth import synth_problem
     tiles = {1: 1, 2: 3}[(N + 255) // 256]
-    B = 3072 // (tiles * ds) + 77         # B * (tiles * ds) >= 3072 work items selects the shape; odd batch on purpose
+    B = 5600 // (tiles * ds) + 77         # ceil(B / 2) * (tiles * ds) >= 2800 workgroups selects the shape; odd batch on purpose
     B += 1 - B % 2
     pb = synth_problem(11, N, ds, da, H, B)
     gp = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"])

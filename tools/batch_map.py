@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Rollouts/s over (N, state_dim, batch size): where each kernel shape of plan_rollout (step.hip) sits against the
+pair-evaluation rate of the large-batch kernel.  Objective + gradient, inputs resident, each rollout replayed as one
+hipGraph below B = 32.  `eff` = pairs/s relative to the pair rate measured at the largest batch of the same (N, ds).
+
+    python tools/batch_map.py [--quick]            # optional GPMPC_TILING / GPMPC_PAIR_SB / GPMPC_FUSED overrides apply
+"""
+import argparse, os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gaussian_process_mpc_amd as g
+from gaussian_process_mpc_amd.rollout import CostParams, GPPack, rollout
+from gaussian_process_mpc_amd.synth import synth_problem
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--quick", action="store_true")
+ap.add_argument("--shapes", default="300:2:1:10,300:4:1:10,1024:4:1:20,2048:4:1:20,4096:6:1:30")
+ap.add_argument("--batches", default="1,2,4,8,16,32,64,128,256")
+args = ap.parse_args()
+dev = g.require_gpu()
+
+for shape in args.shapes.split(","):
+    N, ds, da, H = (int(v) for v in shape.split(":"))
+    bmax = max(int(b) for b in args.batches.split(","))
+    pb = synth_problem(3, N, ds, da, H, bmax)
+    X = torch.as_tensor(pb["X"], device=dev)
+    Y = torch.as_tensor(pb["Y"], device=dev)
+    kinv = []
+    for a in range(ds):
+        gp = g.GaussianProcessRegression(ds + da)
+        gp.set_lambdas(pb["lambdas"][a]); gp.set_sigma_f(np.array(1.0)); gp.set_sigma_n(np.array(pb["sigma_n"][a]))
+        gp.append_train_data(pb["X"], pb["Y"][:, a])
+        kinv.append(gp.Ky_inv)
+    pack = GPPack(X, Y, torch.stack(kinv), pb["lambdas"], pb["sigma_f"])
+    del kinv
+    cost = CostParams(-1.0, pb["Q"], pb["R"], x_ref=pb["x_ref"], u_ref=pb["u_ref"])
+    rows = []
+    for B in (int(b) for b in args.batches.split(",")):
+        if N >= 4096 and B > 128:
+            continue
+        x0 = torch.as_tensor(pb["x0"][:B], device=dev)
+        U = torch.as_tensor(pb["U"][:B], device=dev)
+        graph = B < 32
+        reps = max(3, min(200, int((2e9 if args.quick else 8e9) / (B * H * ds * N * N / 2 * 30))))
+        for _ in range(3):
+            rollout(pack, x0, U, cost, want_grad=True, want_traj=False, graph=graph)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            rollout(pack, x0, U, cost, want_grad=True, want_traj=False, graph=graph)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        rows.append((B, dt, B / dt))
+    pairs = H * ds * N * (N + 1) / 2
+    best = max(r[2] for r in rows)
+    print(f"N={N} ds={ds} da={da} H={H}  (pair-evaluations per rollout {pairs:.3g})")
+    for B, dt, rate in rows:
+        print(f"   B={B:4d}  {dt * 1e3:9.3f} ms per batch  {rate:10.1f} rollouts/s  {rate * pairs / 1e12:7.3f} Tpairs/s  eff {rate / best:5.2f}")
+    del pack
+    torch.cuda.empty_cache()
