@@ -67,11 +67,17 @@ __global__ __launch_bounds__(256) void k_mom_prep(MomArgs A) {
     __shared__ double s_u[D], s_S[D * D], s_B[D * D];
     __shared__ double s_scr[16 * NV], s_out[NV];
     __shared__ double s_tmp[2 * D * D];
-    const int q = blockIdx.x, ds = A.ds;
+    constexpr int GWT = (D + 1 + D * (D + 1) / 2 + 1) & ~1;          // widest G row at this D
+    constexpr bool STAGE = GWT <= 28;                               // 256 rows of it within the 64 KB of static LDS
+    __shared__ double s_g[STAGE ? 256 * GWT : 1];
+    // one workgroup per (query, unit): the per-unit set-up (D x D inverse, Cholesky factor, D^2 products) is the work of ONE
+    // thread, and looping over the units inside a workgroup put ds of those latencies in a row (C5: 400 us per launch)
+    const int q = blockIdx.x, ds = A.ds, unit = blockIdx.y;
     if (threadIdx.x < D) s_u[threadIdx.x] = A.u[(size_t)q * D + threadIdx.x];
     if (threadIdx.x < D * D) s_S[threadIdx.x] = A.S[(size_t)q * D * D + threadIdx.x];
     __syncthreads();
-    for (int a = 0; a < ds; ++a) {
+    if (unit < ds) {
+        const int a = unit;
         double* sp = A.sp + ((size_t)q * A.nunits + a) * A.sps;
         double* pp = A.pp + ((size_t)q * A.nunits + a) * A.pps;
         if (threadIdx.x == 0) {
@@ -172,7 +178,8 @@ __global__ __launch_bounds__(256) void k_mom_prep(MomArgs A) {
     // cross-covariance units (a < b): Gaussian-product form of covariance_prop_torch (:402-465)
     //   Lab = (La^-1 + Lb^-1)^-1, w_a = Lab La^-1, w_b = Lab Lb^-1, Bab = (S + Lab)^-1, c = det(Lab^-1 S + I)^-1/2,
     //   Cm^T Cm = Bab / 2, rows p_i = Cm (w_a o (u - x_i)), columns q_j = Cm (w_b o (u - x_j)).
-    for (int pr = threadIdx.x; pr < A.npairs; pr += blockDim.x) {
+    if (unit >= ds && threadIdx.x == 0) {
+        const int pr = unit - ds;
         const int a = A.pair_ab[2 * pr], b = A.pair_ab[2 * pr + 1];
         const double* la = A.lam + a * D; const double* lb = A.lam + b * D;
         double* sp = A.sp + ((size_t)q * A.nunits + ds + pr) * A.sps;
@@ -212,7 +219,8 @@ __global__ __launch_bounds__(256) void k_mom_prep(MomArgs A) {
     // Column rows of every unit for the scalar-broadcast pair kernel: [q_j (D) | |q_j|^2 | q_jk q_jl (k <= l < ns2) | pad]
     // with q_j = cvec_c - T_c x_j, the unit's COLUMN-side transform written above by this workgroup.
     __syncthreads();
-    for (int u = 0; u < A.nunits; ++u) {
+    {
+        const int u = unit;
         const double* prc = A.pp + ((size_t)q * A.nunits + u) * A.pps + D + D * D;
         double* Gu = A.G + ((size_t)q * A.nunits + u) * A.Np * A.gw;
         double cv[D], T[D * D];
@@ -220,27 +228,40 @@ __global__ __launch_bounds__(256) void k_mom_prep(MomArgs A) {
         for (int k = 0; k < D; ++k) cv[k] = prc[k];
 #pragma unroll
         for (int e = 0; e < D * D; ++e) T[e] = prc[D + e];
-        for (int i = threadIdx.x; i < A.Np; i += blockDim.x) {
-            double x[D], qv[D], qq = 0.0;
+        // The rows of 256 consecutive points are contiguous in G: staged through LDS and written lane-contiguously (a lane
+        // writing its own 8 gw-byte row stores 8 bytes into 64 different cache lines per instruction: C5 376 us per launch
+        // for 671 MB).  D >= 7 (rows of up to 46 doubles) keeps the direct stores: the staging buffer would not fit.
+        for (int i0 = 0; i0 < A.Np; i0 += blockDim.x) {
+            const int i = i0 + threadIdx.x;
+            if (i < A.Np) {
+                double x[D], qv[D], qq = 0.0;
 #pragma unroll
-            for (int k = 0; k < D; ++k) x[k] = A.XT[(size_t)k * A.Np + i];
-            double* g = Gu + (size_t)i * A.gw;
+                for (int k = 0; k < D; ++k) x[k] = A.XT[(size_t)k * A.Np + i];
+                double* g = STAGE ? s_g + (size_t)threadIdx.x * A.gw : Gu + (size_t)i * A.gw;
 #pragma unroll
-            for (int k = 0; k < D; ++k) {
-                double sacc = cv[k];
+                for (int k = 0; k < D; ++k) {
+                    double sacc = cv[k];
 #pragma unroll
-                for (int l = k; l < D; ++l) sacc = fma(-T[k * D + l], x[l], sacc);
-                qv[k] = sacc; g[k] = sacc;
-                qq = fma(sacc, sacc, qq);
+                    for (int l = k; l < D; ++l) sacc = fma(-T[k * D + l], x[l], sacc);
+                    qv[k] = sacc; g[k] = sacc;
+                    qq = fma(sacc, sacc, qq);
+                }
+                g[D] = GPMPC_EXP_NEG_INV_C * qq;                  // pre-scaled for gpmpc_exp_neg_scaled (fast_exp.h)
+                int o = D + 1;
+#pragma unroll
+                for (int k = 0; k < D; ++k)
+#pragma unroll
+                    for (int l = k; l < D; ++l)
+                        if (k < A.ns2 && l < A.ns2) { g[o] = qv[k] * qv[l]; ++o; }
+                for (; o < A.gw; ++o) g[o] = 0.0;
             }
-            g[D] = GPMPC_EXP_NEG_INV_C * qq;                  // pre-scaled for gpmpc_exp_neg_scaled (fast_exp.h)
-            int o = D + 1;
-#pragma unroll
-            for (int k = 0; k < D; ++k)
-#pragma unroll
-                for (int l = k; l < D; ++l)
-                    if (k < A.ns2 && l < A.ns2) { g[o] = qv[k] * qv[l]; ++o; }
-            for (; o < A.gw; ++o) g[o] = 0.0;
+            if (STAGE) {
+                __syncthreads();
+                const int rows = (A.Np - i0 < (int)blockDim.x) ? A.Np - i0 : (int)blockDim.x;
+                double* dst = Gu + (size_t)i0 * A.gw;
+                for (int e = threadIdx.x; e < rows * A.gw; e += blockDim.x) dst[e] = s_g[e];
+                __syncthreads();
+            }
         }
     }
 }
@@ -468,7 +489,7 @@ extern "C" size_t gpmpc_moment_match_workspace_bytes(const gpmpc_pack* p, int nq
 
 template <int D>
 static int run_mom(const gpmpc_pack* p, MomArgs& A, const MomPlan& r, bool grad, hipStream_t s, int* pairs_dev) {
-    hipLaunchKernelGGL(k_mom_prep<D>, dim3(A.nq), dim3(256), 0, s, A);
+    hipLaunchKernelGGL(k_mom_prep<D>, dim3(A.nq, A.nunits), dim3(256), 0, s, A);
     PairArgs P;
     P.M = p->M; P.XT = p->XT; P.pp = A.pp; P.part = A.part; P.work = p->wl[r.mode][r.tiling].work_dev;
     P.Np = p->Np; P.B = A.nq; P.nunits = r.nunits; P.nwork = r.nwork; P.pps = r.pps; P.nm = r.nm;
