@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void gpmpc_pair_kernel_sbf(PairSbfArgs A) {
 
     const double* __restrict__ prm = A.pp + ((size_t)b * A.nunits + unit) * A.pps;     // row-side transform
     const double* __restrict__ G = A.G + ((size_t)b * A.nunits + unit) * Np * GW;
-    double p[D], p2[D], qi = 0.0;
+    double p2[D], qi = 0.0;        // p_i is carried pre-scaled only (10 VGPRs at D = 5: 70 -> 7 waves/SIMD, 60 -> 8)
     {
         double x[D];
 #pragma unroll
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void gpmpc_pair_kernel_sbf(PairSbfArgs A) {
             double s = prm[k];
 #pragma unroll
             for (int l = k; l < D; ++l) s = fma(-prm[D + k * D + l], x[l], s);
-            p[k] = s; p2[k] = (2.0 * GPMPC_EXP_NEG_INV_C) * s;     // exponent carried as s * N/ln2 (fast_exp.h)
+            p2[k] = (2.0 * GPMPC_EXP_NEG_INV_C) * s;               // exponent carried as s * N/ln2 (fast_exp.h)
             qi = fma(s, s, qi);
         }
         qi *= GPMPC_EXP_NEG_INV_C;
@@ -89,6 +89,9 @@ __global__ __launch_bounds__(256) void gpmpc_pair_kernel_sbf(PairSbfArgs A) {
     z[0] = acc[0];
     if (GRAD) {
         const double r = acc[0];
+        double p[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) p[k] = (0.5 / GPMPC_EXP_NEG_INV_C) * p2[k];
 #pragma unroll
         for (int k = 0; k < D; ++k) z[1 + k] = fma(p[k], r, acc[GRAD ? 1 + k : 0]);
         int o = 1 + D, ow = 0;
