@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Long randomised parity soak of the diagonal rollout against the plain-C checker (oracle/cport): shapes, ragged N, batch
+sizes on both sides of every kernel-selection threshold, forced kernel shapes (tuning overrides + reload_tuning), eager /
+graph / solver-callback entries, objective-only calls.  Not part of the test-suite; run on the GPU box:
+    python tools/soak_parity.py [n_cases] [seed]
+Prints one line per case and a summary; exits non-zero if a case misses the north-star tolerances."""
+import os
+import sys
+import time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gaussian_process_mpc_amd as g
+from gaussian_process_mpc_amd.synth import synth_problem
+from oracle import cport, gpmpc_oracle as O
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+torch.set_num_threads(16)
+KNOBS = ("GPMPC_PAIR_SB", "GPMPC_PAIR_TB", "GPMPC_TILING", "GPMPC_FUSED", "GPMPC_NO_FIRST")
+SHAPES = {"auto": {}, "sb256": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "0"}, "sb64": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "2"},
+          "sb_tb1": {"GPMPC_PAIR_SB": "1", "GPMPC_PAIR_TB": "1"}, "staged": {"GPMPC_PAIR_SB": "0", "GPMPC_FUSED": "0"},
+          "staged_tb4": {"GPMPC_PAIR_SB": "0", "GPMPC_FUSED": "0", "GPMPC_PAIR_TB": "4"}, "nofirst": {"GPMPC_NO_FIRST": "1"}}
+worst = {"means": 0.0, "vars": 0.0, "cost": 0.0, "grad": 0.0}
+bad = 0
+t_start = time.time()
+for case in range(n_cases):
+    N = int(rng.choice([1, 3, 31, 64, 65, 127, 128, 200, 257, 300, 449, 512, 700, 1025, 1500, 2049]))
+    ds = int(rng.integers(1, 7)); da = int(rng.integers(1, 3))
+    if ds + da > 8:
+        ds = 8 - da
+    H = int(rng.integers(1, 10))
+    B = int(rng.choice([1, 1, 2, 3, 4, 7, 16, 40, 130, 600, 1500]))
+    if N >= 700:
+        B = min(B, 130)
+    gamma = float(rng.choice([-1.0, 1e-5, 0.0, 0.5]))
+    shape = str(rng.choice(list(SHAPES)))
+    entry = str(rng.choice(["eager", "graph", "callback"] if B == 1 else ["eager", "eager", "graph"]))
+    grad = bool(rng.random() < 0.8) or entry == "callback"
+    for k in KNOBS:
+        os.environ.pop(k, None)
+    os.environ.update(SHAPES[shape])
+    pb = synth_problem(5000 + case, N, ds, da, H, B)
+    pb["Q"] = pb["Q"] + 0.01 * (np.ones((ds, ds)) - np.eye(ds))
+    kinv = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"]).Ky_inv.numpy()
+    pack = g.GPPack(pb["X"], pb["Y"], kinv, pb["lambdas"], pb["sigma_f"])          # reads the overrides
+    cp = g.CostParams(gamma, pb["Q"], pb["R"])
+    if entry == "callback":
+        cg = pack.objective_gradient(pb["x0"][0], pb["U"][0], cp)
+        r = {"cost": torch.tensor(cg[:1]), "grad": torch.tensor(cg[1:]).reshape(1, H, da)}
+    else:
+        r = g.rollout(pack, pb["x0"], pb["U"], cp, want_grad=grad, graph=(entry == "graph"))
+        if entry == "graph":                       # replay once more: the captured graph, not the capture run
+            r = g.rollout(pack, pb["x0"], pb["U"], cp, want_grad=grad, graph=True)
+    pick = sorted({0, B // 2, B - 1})
+    c = cport.rollout(pb, kinv, gamma, x0=pb["x0"][pick], U=pb["U"][pick], nthreads=16)
+    rel = lambda a, ref, fl: float(np.max(np.abs(a - ref) / np.maximum(np.abs(ref), fl))) if a.size else 0.0   # noqa: E731
+    err = {k: 0.0 for k in worst}
+    if "means" in r:
+        err["means"] = rel(r["means"][pick].cpu().numpy(), c["means"], 1e-4)
+        err["vars"] = rel(r["vars"][pick].cpu().numpy(), c["vars"], 1e-8)
+    err["cost"] = rel(r["cost"][pick].cpu().numpy(), c["cost"], 1e-6)
+    if grad:
+        err["grad"] = rel(r["grad"][pick].cpu().numpy(), c["grad"], 1e-3)
+    finite = all(bool(torch.isfinite(v).all()) for v in r.values())
+    ok = finite and err["means"] < 1e-5 and err["vars"] < 1e-4 and err["cost"] < 1e-6 and err["grad"] < 1e-4
+    bad += 0 if ok else 1
+    print(f"case {case:3d}: N={N:4d} ds={ds} da={da} H={H} B={B:4d} gamma={gamma:g} {shape:10s} {entry:8s} grad={int(grad)} "
+          + " ".join(f"{k} {v:.1e}" for k, v in err.items()) + ("" if ok else "   <-- FAIL"), flush=True)
+    for k in worst:
+        worst[k] = max(worst[k], err[k])
+    del pack
+print(f"{n_cases} cases in {time.time() - t_start:.0f} s, {bad} outside the tolerances; worst:", {k: f"{v:.1e}" for k, v in worst.items()})
+sys.exit(1 if bad else 0)
