@@ -693,7 +693,11 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     // ahead at every batch size from B = 2 (295 vs 282 rollouts/s) on.
     const bool tb2 = D <= 5 && B >= 2;
     const long wg0 = (long)(tb2 ? (B + 1) / 2 : B) * p->wl[0][0].nwork;
-    const bool big = sb_ok ? wg0 >= (tb2 ? 2800 : 1500) : (long)((B + 1) / 2) * p->wl[0][0].nwork >= 1024;
+    // Small training sets (Np <= 512: at most 3 tiles per GP) switch earlier, from ~1100 workgroups: their 256x64 workgroups
+    // run 64 columns on at most 4 waves behind a full prologue (N = 512, ds = 3, B = 256: 2.82 vs 3.20 ms per batch of 20 steps;
+    // N = 300, ds = 2, B = 512: 0.88 vs 1.04 ms; N = 100, B = 2048: 1.30 vs 1.44 ms; below 1100 the 256x64 shape stays ahead).
+    const long thr2 = p->Np <= 512 ? 1100 : 2800;
+    const bool big = sb_ok ? wg0 >= (tb2 ? thr2 : 1500) : (long)((B + 1) / 2) * p->wl[0][0].nwork >= 1024;
     // (round 2: 2048 instead of 1024 work items -- below that the one-launch-per-step kernel of step_fused.h wins: N = 2048,
     // B = 2: 1.03 vs 1.19 ms per rollout; N = 1536, B = 4: 1.07 vs 1.23; N = 1024, B = 4: 0.67 vs 1.01)
     const bool mid = !big && sb_ok && (long)B * p->wl[0][2].nwork >= 2048;

@@ -29,6 +29,7 @@
 
 #ifdef CPLX
 typedef double complex num;
+typedef long double complex lnum;
 #define N_EXP cexp
 #define N_SQRT csqrt
 #define N_LOG clog
@@ -36,6 +37,7 @@ typedef double complex num;
 #define FN(name) name##_cplx
 #else
 typedef double num;
+typedef long double lnum;
 #define N_EXP exp
 #define N_SQRT sqrt
 #define N_LOG log
@@ -79,6 +81,7 @@ typedef struct {
  * ct [ds][ds] of the ds GP outputs.  V, AV, Z2: N x D scratch; gq: 2N scratch. */
 static void FN(step)(const ctx_t* c, const num* u, const num* S, num* mt, num* ct, num* V, num* AV, num* gq, num* Z2) {
     const int N = c->N, ds = c->ds, D = c->D;
+    num* rowsum = (num*)malloc(sizeof(num) * (size_t)N);
     for (int i = 0; i < N; ++i) for (int k = 0; k < D; ++k) V[(size_t)i * D + k] = u[k] - c->X[(size_t)i * D + k];
     num mu[MAXD];
     {
@@ -108,22 +111,18 @@ static void FN(step)(const ctx_t* c, const num* u, const num* S, num* mt, num* c
             }
             const double* W = c->Wv + (size_t)a * N * N;
             num T = 0.0;
-#pragma omp parallel
-            {
-                num tl = 0.0;
-#pragma omp for schedule(dynamic, 8) nowait
-                for (int i = 0; i < N; ++i) {
-                    const num* avi = AV + (size_t)i * D; num row = 0.0;
-                    for (int j = i; j < N; ++j) {
-                        const num* vj = V + (size_t)j * D; num G = 0.0;
-                        for (int r = 0; r < D; ++r) G += vj[r] * avi[r];
-                        row += (i == j ? 1.0 : 2.0) * W[(size_t)i * N + j] * N_EXP(-0.125 * (gq[i] + 2.0 * G + gq[j]));
-                    }
-                    tl += row;
+            /* row sums in parallel, then one fixed-order reduction in extended precision (independent of the thread count) */
+#pragma omp parallel for schedule(dynamic, 8)
+            for (int i = 0; i < N; ++i) {
+                const num* avi = AV + (size_t)i * D; num row = 0.0;
+                for (int j = i; j < N; ++j) {
+                    const num* vj = V + (size_t)j * D; num G = 0.0;
+                    for (int r = 0; r < D; ++r) G += vj[r] * avi[r];
+                    row += (i == j ? 1.0 : 2.0) * W[(size_t)i * N + j] * N_EXP(-0.125 * (gq[i] + 2.0 * G + gq[j]));
                 }
-#pragma omp critical
-                T += tl;
+                rowsum[i] = row;
             }
+            { lnum e = 0.0; for (int i = 0; i < N; ++i) e += rowsum[i]; T = (num)e; }
             mt[a] = mu[a];
             ct[a * ds + a] = sf2 - T / N_SQRT(det2) - mu[a] * mu[a];
         }
@@ -145,27 +144,23 @@ static void FN(step)(const ctx_t* c, const num* u, const num* S, num* mt, num* c
                 }
                 const double* ba = c->beta + (size_t)a * N; const double* bb = c->beta + (size_t)b * N;
                 num Qs = 0.0;
-#pragma omp parallel
-                {
-                    num ql = 0.0;
-#pragma omp for schedule(static) nowait
-                    for (int i = 0; i < N; ++i) {
-                        const num* wi = AV + (size_t)i * D; num row = 0.0;
-                        for (int j = 0; j < N; ++j) {
-                            const num* zj = Z2 + (size_t)j * D; num cr = 0.0;
-                            for (int r = 0; r < D; ++r) cr += wi[r] * zj[r];
-                            row += bb[j] * N_EXP(gq[2 * i] + gq[2 * j + 1] + cr);
-                        }
-                        ql += ba[i] * row;
+#pragma omp parallel for schedule(static)
+                for (int i = 0; i < N; ++i) {
+                    const num* wi = AV + (size_t)i * D; num row = 0.0;
+                    for (int j = 0; j < N; ++j) {
+                        const num* zj = Z2 + (size_t)j * D; num cr = 0.0;
+                        for (int r = 0; r < D; ++r) cr += wi[r] * zj[r];
+                        row += bb[j] * N_EXP(gq[2 * i] + gq[2 * j + 1] + cr);
                     }
-#pragma omp critical
-                    Qs += ql;
+                    rowsum[i] = ba[i] * row;
                 }
+                { lnum e = 0.0; for (int i = 0; i < N; ++i) e += rowsum[i]; Qs = (num)e; }
                 const double sfab = c->sf[a] * c->sf[a] * c->sf[b] * c->sf[b];
                 const num cv = sfab / N_SQRT(detR) * Qs - mu[a] * mu[b];
                 ct[a * ds + b] = cv; ct[b * ds + a] = cv;
             }
     }
+    free(rowsum);
 }
 
 /* one trajectory: means [H+1][ds], covs [H+1][ds][ds]; returns the cost (src/mpc.py:182-189) */
