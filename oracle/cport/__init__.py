@@ -13,7 +13,7 @@ def lib():
     global _LIB
     if _LIB is None:
         so = os.path.join(_HERE, "libgpmpc_cpu.so")
-        srcs = [os.path.join(_HERE, f) for f in ("gpmpc_cpu.c", "gpmpc_cpu_fullcov.c")]
+        srcs = [os.path.join(_HERE, f) for f in ("gpmpc_cpu.c", "gpmpc_cpu_fullcov.c", "gpmpc_cpu_ld.c")]
         if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
             subprocess.run(["make", "-C", _HERE], check=True, capture_output=True)
         _LIB = ctypes.CDLL(so)
@@ -40,6 +40,26 @@ def rollout(pb, Ky_inv, gamma, x0=None, U=None, nthreads=0):
     if rc != 0:
         raise RuntimeError(f"gpmpc_cpu_rollout failed: {rc}")
     return {"means": means, "vars": vars_, "cost": cost, "grad": grad}
+
+
+def rollout_extended(pb, Ky_inv, x0=None, U=None, nthreads=0):
+    """Forward pass (means, vars) of the diagonal rollout with every operation in x87 extended precision
+    (oracle/cport/gpmpc_cpu_ld.c): the yardstick for the noise-level accuracy sweep.  Small N only."""
+    c = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64))      # noqa: E731
+    p = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))          # noqa: E731
+    X, Y, lam, sf = c(pb["X"]), c(pb["Y"]), c(pb["lambdas"]), c(pb["sigma_f"])
+    x0 = c(pb["x0"] if x0 is None else x0).reshape(-1, pb["ds"])
+    U = c(pb["U"] if U is None else U)
+    U = U.reshape(-1, U.shape[-2], pb["da"])
+    B, H = U.shape[0], U.shape[1]
+    K = c(Ky_inv)
+    means = np.zeros((B, H + 1, pb["ds"])); vars_ = np.zeros((B, H + 1, pb["ds"]))
+    lib().gpmpc_cpu_rollout_ld.restype = ctypes.c_int
+    rc = lib().gpmpc_cpu_rollout_ld(X.shape[0], pb["ds"], pb["da"], H, B, p(X), p(K), p(Y), p(lam), p(sf), p(x0), p(U),
+                                    p(means), p(vars_), int(nthreads))
+    if rc != 0:
+        raise RuntimeError(f"gpmpc_cpu_rollout_ld failed: {rc}")
+    return {"means": means, "vars": vars_}
 
 
 def rollout_fullcov(pb, Ky_inv, gamma, x0=None, U=None, dirs=None, nthreads=0):
