@@ -78,7 +78,7 @@ class GPPack:
         n, npad, ds, da = (ctypes.c_int() for _ in range(4))
         lib().gpmpc_pack_dims(self._h, ctypes.byref(n), ctypes.byref(npad), ctypes.byref(ds), ctypes.byref(da))
         self.Np = npad.value
-        self._ws = None
+        self._ws = {}
         self._graph_bufs = {}
         self.fullcov = False
 
@@ -128,9 +128,14 @@ class GPPack:
         return self._h
 
     def workspace(self, nbytes):
-        if self._ws is None or self._ws.numel() < nbytes:
-            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
-        return self._ws
+        """Scratch for one call, one buffer per stream: calls on different streams may overlap on the device (the C ABI is
+        re-entrant across streams as long as the workspaces differ)."""
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            self._ws[key] = ws
+        return ws
 
     def beta(self):
         """(ds, N) copy of the cached beta vectors (for tests)."""

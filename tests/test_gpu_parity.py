@@ -400,6 +400,41 @@ def test_nan_passthrough(G, golden):
     assert torch.isnan(r["var"]).any() or torch.isnan(r["mean"]).any()
 
 
+def test_concurrent_streams_share_a_pack(G):
+    """include/gpmpc.h: calls are re-entrant across streams as long as the workspaces differ.  Two streams drive the same
+    pack with different batches, interleaved and overlapping on the device (with the per-kernel timing accumulators
+    switched on, which are shared state); every result equals the one the call gives on its own, bit for bit."""
+    from oracle import gpmpc_oracle as O
+    from gaussian_process_mpc_amd._lib import lib
+    from gaussian_process_mpc_amd.synth import synth_problem
+    pb = synth_problem(31, 700, 3, 1, 6, 96)
+    gp = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"])
+    pack = G.GPPack(pb["X"], pb["Y"], gp.Ky_inv.numpy(), pb["lambdas"], pb["sigma_f"])
+    cost = G.CostParams(-1.0, pb["Q"], pb["R"])
+    jobs = [(slice(0, 64), True), (slice(64, 96), True), (slice(10, 13), False), (slice(0, 96), True)]   # several kernel shapes
+    x0, U = torch.as_tensor(pb["x0"], device=pack.device), torch.as_tensor(pb["U"], device=pack.device)
+    alone = [G.rollout(pack, x0[s], U[s], cost, want_grad=g) for s, g in jobs]
+    torch.cuda.synchronize()
+    lib().gpmpc_timing_enable(1)
+    try:
+        streams = [torch.cuda.Stream(device=pack.device) for _ in range(2)]
+        got = [[None] * len(jobs) for _ in streams]
+        for rep in range(3):
+            for j, (s, g) in enumerate(jobs):
+                for k, st in enumerate(streams):
+                    jj = (j + k) % len(jobs)                      # the two streams run DIFFERENT jobs at the same time
+                    with torch.cuda.stream(st):
+                        got[k][jj] = G.rollout(pack, x0[jobs[jj][0]], U[jobs[jj][0]], cost, want_grad=jobs[jj][1])
+        torch.cuda.synchronize()
+    finally:
+        lib().gpmpc_timing_enable(0)
+        lib().gpmpc_pair_kernel_time(None, None, 1)              # drain and drop the recorded events
+    for k in range(2):
+        for j in range(len(jobs)):
+            for name in alone[j]:
+                assert torch.equal(alone[j][name], got[k][j][name]), (k, j, name)
+
+
 def test_graph_replay_matches_eager(G, golden):
     """GPMPC_USE_GRAPH: the captured launch sequence gives bit-identical results, survives new input values,
     a changed cost (re-capture) and interleaving with eager calls."""
