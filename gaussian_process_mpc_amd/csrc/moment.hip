@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void k_mom_prep(MomArgs A) {
     constexpr int NS2 = D * (D + 1) / 2, NV = 1 + D + NS2;
     __shared__ double s_u[D], s_S[D * D], s_B[D * D];
     __shared__ double s_scr[16 * NV], s_out[NV];
-    __shared__ double s_tmp[2 * D * D];
+    __shared__ double s_tmp[2 * D * D], s_tmpA[D * D], s_Cm[D * D], s_L[D * D], s_cm;
     constexpr int GWT = (D + 1 + D * (D + 1) / 2 + 1) & ~1;          // widest G row at this D
     constexpr bool STAGE = GWT <= 28;                               // 256 rows of it within the 64 KB of static LDS
     __shared__ double s_g[STAGE ? 256 * GWT : 1];
@@ -80,23 +80,28 @@ __global__ __launch_bounds__(256) void k_mom_prep(MomArgs A) {
         const int a = unit;
         double* sp = A.sp + ((size_t)q * A.nunits + a) * A.sps;
         double* pp = A.pp + ((size_t)q * A.nunits + a) * A.pps;
+        // Set-up of the unit: the mean side (B = (S + Lambda)^-1) and the variance side (A = (Lambda/2 + S)^-1, its Cholesky
+        // factor) are independent chains of D x D algebra: one lane each, in different waves, on LDS copies; the results go
+        // to global memory afterwards, one element per thread (the chains used to read their own global stores back).
         if (threadIdx.x == 0) {
             const double* lam = A.lam + a * D;
             double detlam = 1.0;
             for (int k = 0; k < D; ++k) detlam *= lam[k];
             // B = (S + Lambda)^-1, det(Lambda^-1 S + I) = det(S + Lambda) / det(Lambda)
-            for (int r = 0; r < D; ++r) for (int c = 0; c < D; ++c) s_tmp[r * D + c] = 0.5 * (s_S[r * D + c] + s_S[c * D + r]) + (r == c ? lam[r] : 0.0);
-            const double detm = small_inverse(D, s_tmp, s_B) / detlam;
+            for (int r = 0; r < D; ++r) for (int c = 0; c < D; ++c) s_tmpA[r * D + c] = 0.5 * (s_S[r * D + c] + s_S[c * D + r]) + (r == c ? lam[r] : 0.0);
+            const double detm = small_inverse(D, s_tmpA, s_B) / detlam;
+            const double sf = A.sf[a];
+            s_cm = sf * sf / sqrt(detm);
+        } else if (threadIdx.x == 64) {
+            const double* lam = A.lam + a * D;
             // A = (Lambda/2 + S)^-1, det(2 Lambda^-1 S + I) = det(S + Lambda/2) / det(Lambda/2)
             double dethalf = 1.0;
             for (int k = 0; k < D; ++k) dethalf *= 0.5 * lam[k];
             for (int r = 0; r < D; ++r) for (int c = 0; c < D; ++c) s_tmp[r * D + c] = 0.5 * (s_S[r * D + c] + s_S[c * D + r]) + (r == c ? 0.5 * lam[r] : 0.0);
-            double* Am = sp + 3;
             const double detv = small_inverse(D, s_tmp, s_tmp + D * D) / dethalf;
-            for (int e = 0; e < D * D; ++e) Am[e] = s_tmp[D * D + e];
-            // Cholesky A/8 = L L^T, Cm = L^T (upper)
-            double* Cm = sp + 3 + D * D;
-            double L[D * D];
+            const double* Am = s_tmp + D * D;
+            // Cholesky A/8 = L L^T, Cm = L^T (upper); L in LDS (one lane's D^2 doubles would be 2 D^2 registers of every lane)
+            double* L = s_L;
             for (int e = 0; e < D * D; ++e) L[e] = 0.0;
             for (int r = 0; r < D; ++r)
                 for (int c = 0; c <= r; ++c) {
@@ -104,41 +109,48 @@ __global__ __launch_bounds__(256) void k_mom_prep(MomArgs A) {
                     for (int l = 0; l < c; ++l) s -= L[r * D + l] * L[c * D + l];
                     L[r * D + c] = (r == c) ? sqrt(s) : s / L[c * D + c];
                 }
-            for (int r = 0; r < D; ++r) for (int c = 0; c < D; ++c) Cm[r * D + c] = (c >= r) ? L[c * D + r] : 0.0;
+            for (int r = 0; r < D; ++r) for (int c = 0; c < D; ++c) s_Cm[r * D + c] = (c >= r) ? L[c * D + r] : 0.0;
             const double sf = A.sf[a];
             sp[0] = 1.0 / sqrt(detv);
             sp[2] = sf * sf;
-            s_tmp[0] = sf * sf / sqrt(detm);        // c_m, picked up below
-            for (int k = 0; k < D; ++k) {
-                double s = 0.0;
-                for (int l = k; l < D; ++l) s += Cm[k * D + l] * s_u[l];
-                pp[k] = s; pp[D + D * D + k] = s;
-            }
-            for (int e = 0; e < D * D; ++e) { pp[D + e] = Cm[e]; pp[D + D * D + D + e] = Cm[e]; }
         }
         __syncthreads();
-        double u[D], Bm[D * D];
+        if (threadIdx.x < D * D) {
+            const int e = threadIdx.x;
+            sp[3 + e] = s_tmp[D * D + e];                       // Am
+            sp[3 + D * D + e] = s_Cm[e];
+            pp[D + e] = s_Cm[e]; pp[D + D * D + D + e] = s_Cm[e];
+        }
+        if (threadIdx.x >= 64 && threadIdx.x < 64 + D) {
+            const int k = threadIdx.x - 64;
+            double s = 0.0;
+            for (int l = k; l < D; ++l) s += s_Cm[k * D + l] * s_u[l];
+            pp[k] = s; pp[D + D * D + k] = s;
+        }
+        __syncthreads();
+        double u[D];
+        const double* Bm = s_B;      // read from LDS in the loop (wave-uniform addresses: broadcast reads): 2 D^2 registers less
 #pragma unroll
         for (int k = 0; k < D; ++k) u[k] = s_u[k];
-#pragma unroll
-        for (int e = 0; e < D * D; ++e) Bm[e] = s_B[e];
         double v[NV];
 #pragma unroll
         for (int m = 0; m < NV; ++m) v[m] = 0.0;
         for (int i = threadIdx.x; i < A.Np; i += blockDim.x) {
             double d[D], qf = 0.0;
+            int boff = 0;
+            asm volatile("" : "+v"(boff));      // opaque offset: keeps the D^2 reads of B in the loop instead of 2 D^2 hoisted registers
 #pragma unroll
             for (int k = 0; k < D; ++k) d[k] = u[k] - A.XT[(size_t)k * A.Np + i];
 #pragma unroll
             for (int k = 0; k < D; ++k) {
                 double bd = 0.0;
 #pragma unroll
-                for (int l = 0; l < D; ++l) bd = fma(Bm[k * D + l], d[l], bd);
+                for (int l = 0; l < D; ++l) bd = fma(Bm[boff + k * D + l], d[l], bd);
                 qf = fma(bd, d[k], qf);
             }
             const double ex = exp(-0.5 * qf);
             const double p = A.beta[(size_t)a * A.Np + i] * ex;
-            if (A.out_l && i < A.N) A.out_l[((size_t)q * ds + a) * A.N + i] = s_tmp[0] * ex;
+            if (A.out_l && i < A.N) A.out_l[((size_t)q * ds + a) * A.N + i] = s_cm * ex;
             v[0] += p;
             int o = 1 + D;
 #pragma unroll
@@ -149,14 +161,14 @@ __global__ __launch_bounds__(256) void k_mom_prep(MomArgs A) {
                 for (int l = k; l < D; ++l) { v[o] = fma(pd, d[l], v[o]); ++o; }
             }
         }
-        const double cm = s_tmp[0];
+        const double cm = s_cm;
         block_sum<NV>(v, s_scr, s_out);
         if (threadIdx.x == 0) {
             const double mu = cm * s_out[0];
             sp[1] = mu;
             double* dmu_du = sp + 3 + 2 * D * D;
             double* dmu_dS = dmu_du + D;
-            double S2[D * D];
+            double* S2 = s_tmp;                 // LDS scratch of the set-up phase, free by now
             int o = 1 + D;
             for (int k = 0; k < D; ++k) for (int l = k; l < D; ++l) { S2[k * D + l] = S2[l * D + k] = s_out[o]; ++o; }
             for (int k = 0; k < D; ++k) {
@@ -165,7 +177,7 @@ __global__ __launch_bounds__(256) void k_mom_prep(MomArgs A) {
                 dmu_du[k] = -cm * s;
             }
             // B S2 B
-            double BS[D * D];
+            double* BS = s_tmp + D * D;
             for (int r = 0; r < D; ++r) for (int c = 0; c < D; ++c) { double s = 0.0; for (int l = 0; l < D; ++l) s += s_B[r * D + l] * S2[l * D + c]; BS[r * D + c] = s; }
             for (int r = 0; r < D; ++r) for (int c = 0; c < D; ++c) {
                 double s = 0.0;
@@ -184,7 +196,10 @@ __global__ __launch_bounds__(256) void k_mom_prep(MomArgs A) {
         const double* la = A.lam + a * D; const double* lb = A.lam + b * D;
         double* sp = A.sp + ((size_t)q * A.nunits + ds + pr) * A.sps;
         double* pp = A.pp + ((size_t)q * A.nunits + ds + pr) * A.pps;
-        double Mt[D * D], Bab[D * D], L[D * D], wa[D], wb[D];
+        // the matrices live in LDS (free in a cross-unit workgroup): as per-thread arrays indexed by runtime loop counters
+        // they were private (scratch) memory, a global-memory round trip per access
+        double* Mt = s_tmp; double* Bab = s_tmp + D * D; double* L = s_tmpA;
+        double wa[D], wb[D];
         double detlab = 1.0;
         for (int k = 0; k < D; ++k) {
             const double lab = la[k] * lb[k] / (la[k] + lb[k]);
@@ -202,8 +217,8 @@ __global__ __launch_bounds__(256) void k_mom_prep(MomArgs A) {
                 for (int l = 0; l < c; ++l) s -= L[r * D + l] * L[c * D + l];
                 L[r * D + c] = (r == c) ? sqrt(s) : s / L[c * D + c];
             }
-        double* Cm = sp + 3 + D * D;
-        for (int r = 0; r < D; ++r) for (int c = 0; c < D; ++c) Cm[r * D + c] = (c >= r) ? L[c * D + r] : 0.0;
+        double* Cm = s_Cm;
+        for (int r = 0; r < D; ++r) for (int c = 0; c < D; ++c) { Cm[r * D + c] = (c >= r) ? L[c * D + r] : 0.0; sp[3 + D * D + r * D + c] = Cm[r * D + c]; }
         double* pr_r = pp; double* pr_c = pp + D + D * D;
         for (int k = 0; k < D; ++k) {
             double sr = 0.0, sc = 0.0;
@@ -223,11 +238,12 @@ __global__ __launch_bounds__(256) void k_mom_prep(MomArgs A) {
         const int u = unit;
         const double* prc = A.pp + ((size_t)q * A.nunits + u) * A.pps + D + D * D;
         double* Gu = A.G + ((size_t)q * A.nunits + u) * A.Np * A.gw;
-        double cv[D], T[D * D];
+        double cv[D];
+        double* T = s_tmp;           // the column-side transform, read from LDS in the loop like B above
 #pragma unroll
         for (int k = 0; k < D; ++k) cv[k] = prc[k];
-#pragma unroll
-        for (int e = 0; e < D * D; ++e) T[e] = prc[D + e];
+        if (threadIdx.x < D * D) T[threadIdx.x] = prc[D + threadIdx.x];
+        __syncthreads();
         // The rows of 256 consecutive points are contiguous in G: staged through LDS and written lane-contiguously (a lane
         // writing its own 8 gw-byte row stores 8 bytes into 64 different cache lines per instruction: C5 376 us per launch
         // for 671 MB).  D >= 7 (rows of up to 46 doubles) keeps the direct stores: the staging buffer would not fit.
@@ -235,6 +251,8 @@ __global__ __launch_bounds__(256) void k_mom_prep(MomArgs A) {
             const int i = i0 + threadIdx.x;
             if (i < A.Np) {
                 double x[D], qv[D], qq = 0.0;
+                int toff = 0;
+                asm volatile("" : "+v"(toff));      // as for B above: T stays in LDS
 #pragma unroll
                 for (int k = 0; k < D; ++k) x[k] = A.XT[(size_t)k * A.Np + i];
                 double* g = STAGE ? s_g + (size_t)threadIdx.x * A.gw : Gu + (size_t)i * A.gw;
@@ -242,7 +260,7 @@ __global__ __launch_bounds__(256) void k_mom_prep(MomArgs A) {
                 for (int k = 0; k < D; ++k) {
                     double sacc = cv[k];
 #pragma unroll
-                    for (int l = k; l < D; ++l) sacc = fma(-T[k * D + l], x[l], sacc);
+                    for (int l = k; l < D; ++l) sacc = fma(-T[toff + k * D + l], x[l], sacc);
                     qv[k] = sacc; g[k] = sacc;
                     qq = fma(sacc, sacc, qq);
                 }
@@ -267,16 +285,23 @@ __global__ __launch_bounds__(256) void k_mom_prep(MomArgs A) {
 }
 
 template <int D>
-__global__ __launch_bounds__(64) void k_mom_finish(MomArgs A) {
+__global__ __launch_bounds__(256) void k_mom_finish(MomArgs A) {
     constexpr int NMX = 1 + D + D * (D + 1) / 2;
     __shared__ double s_z[(GPMPC_MAX_DS + GPMPC_MAX_PAIRS) * NMX];
     const int q = blockIdx.x, ds = A.ds, nm = A.nm, nunits = A.nunits;
     for (int idx = threadIdx.x; idx < nunits * nm; idx += blockDim.x) {
         const int u = idx / nm, m = idx - u * nm;
         const double* p = A.part + (size_t)q * A.nwork * nm + m;
-        double s = 0.0;
-        for (int wi = A.ustart[u]; wi < A.ustart[u + 1]; ++wi) s += p[(size_t)wi * nm];
-        s_z[idx] = s;
+        // four independent partial sums (fixed order): the loads of a unit's work items are independent, a single running sum
+        // left one load in flight per thread (C5: 94 us per launch for 210 sums of 36-64 values)
+        const int w0 = A.ustart[u], w1 = A.ustart[u + 1];
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int wi = w0;
+        for (; wi + 3 < w1; wi += 4) {
+            s0 += p[(size_t)wi * nm]; s1 += p[(size_t)(wi + 1) * nm]; s2 += p[(size_t)(wi + 2) * nm]; s3 += p[(size_t)(wi + 3) * nm];
+        }
+        for (; wi < w1; ++wi) s0 += p[(size_t)wi * nm];
+        s_z[idx] = (s0 + s1) + (s2 + s3);
     }
     __syncthreads();
     const int u = threadIdx.x;
@@ -504,7 +529,7 @@ static int run_mom(const gpmpc_pack* p, MomArgs& A, const MomPlan& r, bool grad,
         rc = gpmpc_timed_pair(D, false, grad, r.tb, P.colsplit ? 4 : r.waves, P, s);
     }
     if (rc != GPMPC_OK) return rc;
-    hipLaunchKernelGGL(k_mom_finish<D>, dim3(A.nq), dim3(64), 0, s, A);
+    hipLaunchKernelGGL(k_mom_finish<D>, dim3(A.nq), dim3(256), 0, s, A);
     if (A.out_cov && p->ds > 1 && A.npairs == 0) {          // direct N^2 kernel (also the bug-compatible form)
         int h[2 * GPMPC_MAX_DS * GPMPC_MAX_DS], n = 0;
         const bool bug = (A.flags & GPMPC_COV_BUG_COMPAT) != 0;
