@@ -62,7 +62,10 @@ static __device__ unsigned long long g_fused_stamps[64];
 #define GPMPC_FUSED_TABLE 0
 #endif
 #ifndef GPMPC_FUSED_UNROLL
-#define GPMPC_FUSED_UNROLL 4    // columns of the evaluation loop in flight per wave (16 = all of a whole tile's share)
+// Columns of the evaluation loop in flight per wave.  Fully unrolled (16 for a whole tile's share) three instantiations were
+// compiled to 256 VGPRs; 2 / 4 / 8 avoid that and differ little, 2 gives the pendulum shape <3, 2> a fourth wave per SIMD
+// (N = 300, B = 64: 0.231 ms per batch against 0.256 / 0.252; `profiles/r02/batch_size_map.txt`).
+#define GPMPC_FUSED_UNROLL 2
 #endif
 #define GPMPC_FUSED_PZ 4        // Z0 partials of one GP prefetched per thread: covers 256 * 4 workgroups per GP
 
