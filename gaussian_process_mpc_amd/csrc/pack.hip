@@ -183,6 +183,7 @@ void gpmpc_read_tuning(gpmpc_tuning* t) {
     t->no_first = getenv("GPMPC_NO_FIRST") ? 1 : 0;
     t->fused = geti("GPMPC_FUSED", -1);
     t->no_xcd_sort = getenv("GPMPC_NO_XCD_SORT") ? 1 : 0;
+    t->hchunks = geti("GPMPC_HEAD_CHUNKS", -1);
 }
 
 extern "C" int gpmpc_pack_reload_tuning(gpmpc_pack* p) {

@@ -40,12 +40,19 @@ struct RollArgs {
     double* G;     // [B][ds][Np][gw] column rows of the scalar-broadcast pair kernel, or null
     int gw;
     int pps, sps, nwork, nm, grad;
+    // Row chunks of the head kernel (small batches of a large N: B ds workgroups walking all N rows are the slowest thing in
+    // the step).  hchunks > 1: workgroup (b, a, c) takes rows [c, c+1) * hrows; the O(N) mean sums of step t are left as
+    // partial sums mpart [2][B][ds][hchunks][1+2D] (parity t & 1) and combined by the FINISH phase of the next launch, which
+    // then also forms mu and its derivatives; sp carries c_m and B_k instead (layout below).  hchunks <= 1: as before.
+    int hchunks, hrows;
+    double* mpart;
     // outputs of the tail
     double* out_cost; double* out_grad;
     gpmpc_cost_params cost;
 };
 
 // layout of sp (doubles): 0 c | 1 mu | 2 sf2 | 3 A[D] | 3+D scale[D] | 3+2D dmu_du[D] | 3+3D dmu_ds[D]
+//   with row chunks (hchunks > 1):      1 c_m                                  3+2D B[D]      3+3D unused
 __host__ __device__ static inline int sps_of(int D) { return 3 + 4 * D; }
 
 // Finish step t (>= 1) for trajectory b: reduce the pair-kernel partials of ALL ds GPs (mean/var of step t land in
@@ -53,14 +60,26 @@ __host__ __device__ static inline int sps_of(int D) { return 3 + 4 * D; }
 // only (the head kernel runs one workgroup per (trajectory, GP); each recomputes the cheap reduction and owns one GP).
 #define GPMPC_RED_CH 8
 __device__ static void finish_step(const RollArgs& A, int b, int t, int own, double* s_z /* [ds*nm] */,
-                                   double* s_red /* [ds*nm*GPMPC_RED_CH] */, double* s_mu, double* s_var) {
+                                   double* s_red /* [ds*nm*GPMPC_RED_CH] */, double* s_mu, double* s_var,
+                                   double* s_ms /* [MAX_DS*(1+2 MAX_D) + 4 MAX_DS] */) {
     const int ds = A.ds, D = A.D, nm = A.nm;
+    const bool chunked = A.hchunks > 1;
+    if (chunked) {      // mean sums of step t: the row chunks' partial sums, combined in chunk order
+        const int nv = 1 + 2 * D;
+        for (int o = threadIdx.x; o < ds * nv; o += blockDim.x) {
+            const int a = o / nv, m = o - a * nv;
+            const double* q = A.mpart + ((((size_t)(t & 1) * A.B + b) * ds + a) * A.hchunks) * nv + m;
+            double sum = 0.0;
+            for (int c = 0; c < A.hchunks; ++c) sum += q[(size_t)c * nv];
+            s_ms[o] = sum;
+        }
+    }
     // Sum the per-tile partials of every (GP, moment) output; either way the summation order depends only on the
     // shapes, never on timing.
-    if (A.nwork > 128 * ds) {
-        // Many items per GP (small batches of a large N use 64 x 64 tiles: 528 per GP at N = 2048, which the scheme
-        // below walked 66 deep, 45 us per step): one wave per GP, a lane takes whole work items -- the nm moments of an
-        // item are contiguous and the loads of different items are independent -- and the wave sum is the final value.
+    if (A.nwork > 128 * ds && own < 0) {
+        // Many items per GP, every GP owned (the tail kernel: the last step, nothing downstream has to agree with another
+        // workgroup): one wave per GP, a lane takes whole work items -- the nm moments of an item are contiguous and the
+        // loads of different items are independent -- and the wave sum is the final value.
         constexpr int NMAX = 1 + 2 * GPMPC_MAX_D;
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
         const double* p = A.part + (size_t)b * A.nwork * nm;
@@ -83,6 +102,65 @@ __device__ static void finish_step(const RollArgs& A, int b, int t, int own, dou
                     if (lane == 0) s_z[a * nm + m] = sw;
                 }
         }
+    } else if (A.nwork > 128 * ds) {
+        // Many items per GP (256x64 tiles of a large N: 544 per GP at N = 4096, 15 moments each).  Only the workgroup that
+        // writes GP a's Jacobian rows needs all its moments; every workgroup needs Z0 of every GP (the input variances of
+        // the next step).  Owned GPs: thread = (moment m, group g), group g takes items g, g + GR, ... -- the nm moments of an
+        // item are contiguous, so a pass reads GR * nm consecutive doubles -- then a fixed-order combine over the groups.
+        // Z0 of EVERY GP (owned or not): one item per thread and pass, wave sums -- the same order in every workgroup of the
+        // trajectory, so that all of them derive bit-identical input variances: the row-side transform (pp, one workgroup)
+        // and the column rows (G, possibly several row-chunk workgroups) of a unit must agree to the last bit, the N^2 sum
+        // amplifies a relative 1e-9 between them to 1e-2 of the variance.  (One wave per GP with a lane taking whole
+        // items, all moments of all GPs in every workgroup, was 40 us of the head kernel at N = 4096.)
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+        const int GR = (int)blockDim.x / nm < 16 ? (int)blockDim.x / nm : 16;
+        const int tm = threadIdx.x % nm, tg = threadIdx.x / nm;
+        double* s_wz = s_ms + GPMPC_MAX_DS * (1 + 2 * GPMPC_MAX_D);        // [ds][nw], behind the mean sums
+        const double* p = A.part + (size_t)b * A.nwork * nm;
+        const bool filter = !A.ust_inline && A.work;
+        for (int a = 0; a < ds; ++a) {
+            const int w0 = A.ust_inline ? A.ust[a] : (A.work ? 0 : A.ustart[a]);
+            const int w1 = A.ust_inline ? A.ust[a + 1] : (A.work ? A.nwork : A.ustart[a + 1]);
+            double z0 = 0.0;
+            for (int wi = w0 + threadIdx.x; wi < w1; wi += blockDim.x) {
+                if (filter && A.work[4 * wi] != a) continue;
+                z0 += p[(size_t)wi * nm];
+            }
+            z0 = wave_sum(z0);
+            if (lane == 0) s_wz[a * nw + w] = z0;
+        }
+        for (int a = 0; a < ds && nm > 1; ++a) {              // the other moments of the owned GP(s), one GP at a time
+            if (own >= 0 && own != a) continue;               // (workgroup-uniform)
+            const int w0 = A.ust_inline ? A.ust[a] : (A.work ? 0 : A.ustart[a]);
+            const int w1 = A.ust_inline ? A.ust[a + 1] : (A.work ? A.nwork : A.ustart[a + 1]);
+            if (tg < GR) {
+                double sum = 0.0;
+                for (int wi = w0 + tg; wi < w1; wi += GR) {
+                    if (filter && A.work[4 * wi] != a) continue;
+                    sum += p[(size_t)wi * nm + tm];
+                }
+                s_red[tm * GR + tg] = sum;
+            }
+            __syncthreads();
+            if (threadIdx.x >= 1 && (int)threadIdx.x < nm) {
+                const double* r = s_red + threadIdx.x * GR;
+                double sum = 0.0;
+                for (int g = 0; g < GR; ++g) sum += r[g];
+                s_z[a * nm + threadIdx.x] = sum;
+            }
+            __syncthreads();                                  // s_red is reused by the next owned GP
+        }
+        __syncthreads();
+        for (int a = threadIdx.x; a < ds; a += blockDim.x) {
+            double sum = 0.0;
+            for (int ww = 0; ww < nw; ++ww) sum += s_wz[a * nw + ww];
+            s_z[a * nm] = sum;
+        }
+        if (nm > 1)
+            for (int o = threadIdx.x; o < ds * nm; o += blockDim.x) {
+                const int a = o / nm, m = o - a * nm;
+                if (m > 0 && own >= 0 && own != a) s_z[o] = 0.0;       // not needed by this workgroup
+            }
     } else {
         // Few items per GP: GPMPC_RED_CH threads share one output (each a strided subset of the work items, so the
         // global loads of a pass are independent), then a fixed-order combine.
@@ -115,7 +193,9 @@ __device__ static void finish_step(const RollArgs& A, int b, int t, int own, dou
         const int a = threadIdx.x;
         const double* sp = A.sp + (((size_t)(t & 1) * A.B + b) * ds + a) * A.sps;
         const double* z = s_z + a * nm;
-        const double c = sp[0], mu = sp[1], sf2 = sp[2];
+        const double* ms = s_ms + a * (1 + 2 * D);
+        const double cm = sp[1];                                   // chunked layout only
+        const double c = sp[0], mu = chunked ? cm * ms[0] : sp[1], sf2 = sp[2];
         const double T = c * z[0];
         const double var = sf2 - T - mu * mu;
         s_mu[a] = mu;
@@ -129,7 +209,9 @@ __device__ static void finish_step(const RollArgs& A, int b, int t, int own, dou
                 double* jv = A.jac + (((size_t)b * A.H + (t - 1)) * 2 * ds + ds + a) * nc;   // row of var_a
                 for (int k = 0; k < D; ++k) {
                     const double Ak = sp[3 + k], sc = sp[3 + D + k];
-                    const double dmu_du = sp[3 + 2 * D + k], dmu_ds = sp[3 + 3 * D + k];
+                    const double Bq = sp[3 + 2 * D + k];                       // chunked layout: B_k (same expressions as prep_step)
+                    const double dmu_du = chunked ? -Bq * cm * ms[1 + k] : sp[3 + 2 * D + k];
+                    const double dmu_ds = chunked ? -0.5 * mu * Bq + 0.5 * Bq * Bq * cm * ms[1 + D + k] : sp[3 + 3 * D + k];
                     const double dT_du = -4.0 * sc * c * z[1 + k];
                     const double dT_ds = Ak * (c * z[1 + D + k] - 0.5 * T);
                     const double dv_du = -dT_du - 2.0 * mu * dmu_du;
@@ -151,7 +233,7 @@ __device__ static void finish_step(const RollArgs& A, int b, int t, int own, dou
 // Prepare step t (>= 1) for GP a: input moments (mean/var of step t-1 in s_mu / s_var, action t-1), the O(N) mean
 // sums, the pair-kernel parameters.
 template <int D>
-__device__ static void prep_step(const RollArgs& A, int b, int t, int a, const double* s_mu, const double* s_var,
+__device__ static void prep_step(const RollArgs& A, int b, int t, int a, int chunk, const double* s_mu, const double* s_var,
                                  double* s_u, double* s_s, double* s_scr, double* s_out, double* s_g) {
     const int ds = A.ds;
     // per-dimension scalars: one lane per input dimension (the divisions and square roots are long dependent chains;
@@ -189,9 +271,11 @@ __device__ static void prep_step(const RollArgs& A, int b, int t, int a, const d
     double v[1 + 2 * D];
 #pragma unroll
     for (int m = 0; m < 1 + 2 * D; ++m) v[m] = 0.0;
-    for (int i0 = 0; i0 < A.Np; i0 += blockDim.x) {          // uniform trip count: the G rows go through LDS
+    const bool chunked = A.hchunks > 1;
+    const int r0 = chunked ? chunk * A.hrows : 0, r1 = chunked ? (r0 + A.hrows < A.Np ? r0 + A.hrows : A.Np) : A.Np;
+    for (int i0 = r0; i0 < r1; i0 += blockDim.x) {           // uniform trip count: the G rows go through LDS
         const int i = i0 + threadIdx.x;
-        if (i < A.Np) {
+        if (i < r1) {
             double d[D], xk[D], q = 0.0;
 #pragma unroll
             for (int k = 0; k < D; ++k) { xk[k] = A.XT[(size_t)k * A.Np + i]; d[k] = u[k] - xk[k]; q = fma(Bk[k] * d[k], d[k], q); }
@@ -215,13 +299,34 @@ __device__ static void prep_step(const RollArgs& A, int b, int t, int a, const d
         }
         if (Grow) {        // rows of blockDim.x consecutive points are contiguous in G: write them out lane-contiguously
             __syncthreads();
-            const int rows = (A.Np - i0 < (int)blockDim.x) ? A.Np - i0 : (int)blockDim.x;
+            const int rows = (r1 - i0 < (int)blockDim.x) ? r1 - i0 : (int)blockDim.x;
             double* dst = Grow + (size_t)i0 * A.gw;
             for (int e = threadIdx.x; e < rows * A.gw; e += blockDim.x) dst[e] = s_g[e];
             __syncthreads();
         }
     }
     block_sum<1 + 2 * D>(v, s_scr, s_out);
+    if (chunked) {
+        // partial sums of this row chunk; the constants of the step by chunk 0 (the next launch's finish phase forms mu)
+        if (threadIdx.x < 1 + 2 * D)
+            A.mpart[((((size_t)(t & 1) * A.B + b) * ds + a) * A.hchunks + chunk) * (1 + 2 * D) + threadIdx.x] = s_out[threadIdx.x];
+        if (chunk == 0 && threadIdx.x < D) {
+            const int k = threadIdx.x;
+            const double sf = A.sf[a], sf2 = sf * sf;
+            double detm = 1.0, detv = 1.0;
+            for (int l = 0; l < D; ++l) { detm *= s_r1[l]; detv *= s_r2[l]; }
+            const double cm = sf2 / sqrt(detm), c = 1.0 / sqrt(detv);
+            double* sp = A.sp + (((size_t)(t & 1) * A.B + b) * ds + a) * A.sps;
+            double* pp = A.pp + ((size_t)b * ds + a) * A.pps;
+            if (k == 0) { sp[0] = c; sp[1] = cm; sp[2] = sf2; }
+            const double sc = s_sc[k];
+            sp[3 + k] = s_A[k]; sp[3 + D + k] = sc;
+            sp[3 + 2 * D + k] = s_B[k];
+            pp[k] = sc * s_u[k];
+            pp[D + k] = sc;
+        }
+        return;
+    }
     if (threadIdx.x < D) {                                    // lane k writes the entries of dimension k; lane 0 the scalars
         const int k = threadIdx.x;
         const double sf = A.sf[a], sf2 = sf * sf;
@@ -251,22 +356,23 @@ __global__ __launch_bounds__(256) void k_roll_head(RollArgs A, int t) {
     __shared__ double s_u[GPMPC_MAX_D], s_s[GPMPC_MAX_D];
     __shared__ double s_scr[16 * (1 + 2 * D)], s_out[1 + 2 * D];
     __shared__ double s_g[256 * (2 * D + 2)];             // staging of 256 G rows (gw <= 2D + 2)
-    const int b = blockIdx.x, a = blockIdx.y;
+    __shared__ double s_ms[GPMPC_MAX_DS * (1 + 2 * GPMPC_MAX_D) + 4 * GPMPC_MAX_DS];      // mean sums | Z0 wave sums
+    const int b = blockIdx.x, a = blockIdx.y, chunk = blockIdx.z;
     if (t == 1) {
         if (threadIdx.x < A.ds) {
             const double x = A.x0[(size_t)b * A.ds + threadIdx.x];
             s_mu[threadIdx.x] = x;
             s_var[threadIdx.x] = GPMPC_INIT_VAR;
-            if (a == 0) {
+            if (a == 0 && chunk == 0) {
                 A.means[((size_t)b * (A.H + 1)) * A.ds + threadIdx.x] = x;
                 A.vars[((size_t)b * (A.H + 1)) * A.ds + threadIdx.x] = GPMPC_INIT_VAR;
             }
         }
         __syncthreads();
     } else {
-        finish_step(A, b, t - 1, a, s_z, s_zred, s_mu, s_var);
+        finish_step(A, b, t - 1, chunk == 0 ? a : A.ds, s_z, s_zred, s_mu, s_var, s_ms);     // rows of GP a are written by chunk 0 only
     }
-    prep_step<D>(A, b, t, a, s_mu, s_var, s_u, s_s, s_scr, s_out, s_g);
+    prep_step<D>(A, b, t, a, chunk, s_mu, s_var, s_u, s_s, s_scr, s_out, s_g);
 }
 
 // ---------------------------------------------------------------------------
@@ -501,7 +607,8 @@ __global__ __launch_bounds__(256) void k_roll_tail(RollArgs A) {
     __shared__ double s_adj[2][2 * GPMPC_MAX_DS];
     const int b = blockIdx.x, ds = A.ds, da = A.da, H = A.H, tid = threadIdx.x;
     const int nz = 2 * ds, nc = 2 * ds + da;
-    finish_step(A, b, H, -1, s_z, s_zred, s_mu, s_var);
+    __shared__ double s_ms[GPMPC_MAX_DS * (1 + 2 * GPMPC_MAX_D) + 4 * GPMPC_MAX_DS];      // mean sums | Z0 wave sums
+    finish_step(A, b, H, -1, s_z, s_zred, s_mu, s_var, s_ms);
     double* s_ct = s_dyn;
     double* s_dl = s_ct + (H + 1);
     double* s_gU = s_dl + (size_t)(H + 1) * nz;
@@ -676,7 +783,7 @@ int gpmpc_timed_pair_sbf(int D, bool grad, int ns2, int waves, const PairSbfArgs
     return timed_launch(GPMPC_TIME_FULL, s, [&] { return gpmpc_launch_pair_sbf(D, grad, ns2, waves, a, s); });
 }
 
-struct RollPlan { int tiling, tb, waves, nwork, nm, pps, sps, sb, gw, rgroup, fused, fq; size_t off_G; size_t off_pp, off_sp, off_part, off_partz, off_jac, off_means, off_vars, total; };
+struct RollPlan { int tiling, tb, waves, nwork, nm, pps, sps, sb, gw, rgroup, fused, fq, hchunks, hrows; size_t off_mpart; size_t off_G; size_t off_pp, off_sp, off_part, off_partz, off_jac, off_means, off_vars, total; };
 
 static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag, RollPlan* r, bool lowprec = false) {
     const int D = p->D;
@@ -741,6 +848,17 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     r->off_sp = take((size_t)2 * B * p->ds * r->sps);
     r->off_part = take((size_t)(r->fused ? 2 * r->fq : 1) * B * r->nwork * r->nm);     // fused: double-buffered by step parity
     r->off_partz = take(r->fused ? (size_t)2 * r->fq * B * r->nwork : 0);
+    // Row chunks of the head kernel (two-kernel form only): about 64 workgroups, at least 512 rows each.  N = 4096, ds = 6,
+    // B = 1: the head kernel was 66 us of a 172 us step on 6 workgroups.
+    r->hchunks = 0; r->hrows = 0;
+    if (!r->fused && !lowprec) {
+        int c = 64 / (B * p->ds);
+        if (c > p->Np / 512) c = p->Np / 512;
+        if (c > 16) c = 16;
+        if (tn.hchunks >= 0) c = tn.hchunks;
+        if (c > 1) { r->hrows = ((p->Np + c - 1) / c + 255) & ~255; r->hchunks = (p->Np + r->hrows - 1) / r->hrows; if (r->hchunks <= 1) r->hchunks = 0; }
+    }
+    r->off_mpart = take(r->hchunks > 1 ? (size_t)2 * B * p->ds * r->hchunks * (1 + 2 * D) : 0);
     r->off_jac = take(grad ? (size_t)B * H * 2 * p->ds * (2 * p->ds + p->da) : 0);
     r->gw = gpmpc_sb_gw(D, p->ds);
     r->off_G = take(r->sb ? (size_t)B * p->ds * p->Np * r->gw : 0);
@@ -772,7 +890,7 @@ static int launch_step_fused(int D, bool grad, int ns2, int q, const FusedArgs& 
 
 template <int D>
 static void launch_head(const RollArgs& A, int t, hipStream_t s) {
-    hipLaunchKernelGGL(k_roll_head<D>, dim3(A.B, A.ds), dim3(256), 0, s, A, t);
+    hipLaunchKernelGGL(k_roll_head<D>, dim3(A.B, A.ds, A.hchunks > 1 ? A.hchunks : 1), dim3(256), 0, s, A, t);
 }
 
 static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, const double* U,
@@ -798,6 +916,7 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
     A.vars = out_vars ? out_vars : (double*)(ws + r.off_vars);
     A.pp = (double*)(ws + r.off_pp); A.sp = (double*)(ws + r.off_sp); A.part = (double*)(ws + r.off_part);
     A.jac = grad ? (double*)(ws + r.off_jac) : nullptr;
+    A.hchunks = r.hchunks; A.hrows = r.hrows; A.mpart = r.hchunks > 1 ? (double*)(ws + r.off_mpart) : nullptr;
     A.G = r.sb ? (double*)(ws + r.off_G) : nullptr; A.gw = r.gw;
     A.pps = r.pps; A.sps = r.sps; A.nwork = r.nwork; A.nm = r.nm; A.grad = grad ? 1 : 0;
     A.ustart = p->wl[0][r.tiling].ustart_dev;
