@@ -400,6 +400,30 @@ def test_nan_passthrough(G, golden):
     assert torch.isnan(r["var"]).any() or torch.isnan(r["mean"]).any()
 
 
+@pytest.mark.parametrize("chunks", ["1", "auto", "8"])
+def test_row_chunked_head_kernel_vs_cport(G, monkeypatch, chunks):
+    """Small batch of a large training set (N = 2049, ds = 5: 765 work items, the many-items reduction): the head kernel split
+    over row chunks (GPMPC_HEAD_CHUNKS: off / chosen per call / 8) against the C port.  Guards the bit-consistency the
+    scheme depends on: every workgroup of a trajectory must derive identical input variances, or the row-side transform of
+    a unit and the column rows written by another chunk's workgroup disagree by 1e-9 and the N^2 sum turns that into 1e-2."""
+    from oracle import cport, gpmpc_oracle as O
+    from gaussian_process_mpc_amd.synth import synth_problem
+    if chunks == "auto":
+        monkeypatch.delenv("GPMPC_HEAD_CHUNKS", raising=False)
+    else:
+        monkeypatch.setenv("GPMPC_HEAD_CHUNKS", chunks)
+    monkeypatch.setenv("GPMPC_FUSED", "0")
+    pb = synth_problem(99, 2049, 5, 1, 3, 4)
+    kinv = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"]).Ky_inv.numpy()
+    pack = G.GPPack(pb["X"], pb["Y"], kinv, pb["lambdas"], pb["sigma_f"])          # reads the overrides
+    r = G.rollout(pack, pb["x0"], pb["U"], G.CostParams(-1.0, pb["Q"], pb["R"]))
+    c = cport.rollout(pb, kinv, -1.0, nthreads=16)
+    np.testing.assert_allclose(r["means"].cpu().numpy(), c["means"], rtol=MEAN_RTOL, atol=1e-9)
+    np.testing.assert_allclose(r["vars"].cpu().numpy(), c["vars"], rtol=VAR_RTOL)
+    np.testing.assert_allclose(r["cost"].cpu().numpy(), c["cost"], rtol=1e-6)
+    np.testing.assert_allclose(r["grad"].cpu().numpy(), c["grad"], rtol=1e-4, atol=1e-7)
+
+
 def test_concurrent_streams_share_a_pack(G):
     """include/gpmpc.h: calls are re-entrant across streams as long as the workspaces differ.  Two streams drive the same
     pack with different batches, interleaved and overlapping on the device (with the per-kernel timing accumulators
