@@ -807,7 +807,8 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     const bool big = sb_ok ? wg0 >= (tb2 ? thr2 : 1500) : (long)((B + 1) / 2) * p->wl[0][0].nwork >= 1024;
     // (round 2: 2048 instead of 1024 work items -- below that the one-launch-per-step kernel of step_fused.h wins: N = 2048,
     // B = 2: 1.03 vs 1.19 ms per rollout; N = 1536, B = 4: 1.07 vs 1.23; N = 1024, B = 4: 0.67 vs 1.01)
-    const bool mid = !big && sb_ok && (long)B * p->wl[0][2].nwork >= 2048;
+    // (1700 since the head kernel is split over row chunks: N = 2048, B = 3: 1.16 vs 1.33 ms; N = 1536, B = 6: 1.31 vs 1.40)
+    const bool mid = !big && sb_ok && (long)B * p->wl[0][2].nwork >= 1700;
     r->sb = (sb_ok && (big || mid)) ? 1 : 0;
     const bool many = (long)p->wl[0][1].nwork > 256L * p->ds;        // > 256 one-wave tiles per GP (N >= 1472)
     r->tiling = big ? 0 : (mid ? 2 : (many ? 3 : 1));

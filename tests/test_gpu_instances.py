@@ -3,7 +3,7 @@
 The rollout picks its kernel by the amount of work (csrc/step.hip::plan_rollout, csrc/moment.hip::plan_mom):
 
     one launch per step, 64-row tiles (step_fused.h)      small batches (the staged pair_kernel.h with GPMPC_FUSED=0 / full S)
-    scalar broadcast, 256x64 tiles   (pair_kernel_sb.h)   B * tiles >= 2048, one trajectory per wave
+    scalar broadcast, 256x64 tiles   (pair_kernel_sb.h)   B * tiles >= 1700, one trajectory per wave
     scalar broadcast, 256x256 tiles  (pair_kernel_sb.h)   >= 2800 workgroups of two trajectories per wave (D <= 5), >= 1500 of one
     scalar broadcast, full S         (pair_kernel_sbf.h)  full-covariance rollout / moment matching on large batches
 
@@ -45,7 +45,7 @@ def test_diag_rollout_every_shape_vs_cport(G, ds, da):
     N, H = 150, 3                                   # Np = 192: 1 row tile, 3 column chunks of the 256x64 work list
     b_big = 5600 // ds + 3                          # ceil(B / 2) * ds >= 2800 workgroups (D <= 5; B * ds >= 1500 above) -> 256x256 tiles
     b_big += 1 - b_big % 2                          # odd on purpose (the last wave of the two-trajectory shape is half empty)
-    b_mid = 2048 // (3 * ds) + 2                    # B * 3 ds >= 2048 -> 256x64 tiles
+    b_mid = 2048 // (3 * ds) + 2                    # B * 3 ds >= 1700 -> 256x64 tiles
     pb, kinv = _problem(40 + 8 * ds + da, N, ds, da, H, b_big)
     pack = G.GPPack(pb["X"], pb["Y"], kinv, pb["lambdas"], pb["sigma_f"])
     cost = G.CostParams(-1.0, pb["Q"], pb["R"])
