@@ -41,6 +41,7 @@ struct gpmpc_tuning {
     int fused;       // GPMPC_FUSED       0: head + staged pair kernel per step for small batches | -1 unset (fused step kernel)
     int no_xcd_sort; // GPMPC_NO_XCD_SORT natural tile order of the 256x256 work list (takes effect at pack creation only)
     int hchunks;     // GPMPC_HEAD_CHUNKS row chunks of the head kernel: 0 / 1 none | 2..16 | -1 unset (chosen per call)
+    int sbf_min;     // GPMPC_SBF_MIN     workgroups from which the full-S path uses 256x256 tiles + pair_kernel_sbf.h | 0 unset
 };
 void gpmpc_read_tuning(gpmpc_tuning* t);
 

@@ -184,6 +184,7 @@ void gpmpc_read_tuning(gpmpc_tuning* t) {
     t->fused = geti("GPMPC_FUSED", -1);
     t->no_xcd_sort = getenv("GPMPC_NO_XCD_SORT") ? 1 : 0;
     t->hchunks = geti("GPMPC_HEAD_CHUNKS", -1);
+    t->sbf_min = geti("GPMPC_SBF_MIN", 0);
 }
 
 extern "C" int gpmpc_pack_reload_tuning(gpmpc_pack* p) {
