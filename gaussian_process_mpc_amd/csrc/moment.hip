@@ -482,8 +482,9 @@ static void plan_mom(const gpmpc_pack* p, int nq, bool grad, bool pair_cov, int 
     // large tiles are mostly padding): the staged kernel costs 2.5 x as much per pair, so it only wins while the grid is
     // tiny -- full covariance at N = 1024, B = 8: 7.3 -> 3.4 ms per rollout; N = 2048, B = 2: 9.4 -> 4.5 ms; N = 700, B = 16:
     // 3.4 -> 1.7 ms (the threshold used to be 1024 workgroups).
-    const long thr = p->tune.sbf_min > 0 ? p->tune.sbf_min : (p->Np <= 512 ? 640 : 256);
-    r->tiling = (groups * p->wl[r->mode][0].nwork >= thr) ? 0 : 1;
+    // (small training sets: 640, and 1536 when the padded size is not a multiple of 256 -- N = 300: the 256-row tiles are mostly padding)
+    const long thr = p->tune.sbf_min > 0 ? p->tune.sbf_min : (p->Np >= 640 ? 256 : (p->Np % 256 == 0 ? 640 : 1536));
+    r->tiling = (groups * p->wl[r->mode][0].nwork >= thr || p->tune.pair_sb == 1) ? 0 : 1;     // GPMPC_PAIR_SB=1 forces the large tiles
     // scalar-broadcast kernel (pair_kernel_sbf.h) once the grid fills the chip; GPMPC_PAIR_SB=0 (read at pack creation) keeps the staged kernel
     r->sbf = (r->tiling == 0 && D - ns2 <= 2) ? 1 : 0;
     if (p->tune.pair_sb == 0) r->sbf = 0;

@@ -71,7 +71,7 @@ def test_fullcov_rollout_every_shape_vs_cport(G, ds, da):
     from oracle import cport
     N, H = 110, 3
     units = ds + ds * (ds - 1) // 2
-    b_big = 2 * (1024 // units) + 5                 # ceil(B / 2) * units >= 640 (Np <= 512) -> pair_kernel_sbf.h
+    b_big = 2 * (1536 // units) + 5                 # ceil(B / 2) * units >= 1536 (Np = 192: not a multiple of 256) -> pair_kernel_sbf.h
     pb, kinv = _problem(60 + 8 * ds + da, N, ds, da, H, b_big)
     pb["Q"] = pb["Q"] + 0.02 * (np.ones((ds, ds)) - np.eye(ds))           # couples the off-diagonal covariances into the cost
     pack = G.GPPack(pb["X"], pb["Y"], kinv, pb["lambdas"], pb["sigma_f"])

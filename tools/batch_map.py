@@ -10,11 +10,12 @@ import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gaussian_process_mpc_amd as g
-from gaussian_process_mpc_amd.rollout import CostParams, GPPack, rollout
+from gaussian_process_mpc_amd.rollout import CostParams, GPPack, rollout, rollout_fullcov
 from gaussian_process_mpc_amd.synth import synth_problem
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--quick", action="store_true")
+ap.add_argument("--fullcov", action="store_true", help="full-covariance rollout (gpmpc_rollout_fullcov; eager)")
 ap.add_argument("--shapes", default="300:2:1:10,300:4:1:10,1024:4:1:20,2048:4:1:20,4096:6:1:30")
 ap.add_argument("--batches", default="1,2,4,8,16,32,64,128,256")
 args = ap.parse_args()
@@ -41,18 +42,19 @@ for shape in args.shapes.split(","):
             continue
         x0 = torch.as_tensor(pb["x0"][:B], device=dev)
         U = torch.as_tensor(pb["U"][:B], device=dev)
-        graph = B < 32
-        reps = max(3, min(200, int((2e9 if args.quick else 8e9) / (B * H * ds * N * N / 2 * 30))))
+        graph = B < 32 and not args.fullcov
+        run = (lambda: rollout_fullcov(pack, x0, U, cost)) if args.fullcov else (lambda: rollout(pack, x0, U, cost, want_grad=True, want_traj=False, graph=graph))
+        reps = max(3, min(200, int((2e9 if args.quick else 8e9) / (B * H * (ds * ds if args.fullcov else ds) * N * N / 2 * 30))))
         for _ in range(3):
-            rollout(pack, x0, U, cost, want_grad=True, want_traj=False, graph=graph)
+            run()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(reps):
-            rollout(pack, x0, U, cost, want_grad=True, want_traj=False, graph=graph)
+            run()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / reps
         rows.append((B, dt, B / dt))
-    pairs = H * ds * N * (N + 1) / 2
+    pairs = H * (ds * N * (N + 1) / 2 + (ds * (ds - 1) / 2 * N * N if args.fullcov else 0))
     best = max(r[2] for r in rows)
     print(f"N={N} ds={ds} da={da} H={H}  (pair-evaluations per rollout {pairs:.3g})")
     for B, dt, rate in rows:

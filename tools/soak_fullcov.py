@@ -27,10 +27,12 @@ for case in range(n_cases):
     if N >= 449:
         B = min(B, 260)
     gamma = float(rng.choice([-1.0, 1e-5, 0.0, 0.5]))
-    sb = str(rng.choice(["auto", "auto", "staged"]))
+    sb = str(rng.choice(["auto", "auto", "staged", "sbf"]))
     os.environ.pop("GPMPC_PAIR_SB", None)
     if sb == "staged":
         os.environ["GPMPC_PAIR_SB"] = "0"
+    elif sb == "sbf":
+        os.environ["GPMPC_PAIR_SB"] = "1"
     pb = synth_problem(7000 + case, N, ds, da, H, B)
     pb["Q"] = pb["Q"] + 0.02 * (np.ones((ds, ds)) - np.eye(ds))
     kinv = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"]).Ky_inv.numpy()
