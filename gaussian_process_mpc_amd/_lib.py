@@ -66,6 +66,10 @@ SIGNATURES = {
     "gpmpc_moment_match_workspace_bytes": (_sz, [_vp, _i]),
     "gpmpc_moment_match": (_i, [_vp, _i, _vp, _vp, _u] + [_vp] * 10 + [_vp, _sz, _vp]),
     "gpmpc_cost": (_i, [_i, _i, _i, _i, ctypes.POINTER(CostParamsC), _vp, _vp, _vp, _vp, _vp]),
+    "gpmpc_cost_grad": (_i, [_i, _i, _i, _i, ctypes.POINTER(CostParamsC)] + [_vp] * 8),
+    "gpmpc_rollout_jac_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "gpmpc_rollout_jac": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "gpmpc_rollout_vjp": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gpmpc_rollout_workspace_bytes": (_sz, [_vp, _i, _i, _u]),
     "gpmpc_rollout": (_i, [_vp, _i, _i, _vp, _vp, ctypes.POINTER(CostParamsC), _u, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gpmpc_objective_gradient": (_i, [_vp, _i, _dp, _dp, ctypes.POINTER(CostParamsC), _u, _dp, _vp]),

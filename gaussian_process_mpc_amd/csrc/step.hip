@@ -383,8 +383,10 @@ __global__ __launch_bounds__(256) void k_roll_head(RollArgs A, int t) {
 // (Q^-1 + gamma Sig)^-1 = (I + gamma Q Sig)^-1 Q =: Z, so one LU of Mx = I + gamma Q Sig gives the
 // determinant and Z (no inverse of Q is formed).  Optionally returns d/dmu and d/dSig_kk.
 // w: scratch, ds * 2ds doubles.  gamma == 0: tr(Q Sig) + e^T Q e.
+// dsig (optional, [ds][ds], general Sigma): d/dSig_kl = Z_lk - gamma (Z^T e)_k (Z e)_l -- what autograd returns for the
+// reference's expression with a non-symmetric Sig (src/mpc.py:182-185).
 __device__ static double state_cost(int ds, const gpmpc_cost_params& C, const double* mu, const double* Sig, int sig_ld,
-                                    bool sig_diag, double* w, double* dmu, double* dvar) {
+                                    bool sig_diag, double* w, double* dmu, double* dvar, double* dsig = nullptr) {
     const double g = C.gamma;
     double e[GPMPC_MAX_DS];
     for (int k = 0; k < ds; ++k) e[k] = mu[k] - C.x_ref[k];
@@ -402,7 +404,8 @@ __device__ static double state_cost(int ds, const gpmpc_cost_params& C, const do
                 double qte = 0.0;
                 for (int l = 0; l < ds; ++l) qte += C.Q[l * ds + k] * e[l];
                 dmu[k] = qe + qte;
-                dvar[k] = C.Q[k * ds + k];
+                if (dvar) dvar[k] = C.Q[k * ds + k];
+                if (dsig) for (int l = 0; l < ds; ++l) dsig[k * ds + l] = C.Q[l * ds + k];
             }
         }
         return c;
@@ -445,7 +448,8 @@ __device__ static double state_cost(int ds, const gpmpc_cost_params& C, const do
     if (dmu)
         for (int k = 0; k < ds; ++k) {
             dmu[k] = ze[k] + zte[k];
-            dvar[k] = w[k * ld + ds + k] - g * zte[k] * ze[k];
+            if (dvar) dvar[k] = w[k * ld + ds + k] - g * zte[k] * ze[k];
+            if (dsig) for (int l = 0; l < ds; ++l) dsig[k * ds + l] = w[l * ld + ds + k] - g * zte[k] * ze[l];
         }
     return log(det) / g + quad;
 }
@@ -685,17 +689,52 @@ __global__ __launch_bounds__(256) void k_roll_tail(RollArgs A) {
 }
 
 // Stand-alone cost for given means / FULL covariances (cost_torch parity, src/mpc.py:156-200).
+// d_means / d_covs / d_U (all or none): the analytic derivatives autograd takes of the reference's expression
+// (src/mpc.py:251 backward through :179-198), for the differentiable cost_torch of the host mirror.
 __global__ void k_cost_full(int B, int H, int ds, int da, gpmpc_cost_params C, const double* means, const double* covs,
-                            const double* U, double* out) {
+                            const double* U, double* out, double* d_means, double* d_covs, double* d_U) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     double w[GPMPC_MAX_DS * 2 * GPMPC_MAX_DS];
     double total = 0.0;
-    for (int i = 0; i <= H; ++i)
-        total += state_cost(ds, C, means + ((size_t)b * (H + 1) + i) * ds, covs + ((size_t)b * (H + 1) + i) * ds * ds, ds,
-                            false, w, nullptr, nullptr);
-    total += input_cost(H, da, C, U + (size_t)b * H * da, nullptr);
+    for (int i = 0; i <= H; ++i) {
+        const size_t o = (size_t)b * (H + 1) + i;
+        total += state_cost(ds, C, means + o * ds, covs + o * ds * ds, ds, false, w, d_means ? d_means + o * ds : nullptr,
+                            nullptr, d_means ? d_covs + o * ds * ds : nullptr);
+    }
+    if (d_U) for (int q = 0; q < H * da; ++q) d_U[(size_t)b * H * da + q] = 0.0;
+    total += input_cost(H, da, C, U + (size_t)b * H * da, d_U ? d_U + (size_t)b * H * da : nullptr);
     out[b] = total;
+}
+
+// Vector-Jacobian product of the rollout (the backward pass of forward_propagate_torch's autograd graph,
+// src/dynamics.py:126-191 under src/mpc.py:251): reverse sweep over the step Jacobians J_t [2ds][2ds+da] (rows: mu_t, var_t;
+// columns: mu_{t-1}, var_{t-1}, u_{t-1}) seeded with the upstream gradients of EVERY step's mean and variance.
+// One wave per trajectory; lane c owns column c.
+__global__ __launch_bounds__(64) void k_rollout_vjp(int B, int H, int ds, int da, const double* __restrict__ jac,
+                                                    const double* __restrict__ g_means, const double* __restrict__ g_vars,
+                                                    double* __restrict__ out_gU, double* __restrict__ out_gx0) {
+    __shared__ double s_adj[2][2 * GPMPC_MAX_DS];
+    const int b = blockIdx.x, c = threadIdx.x, nz = 2 * ds, nc = 2 * ds + da;
+    auto seed = [&](int t, int r) {
+        const size_t o = ((size_t)b * (H + 1) + t) * ds;
+        return r < ds ? (g_means ? g_means[o + r] : 0.0) : (g_vars ? g_vars[o + (r - ds)] : 0.0);
+    };
+    if (c < nz) s_adj[0][c] = seed(H, c);
+    __syncthreads();
+    int cur = 0;
+    for (int t = H; t >= 1; --t) {
+        const double* Jt = jac + ((size_t)b * H + (t - 1)) * nz * nc;
+        if (c < nc) {
+            double sum = 0.0;
+            for (int r = 0; r < nz; ++r) sum = fma(Jt[r * nc + c], s_adj[cur][r], sum);
+            if (c < nz) s_adj[cur ^ 1][c] = seed(t - 1, c) + sum;
+            else out_gU[((size_t)b * H + (t - 1)) * da + (c - nz)] = sum;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (out_gx0 && c < ds) out_gx0[(size_t)b * ds + c] = s_adj[cur][c];      // mu_0 = x0; Sigma_0 is a constant
 }
 
 // ---------------------------------------------------------------------------
@@ -894,9 +933,12 @@ static void launch_head(const RollArgs& A, int t, hipStream_t s) {
     hipLaunchKernelGGL(k_roll_head<D>, dim3(A.B, A.ds, A.hchunks > 1 ? A.hchunks : 1), dim3(256), 0, s, A, t);
 }
 
+// ext_jac: caller-owned [B][H][2ds][2ds+da] buffer for the step Jacobians instead of the workspace's (gpmpc_rollout_jac);
+// full_first: horizon step 1 keeps the derivatives w.r.t. its state inputs (needed for d/dx0).
 static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, const double* U,
                            const gpmpc_cost_params* cost, unsigned flags, double* out_means, double* out_vars,
-                           double* out_cost, double* out_grad, void* workspace, size_t workspace_bytes, void* stream) {
+                           double* out_cost, double* out_grad, void* workspace, size_t workspace_bytes, void* stream,
+                           double* ext_jac = nullptr, bool full_first = false) {
     if (!p || !x0 || !U || !cost || !out_cost || !workspace || B < 1 || H < 1) return GPMPC_E_ARG;
     if (!p->built) return GPMPC_E_STATE;
     const bool grad = (flags & GPMPC_WANT_GRAD) != 0;
@@ -916,7 +958,7 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
     A.means = out_means ? out_means : (double*)(ws + r.off_means);
     A.vars = out_vars ? out_vars : (double*)(ws + r.off_vars);
     A.pp = (double*)(ws + r.off_pp); A.sp = (double*)(ws + r.off_sp); A.part = (double*)(ws + r.off_part);
-    A.jac = grad ? (double*)(ws + r.off_jac) : nullptr;
+    A.jac = grad ? (ext_jac ? ext_jac : (double*)(ws + r.off_jac)) : nullptr;
     A.hchunks = r.hchunks; A.hrows = r.hrows; A.mpart = r.hchunks > 1 ? (double*)(ws + r.off_mpart) : nullptr;
     A.G = r.sb ? (double*)(ws + r.off_G) : nullptr; A.gw = r.gw;
     A.pps = r.pps; A.sps = r.sps; A.nwork = r.nwork; A.nm = r.nm; A.grad = grad ? 1 : 0;
@@ -968,7 +1010,7 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
             PairSbArgs Q;
             Q.M = p->M; Q.XT = p->XT; Q.pp = A.pp; Q.G = A.G; Q.part = A.part; Q.work = P.work;
             Q.Np = p->Np; Q.B = B; Q.ds = p->ds; Q.nwork = r.nwork; Q.pps = r.pps; Q.nm = r.nm; Q.rgroup = r.rgroup;
-            Q.first_step = (t == 1 && !p->tune.no_first) ? 1 : 0;
+            Q.first_step = (t == 1 && !p->tune.no_first && !full_first) ? 1 : 0;
             rc = gpmpc_timed_pair_sb(p->D, grad, r.tb, p->ds, r.waves, Q, s);
         } else {
             rc = gpmpc_timed_pair(p->D, true, grad, r.tb, P.colsplit ? 4 : r.waves, P, s);
@@ -1192,13 +1234,55 @@ extern "C" int gpmpc_rollout(const gpmpc_pack* p, int B, int H, const double* x0
                            workspace_bytes, stream);
 }
 
-extern "C" int gpmpc_cost(int B, int H, int ds, int da, const gpmpc_cost_params* cost, const double* means,
-                          const double* covs, const double* U, double* out_cost, void* stream) {
+extern "C" int gpmpc_cost_grad(int B, int H, int ds, int da, const gpmpc_cost_params* cost, const double* means,
+                               const double* covs, const double* U, double* out_cost, double* d_means, double* d_covs,
+                               double* d_U, void* stream) {
     if (!cost || !means || !covs || !U || !out_cost || B < 1 || H < 1 || ds < 1 || ds > GPMPC_MAX_DS || da < 0 ||
         da > GPMPC_MAX_D)
         return GPMPC_E_ARG;
+    const int ng = (d_means != nullptr) + (d_covs != nullptr) + (d_U != nullptr);
+    if (ng != 0 && ng != 3) return GPMPC_E_ARG;            // all three derivative outputs or none
     hipLaunchKernelGGL(k_cost_full, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, B, H, ds, da, *cost, means,
-                       covs, U, out_cost);
+                       covs, U, out_cost, d_means, d_covs, d_U);
+    GPMPC_HIP(hipGetLastError());
+    return GPMPC_OK;
+}
+
+extern "C" int gpmpc_cost(int B, int H, int ds, int da, const gpmpc_cost_params* cost, const double* means,
+                          const double* covs, const double* U, double* out_cost, void* stream) {
+    return gpmpc_cost_grad(B, H, ds, da, cost, means, covs, U, out_cost, nullptr, nullptr, nullptr, stream);
+}
+
+// ---------------------------------------------------------------------------
+// Differentiable propagation: trajectory + step Jacobians, and their vector-Jacobian product
+// ---------------------------------------------------------------------------
+static inline size_t jac_scratch_bytes(const gpmpc_pack* p, int B, int H) {     // [cost | grad] of the (zero-cost) tail kernel
+    return (sizeof(double) * (size_t)B * (1 + (size_t)H * p->da) + 255) & ~(size_t)255;
+}
+extern "C" size_t gpmpc_rollout_jac_workspace_bytes(const gpmpc_pack* p, int B, int H) {
+    if (!p || B < 1 || H < 1) return 0;
+    return gpmpc_rollout_workspace_bytes(p, B, H, GPMPC_WANT_GRAD) + jac_scratch_bytes(p, B, H);
+}
+
+extern "C" int gpmpc_rollout_jac(const gpmpc_pack* p, int B, int H, const double* x0, const double* U, double* out_means,
+                                 double* out_vars, double* out_jac, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!p || !x0 || !U || !out_means || !out_vars || !out_jac || !workspace || B < 1 || H < 1) return GPMPC_E_ARG;
+    if (int rc_dev = gpmpc_check_device(p)) return rc_dev;
+    const size_t base = gpmpc_rollout_workspace_bytes(p, B, H, GPMPC_WANT_GRAD), extra = jac_scratch_bytes(p, B, H);
+    if (workspace_bytes < base + extra) return GPMPC_E_WORKSPACE;
+    gpmpc_cost_params zero;                                 // propagation only: a zero cost keeps the tail kernel trivial
+    memset(&zero, 0, sizeof(zero));
+    double* scratch = (double*)((char*)workspace + base);
+    return enqueue_rollout(p, B, H, x0, U, &zero, GPMPC_WANT_GRAD, out_means, out_vars, scratch, scratch + B, workspace, base,
+                           stream, out_jac, true);
+}
+
+extern "C" int gpmpc_rollout_vjp(int B, int H, int ds, int da, const double* jac, const double* g_means,
+                                 const double* g_vars, double* out_gU, double* out_gx0, void* stream) {
+    if (!jac || !out_gU || B < 1 || H < 1 || ds < 1 || ds > GPMPC_MAX_DS || da < 1 || da > GPMPC_MAX_D || 2 * ds + da > 64)
+        return GPMPC_E_ARG;
+    hipLaunchKernelGGL(k_rollout_vjp, dim3(B), dim3(64), 0, (hipStream_t)stream, B, H, ds, da, jac, g_means, g_vars, out_gU,
+                       out_gx0);
     GPMPC_HIP(hipGetLastError());
     return GPMPC_OK;
 }

@@ -1,13 +1,15 @@
 """Dynamics: host-side mirror of the reference class (src/dynamics.py:8-191) -- a bundle of
 ``state_dim`` GPs sharing X_train -- whose rollout runs in the HIP library.
 
-``forward_propagate_torch`` keeps the reference signature and return types (lists of H+1 tensors).
+``forward_propagate_torch`` keeps the reference signature and return types (lists of H+1 tensors, graph
+attached when the actions require grad).
 The batched entry ``rollout`` is the build's extension (the reference handles one trajectory per call).
 """
 import numpy as np
 import torch
 
 from .gpr import GaussianProcessRegression
+from .autograd import RolloutFunction, wants_grad
 from .rollout import CostParams, GPPack, rollout, rollout_fullcov
 
 
@@ -83,11 +85,21 @@ class Dynamics(object):
 
     def forward_propagate_torch(self, horizon, curr_state, actions):
         """Means and (diagonal) covariances of the H-step shooting rollout (src/dynamics.py:126-191).
-        Returns (list of H+1 (ds,) tensors, list of H+1 (ds,ds) tensors) on the device; the tensors are
-        results of the HIP kernels and carry no autograd graph (gradients w.r.t. the actions come from
-        RiskSensitiveMPC.gradient / Dynamics.rollout(want_grad=True))."""
-        U = torch.as_tensor(actions).detach().to(self.device, torch.float64).reshape(horizon, self.action_dim)
-        x0 = torch.as_tensor(curr_state).detach().to(self.device, torch.float64).reshape(self.state_dim)
-        r = self.rollout(x0, U)
-        means, vars_ = r["means"][0], r["vars"][0]
+        Returns (list of H+1 (ds,) tensors, list of H+1 (ds,ds) tensors) on the device.  Like the reference's, the
+        tensors carry the autograd graph when ``actions`` (or ``curr_state``) requires grad: the reference pattern
+        ``forward_propagate_torch -> cost_torch -> backward()`` (src/mpc.py:217-255) works on the mirror classes; the
+        graph has ONE node for the whole rollout (autograd.RolloutFunction: HIP forward, analytic step Jacobians, reverse
+        sweep on the device) instead of ~40 torch ops per (step, GP)."""
+        U = torch.as_tensor(actions)
+        x0 = torch.as_tensor(curr_state)
+        if wants_grad(U, x0):
+            Ud = U.to(self.device, torch.float64).reshape(1, horizon, self.action_dim)
+            xd = x0.to(self.device, torch.float64).reshape(1, self.state_dim)
+            means, vars_ = RolloutFunction.apply(xd, Ud, self.pack())
+            means, vars_ = means[0], vars_[0]
+        else:
+            U = U.detach().to(self.device, torch.float64).reshape(horizon, self.action_dim)
+            x0 = x0.detach().to(self.device, torch.float64).reshape(self.state_dim)
+            r = self.rollout(x0, U)
+            means, vars_ = r["means"][0], r["vars"][0]
         return [means[t] for t in range(horizon + 1)], [torch.diag(vars_[t]) for t in range(horizon + 1)]

@@ -14,6 +14,7 @@ forced by moving the rollout into one fused HIP call:
 import numpy as np
 import torch
 
+from .autograd import CostFunction, wants_grad
 from .dynamics import Dynamics
 from .rollout import CostParams, cost_full, rollout, rollout_fullcov
 
@@ -112,13 +113,19 @@ class RiskSensitiveMPC:
 
     def cost_torch(self, x, u, sig, x_ref, u_ref):
         """Risk-sensitive cost incl. the input-rate term for FULL covariance matrices
-        (src/mpc.py:156-200) on the device; x / sig may be lists of tensors or stacked tensors."""
+        (src/mpc.py:156-200) on the device; x / sig may be lists of tensors or stacked tensors.  Differentiable
+        like the reference's: if any of x, sig, u carries a graph the result does too (autograd.CostFunction), so
+        ``cost_torch(...).backward()`` fills ``u.grad`` as src/mpc.py:251 does."""
         xs = torch.stack([t.reshape(-1) for t in x]) if isinstance(x, (list, tuple)) else torch.as_tensor(x)
         ss = torch.stack(list(sig)) if isinstance(sig, (list, tuple)) else torch.as_tensor(sig)
         ss = ss.reshape(xs.shape[0], self.state_dim, self.state_dim)
-        out = cost_full(self._cost_params(x_ref, u_ref), xs.reshape(-1, self.state_dim), ss,
-                        torch.as_tensor(u).reshape(-1, self.input_dim))
-        return out[0]
+        xs = xs.reshape(-1, self.state_dim)
+        ut = torch.as_tensor(u).reshape(-1, self.input_dim)
+        cp = self._cost_params(x_ref, u_ref)
+        if wants_grad(xs, ss, ut):
+            to = lambda t: t.to(self.device, torch.float64)  # noqa: E731
+            return CostFunction.apply(to(xs)[None], to(ss)[None], to(ut)[None], cp)[0]
+        return cost_full(cp, xs, ss, ut)[0]
 
     # -- cyipopt problem object (src/mpc.py:202-267)
     def _evaluate(self, x):

@@ -167,6 +167,14 @@ int gpmpc_cost(int B, int H, int state_dim, int action_dim, const gpmpc_cost_par
                const double* means_dev, const double* covs_dev, const double* U_dev,
                double* out_cost, void* stream);
 
+/* The same cost with its derivatives: what `curr_cost.backward()` (src/mpc.py:251) leaves in the graph of
+ * cost_torch (src/mpc.py:179-198) -- d_means dev [B][H+1][ds], d_covs dev [B][H+1][ds][ds] (element [k][l] =
+ * d cost / d Sigma_kl of a general, possibly non-symmetric Sigma), d_U dev [B][H][da] (input and input-rate terms).
+ * The three derivative outputs are given together or all NULL. */
+int gpmpc_cost_grad(int B, int H, int state_dim, int action_dim, const gpmpc_cost_params* cost_host,
+                    const double* means_dev, const double* covs_dev, const double* U_dev,
+                    double* out_cost, double* d_means, double* d_covs, double* d_U, void* stream);
+
 /* ---------------------------------------------------------------------------
  * The hot path: B independent shooting rollouts + cost + gradient.
  * Replaces, for each trajectory b,
@@ -185,6 +193,22 @@ int gpmpc_rollout(const gpmpc_pack* pack, int B, int H, const double* x0_dev, co
                   const gpmpc_cost_params* cost_host, unsigned flags,
                   double* out_means, double* out_vars, double* out_cost, double* out_grad,
                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Differentiable propagation: Dynamics.forward_propagate_torch (src/dynamics.py:126-191) returns tensors with the autograd
+ * graph attached, and RiskSensitiveMPC.gradient back-propagates through it (src/mpc.py:218, :251).  The two entry points
+ * below are the forward and the backward of that graph:
+ *   gpmpc_rollout_jac   means / variances of B rollouts (no cost) + the step Jacobians
+ *                       out_jac dev [B][H][2ds][2ds+da]: rows (mu_t, var_t), columns (mu_{t-1}, var_{t-1}, u_{t-1})
+ *   gpmpc_rollout_vjp   g_means, g_vars dev [B][H+1][ds] (upstream gradients of every step's mean / variance; either
+ *                       may be NULL = zero) -> out_gU dev [B][H][da], out_gx0 dev [B][ds] or NULL.
+ * ------------------------------------------------------------------------- */
+size_t gpmpc_rollout_jac_workspace_bytes(const gpmpc_pack* pack, int B, int H);
+int gpmpc_rollout_jac(const gpmpc_pack* pack, int B, int H, const double* x0_dev, const double* U_dev,
+                      double* out_means, double* out_vars, double* out_jac,
+                      void* workspace, size_t workspace_bytes, void* stream);
+int gpmpc_rollout_vjp(int B, int H, int state_dim, int action_dim, const double* jac_dev,
+                      const double* g_means, const double* g_vars, double* out_gU, double* out_gx0, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Full-covariance form of the hot path (BASELINE config 5): the state distribution carries the whole ds x ds
