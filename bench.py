@@ -51,6 +51,9 @@ def parse_args():
     ap.add_argument("--kinv-cache", default="",
                     help="file to load the inverse kernel matrices from / save them to (profiling passes: rocprofv3 --pmc crashes "
                          "inside rocSOLVER's 4096^2 LU, so an unprofiled run writes the file and the profiled runs read it)")
+    ap.add_argument("--shared-lambda", action="store_true",
+                    help="every GP gets the same length-scales (the regime of the reference's experiments): exponent and exp "
+                         "are evaluated once per pair for all GPs (pair_kernel_sbs.h)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="rehearsal only: allow more ranks than visible GPUs (ranks share cards; use --backend gloo)")
     return ap.parse_args()
@@ -259,7 +262,7 @@ def run_rank(args):
     if args.config == "C4" and not args.batch:
         B = cfg["B"] // 8                                  # 1024 trajectories over 8 GPUs
     cid = int(args.config[1])
-    pb = synth_problem(cid, cfg["N"], cfg["ds"], cfg["da"], cfg["H"], B * world)
+    pb = synth_problem(cid, cfg["N"], cfg["ds"], cfg["da"], cfg["H"], B * world, shared_lambda=args.shared_lambda)
     N, ds, da, H, D = cfg["N"], cfg["ds"], cfg["da"], cfg["H"], cfg["ds"] + cfg["da"]
 
     # GP pack: rank 0 inverts, everyone receives the same bits

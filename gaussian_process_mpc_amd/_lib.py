@@ -62,6 +62,7 @@ SIGNATURES = {
     "gpmpc_pack_build_beta": (_i, [_vp, _vp, _vp, _vp, _dp, _dp, _vp]),
     "gpmpc_pack_enable_fullcov": (_i, [_vp, _vp]),
     "gpmpc_pack_dims": (_i, [_vp] + [ctypes.POINTER(_i)] * 4),
+    "gpmpc_pack_shared_lambda": (_i, [_vp]),
     "gpmpc_pack_export": (_i, [_vp, _vp, _vp, _vp]),
     "gpmpc_moment_match_workspace_bytes": (_sz, [_vp, _i]),
     "gpmpc_moment_match": (_i, [_vp, _i, _vp, _vp, _u] + [_vp] * 10 + [_vp, _sz, _vp]),

@@ -32,6 +32,19 @@ int gpmpc_launch_pair_sb(int D, bool grad, int tb, int ns2, int waves, const Pai
     return GPMPC_E_ARG;
 }
 
+int gpmpc_launch_pair_sbs(int D, bool grad, int ng, int ns2, const PairSbsArgs& a, hipStream_t s) {
+    switch (D) {
+        case 2: return gpmpc_launch_pair_sbs_D<2>(grad, ng, ns2, a, s);
+        case 3: return gpmpc_launch_pair_sbs_D<3>(grad, ng, ns2, a, s);
+        case 4: return gpmpc_launch_pair_sbs_D<4>(grad, ng, ns2, a, s);
+        case 5: return gpmpc_launch_pair_sbs_D<5>(grad, ng, ns2, a, s);
+        case 6: return gpmpc_launch_pair_sbs_D<6>(grad, ng, ns2, a, s);
+        case 7: return gpmpc_launch_pair_sbs_D<7>(grad, ng, ns2, a, s);
+        case 8: return gpmpc_launch_pair_sbs_D<8>(grad, ng, ns2, a, s);
+    }
+    return GPMPC_E_ARG;
+}
+
 int gpmpc_launch_pair_sbf(int D, bool grad, int ns2, int waves, const PairSbfArgs& a, hipStream_t s) {
     if (waves < 1 || waves > 4) return GPMPC_E_ARG;
     switch (D) {

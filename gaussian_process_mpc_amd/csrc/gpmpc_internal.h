@@ -42,6 +42,7 @@ struct gpmpc_tuning {
     int no_xcd_sort; // GPMPC_NO_XCD_SORT natural tile order of the 256x256 work list (takes effect at pack creation only)
     int hchunks;     // GPMPC_HEAD_CHUNKS row chunks of the head kernel: 0 / 1 none | 2..16 | -1 unset (chosen per call)
     int sbf_min;     // GPMPC_SBF_MIN     workgroups from which the full-S path uses 256x256 tiles + pair_kernel_sbf.h | 0 unset
+    int shared;      // GPMPC_SHARED      0: never use the shared-lambda kernel (pair_kernel_sbs.h) | -1 unset (used when lambdas are shared)
 };
 void gpmpc_read_tuning(gpmpc_tuning* t);
 
@@ -67,6 +68,11 @@ struct gpmpc_pack {
     void* graph_cache;         // captured rollout (GPMPC_USE_GRAPH), owned by step.hip
     void* cb_cache;            // buffers + captured graph of gpmpc_objective_gradient (solver callbacks), owned by step.hip
     gpmpc_worklist wl[2][4];   // [0: variance units only | 1: + cross units][0: 256x256 tiles | 1: 64x64 | 2: 256x64 | 3: 64x128]
+    // shared-lambda path (pair_kernel_sbs.h): every GP has bit-identical length-scales (detected at gpmpc_pack_build)
+    int shared_lambda;
+    int sh_ng;                 // GPs per workgroup
+    gpmpc_worklist wl_sh[2];   // items {group, i0, j0, tile}: [0: 256x256 tiles, XCD-sorted | 1: 256x64]; .nunits = groups
+    int sh_tiles[2];           // tiles per GP
 };
 
 // Number of pair-kernel output moments per (trajectory, GP, tile).
@@ -117,6 +123,29 @@ struct PairSbfArgs {
 static inline int gpmpc_sbf_gw(int D, int ns2) { return (D + 1 + ns2 * (ns2 + 1) / 2 + 1) & ~1; }
 int gpmpc_launch_pair_sbf(int D, bool grad, int ns2, int waves, const PairSbfArgs& a, hipStream_t s);
 template <int D> int gpmpc_launch_pair_sbf_D(bool grad, int ns2, int waves, const PairSbfArgs& a, hipStream_t s);
+
+// Arguments of the shared-lambda pair kernel (pair_kernel_sbs.h): all GPs of the bundle have the same length-scales.
+struct PairSbsArgs {
+    const double* M;      // [ds][Np][Np] as PairSbArgs
+    const double* XT;     // [D][Np]
+    const double* pp;     // [B][ds][pps]; the entry of GP 0 is read (the transform is the same for every GP)
+    const double* G;      // [B][Np][GW] ONE set of column rows per trajectory
+    double* part;         // [B][ds * tiles][nm]: tile q of GP a at item a * tiles + q
+    const int* work;      // [nwork][4] = {GP group, i0, j0, tile index within a GP}
+    int Np, B, ds, nwork, tiles, jt, pps, nm;
+    int rgroup, first_step;
+};
+// GPs per workgroup of the shared-lambda kernel: as many as keep the accumulators (NG x (1 + D + ds) doubles) within ~48,
+// then balanced over the groups.
+static inline int gpmpc_sbs_group(int ds, int D) {
+    int cap = 48 / (1 + D + ds);
+    if (cap > 4) cap = 4;
+    if (cap < 2) cap = 2;
+    const int groups = (ds + cap - 1) / cap;
+    return (ds + groups - 1) / groups;
+}
+int gpmpc_launch_pair_sbs(int D, bool grad, int ng, int ns2, const PairSbsArgs& a, hipStream_t s);
+template <int D> int gpmpc_launch_pair_sbs_D(bool grad, int ng, int ns2, const PairSbsArgs& a, hipStream_t s);
 
 int gpmpc_launch_pair_lowprec(int D, int mode, const PairArgs& a, hipStream_t s);     // lowprec.hip (tolerance sweep)
 

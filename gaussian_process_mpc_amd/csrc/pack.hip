@@ -117,7 +117,10 @@ __global__ void k_pack_cross(const double* __restrict__ beta, const double* __re
     Mx[((size_t)pr * Np + j) * Np + i] = out;
 }
 
-static int build_worklist(int Np, int it, int jt, int ds, int npairs, bool xcd_sort, gpmpc_worklist* w) {
+// tile_slot: the 4th entry of an item is the tile's index within its unit instead of j1 (the shared-lambda kernel computes
+// j1 from j0 and writes its partial sums by (GP, tile)); *tiles_out = tiles per unit.
+static int build_worklist(int Np, int it, int jt, int ds, int npairs, bool xcd_sort, gpmpc_worklist* w,
+                          bool tile_slot = false, int* tiles_out = nullptr) {
     const int ti = (Np + it - 1) / it, tj = (Np + jt - 1) / jt;
     const size_t cap = (size_t)ti * tj * (ds + npairs);
     int* h = (int*)malloc(sizeof(int) * 4 * cap);
@@ -129,8 +132,9 @@ static int build_worklist(int Np, int it, int jt, int ds, int npairs, bool xcd_s
             for (int j0 = 0; j0 < Np; j0 += jt) {
                 const int j1 = j0 + jt < Np ? j0 + jt : Np;
                 if (u < ds && j1 <= i0) continue;            // variance unit: tile wholly below the diagonal
-                h[4 * n] = u; h[4 * n + 1] = i0; h[4 * n + 2] = j0; h[4 * n + 3] = j1; ++n;
+                h[4 * n] = u; h[4 * n + 1] = i0; h[4 * n + 2] = j0; h[4 * n + 3] = tile_slot ? n - w->ustart_host[u] : j1; ++n;
             }
+        if (tiles_out) *tiles_out = n - w->ustart_host[u];
     }
     w->ustart_host[ds + npairs] = n;
     w->contiguous = 1;
@@ -185,10 +189,12 @@ void gpmpc_read_tuning(gpmpc_tuning* t) {
     t->no_xcd_sort = getenv("GPMPC_NO_XCD_SORT") ? 1 : 0;
     t->hchunks = geti("GPMPC_HEAD_CHUNKS", -1);
     t->sbf_min = geti("GPMPC_SBF_MIN", 0);
+    t->shared = geti("GPMPC_SHARED", -1);
 }
 
 extern "C" int gpmpc_pack_reload_tuning(gpmpc_pack* p) {
     if (!p) return GPMPC_E_ARG;
+    if (int rc_dev = gpmpc_check_device(p)) return rc_dev;   // the caches below hold streams / buffers of the pack's device
     const int keep = p->tune.no_xcd_sort;             // baked into the work list at creation
     gpmpc_read_tuning(&p->tune);
     p->tune.no_xcd_sort = keep;
@@ -234,6 +240,13 @@ extern "C" int gpmpc_pack_create(gpmpc_pack** out, int n_train, int state_dim, i
             if (mode == 1 && k >= 2) continue;
             ok = build_worklist(p->Np, cfg[k][0], cfg[k][1], state_dim, mode ? p->npairs : 0, mode == 0 && k == 0 && !p->tune.no_xcd_sort, &p->wl[mode][k]) == 0;
         }
+    // shared-lambda work lists (pair_kernel_sbs.h): "units" are groups of sh_ng GPs
+    if (ok && state_dim >= 2 && action_dim >= 1 && action_dim <= 2) {
+        p->sh_ng = gpmpc_sbs_group(state_dim, D);
+        const int groups = (state_dim + p->sh_ng - 1) / p->sh_ng;
+        ok = build_worklist(p->Np, 256, cfg[0][1], groups, 0, !p->tune.no_xcd_sort, &p->wl_sh[0], true, &p->sh_tiles[0]) == 0 &&
+             build_worklist(p->Np, 256, 64, groups, 0, false, &p->wl_sh[1], true, &p->sh_tiles[1]) == 0;
+    }
     if (!ok) { gpmpc_set_error("gpmpc_pack_create", e); gpmpc_pack_destroy(p); return GPMPC_E_ALLOC; }
     *out = p;
     return GPMPC_OK;
@@ -255,6 +268,10 @@ extern "C" int gpmpc_pack_destroy(gpmpc_pack* p) {
             if (p->wl[mode][k].work_dev) (void)hipFree(p->wl[mode][k].work_dev);
             if (p->wl[mode][k].ustart_dev) (void)hipFree(p->wl[mode][k].ustart_dev);
         }
+    for (int k = 0; k < 2; ++k) {
+        if (p->wl_sh[k].work_dev) (void)hipFree(p->wl_sh[k].work_dev);
+        if (p->wl_sh[k].ustart_dev) (void)hipFree(p->wl_sh[k].ustart_dev);
+    }
     free(p);
     return GPMPC_OK;
 }
@@ -279,6 +296,11 @@ static int pack_build_impl(gpmpc_pack* p, const double* X_dev, const double* Y_d
             if (!(p->lam_host[a][k] > 0.0)) return GPMPC_E_ARG;
         }
     }
+    // every GP with bit-identical length-scales (the reference's experiments): the rollout may share exponent and exp
+    // across the GPs of a pair (pair_kernel_sbs.h)
+    p->shared_lambda = p->sh_ng > 0 ? 1 : 0;
+    for (int a = 1; a < p->ds && p->shared_lambda; ++a)
+        if (memcmp(p->lam_host[a], p->lam_host[0], sizeof(double) * p->D) != 0) p->shared_lambda = 0;
     // hyper-parameters are tiny; pageable-host copies are staged synchronously by the runtime
     GPMPC_HIP(hipMemcpyAsync(p->lam, lambdas_host, sizeof(double) * p->ds * p->D, hipMemcpyHostToDevice, s));
     GPMPC_HIP(hipMemcpyAsync(p->sf, sigma_f_host, sizeof(double) * p->ds, hipMemcpyHostToDevice, s));
@@ -343,6 +365,11 @@ extern "C" int gpmpc_pack_dims(const gpmpc_pack* p, int* n, int* np, int* ds, in
     if (ds) *ds = p->ds;
     if (da) *da = p->da;
     return GPMPC_OK;
+}
+extern "C" int gpmpc_pack_shared_lambda(const gpmpc_pack* p) {
+    if (!p) return GPMPC_E_ARG;
+    if (!p->built) return GPMPC_E_STATE;
+    return p->shared_lambda;
 }
 extern "C" int gpmpc_pack_export(const gpmpc_pack* p, double* beta_out, double* weights_out, void* stream) {
     if (!p) return GPMPC_E_ARG;

@@ -39,6 +39,7 @@ struct RollArgs {
     double* jac;   // [B][H][2ds][2ds+da] or null
     double* G;     // [B][ds][Np][gw] column rows of the scalar-broadcast pair kernel, or null
     int gw;
+    int shared;    // shared-lambda path: G is [B][Np][gw], written by the workgroups of GP 0 only (pair_kernel_sbs.h)
     int pps, sps, nwork, nm, grad;
     // Row chunks of the head kernel (small batches of a large N: B ds workgroups walking all N rows are the slowest thing in
     // the step).  hchunks > 1: workgroup (b, a, c) takes rows [c, c+1) * hrows; the O(N) mean sums of step t are left as
@@ -267,7 +268,8 @@ __device__ static void prep_step(const RollArgs& A, int b, int t, int a, int chu
         Bk[k] = s_B[k];
         sck[k] = s_sc[k];
     }
-    double* __restrict__ Grow = A.G ? A.G + ((size_t)b * ds + a) * A.Np * A.gw : nullptr;
+    double* __restrict__ Grow = A.G ? (A.shared ? (a == 0 ? A.G + (size_t)b * A.Np * A.gw : nullptr)
+                                                : A.G + ((size_t)b * ds + a) * A.Np * A.gw) : nullptr;
     double v[1 + 2 * D];
 #pragma unroll
     for (int m = 0; m < 1 + 2 * D; ++m) v[m] = 0.0;
@@ -818,11 +820,15 @@ int gpmpc_timed_pair_sb(int D, bool grad, int tb, int ns2, int waves, const Pair
     return timed_launch(a.first_step ? GPMPC_TIME_FIRST : GPMPC_TIME_FULL, s,
                         [&] { return gpmpc_launch_pair_sb(D, grad, tb, ns2, waves, a, s); });
 }
+int gpmpc_timed_pair_sbs(int D, bool grad, int ng, int ns2, const PairSbsArgs& a, hipStream_t s) {
+    return timed_launch(a.first_step ? GPMPC_TIME_FIRST : GPMPC_TIME_FULL, s,
+                        [&] { return gpmpc_launch_pair_sbs(D, grad, ng, ns2, a, s); });
+}
 int gpmpc_timed_pair_sbf(int D, bool grad, int ns2, int waves, const PairSbfArgs& a, hipStream_t s) {
     return timed_launch(GPMPC_TIME_FULL, s, [&] { return gpmpc_launch_pair_sbf(D, grad, ns2, waves, a, s); });
 }
 
-struct RollPlan { int tiling, tb, waves, nwork, nm, pps, sps, sb, gw, rgroup, fused, fq, hchunks, hrows; size_t off_mpart; size_t off_G; size_t off_pp, off_sp, off_part, off_partz, off_jac, off_means, off_vars, total; };
+struct RollPlan { int tiling, tb, waves, nwork, nm, pps, sps, sb, gw, rgroup, fused, fq, hchunks, hrows, shared, sh_list; size_t off_mpart; size_t off_G; size_t off_pp, off_sp, off_part, off_partz, off_jac, off_means, off_vars, total; };
 
 static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag, RollPlan* r, bool lowprec = false) {
     const int D = p->D;
@@ -879,6 +885,17 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     r->fq = (r->fused && r->tiling == 1 && (long)B * p->wl[0][1].nwork < 256) ? 4 : 1;
     r->waves = p->wl[0][r->tiling].waves;
     r->nwork = p->wl[0][r->tiling].nwork;
+    // Shared length-scales: one exponent / exp per pair for a group of GPs (pair_kernel_sbs.h) wherever the scalar-broadcast
+    // kernel would run.  256x256 tiles once they give ~1500 workgroups (one trajectory per workgroup), else 256x64.
+    r->shared = 0; r->sh_list = 0;
+    if (r->sb && !lowprec && p->shared_lambda && tn.shared != 0 && p->sh_ng >= 2) {
+        r->shared = 1;
+        r->sh_list = ((long)B * p->wl_sh[0].nwork >= 1500) ? 0 : 1;
+        if (tn.tiling == 0 || tn.tiling == 2) r->sh_list = tn.tiling == 0 ? 0 : 1;
+        r->tb = 1; r->waves = 4;
+        r->nwork = p->ds * p->sh_tiles[r->sh_list];           // partial sums per trajectory: [GP][tile]
+        r->rgroup = r->sh_list == 0 ? ((tn.rgroup >= 1 && tn.rgroup <= 16) ? tn.rgroup : 4) : 1;
+    }
     r->nm = gpmpc_num_moments(D, diag, grad);
     r->pps = D + D * D;
     r->sps = sps_of(D);
@@ -901,7 +918,7 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     r->off_mpart = take(r->hchunks > 1 ? (size_t)2 * B * p->ds * r->hchunks * (1 + 2 * D) : 0);
     r->off_jac = take(grad ? (size_t)B * H * 2 * p->ds * (2 * p->ds + p->da) : 0);
     r->gw = gpmpc_sb_gw(D, p->ds);
-    r->off_G = take(r->sb ? (size_t)B * p->ds * p->Np * r->gw : 0);
+    r->off_G = take(r->sb ? (size_t)B * (r->shared ? 1 : p->ds) * p->Np * r->gw : 0);
     r->off_means = take((size_t)B * (H + 1) * p->ds);
     r->off_vars = take((size_t)B * (H + 1) * p->ds);
     r->total = off;
@@ -965,6 +982,10 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
     A.ustart = p->wl[0][r.tiling].ustart_dev;
     A.work = p->wl[0][r.tiling].contiguous ? nullptr : p->wl[0][r.tiling].work_dev;
     A.out_cost = out_cost; A.out_grad = out_grad; A.cost = *cost;
+    if (r.shared) {                                          // partial sums laid out [GP][tile]
+        A.shared = 1; A.ust_inline = 1; A.work = nullptr;
+        for (int a = 0; a <= p->ds; ++a) A.ust[a] = a * p->sh_tiles[r.sh_list];
+    }
 
     PairArgs P;
     P.M = p->M; P.XT = p->XT; P.pp = A.pp; P.part = A.part; P.work = p->wl[0][r.tiling].work_dev;
@@ -1006,6 +1027,14 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
         int rc;
         if (lowprec) {
             rc = gpmpc_launch_pair_lowprec(p->D, lowprec, P, s);
+        } else if (r.shared) {
+            const gpmpc_worklist& wl = p->wl_sh[r.sh_list];
+            PairSbsArgs Q;
+            Q.M = p->M; Q.XT = p->XT; Q.pp = A.pp; Q.G = A.G; Q.part = A.part; Q.work = wl.work_dev;
+            Q.Np = p->Np; Q.B = B; Q.ds = p->ds; Q.nwork = wl.nwork; Q.tiles = p->sh_tiles[r.sh_list]; Q.jt = wl.jt;
+            Q.pps = r.pps; Q.nm = r.nm; Q.rgroup = r.rgroup;
+            Q.first_step = (t == 1 && !p->tune.no_first && !full_first) ? 1 : 0;
+            rc = gpmpc_timed_pair_sbs(p->D, grad, p->sh_ng, p->ds, Q, s);
         } else if (r.sb) {
             PairSbArgs Q;
             Q.M = p->M; Q.XT = p->XT; Q.pp = A.pp; Q.G = A.G; Q.part = A.part; Q.work = P.work;

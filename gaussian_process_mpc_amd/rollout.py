@@ -119,9 +119,17 @@ class GPPack:
 
     def reload_tuning(self):
         """Re-read the GPMPC_* tuning environment variables (read once at pack creation otherwise)."""
-        check(lib().gpmpc_pack_reload_tuning(self._h), "gpmpc_pack_reload_tuning")
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize(self.device)
+            check(lib().gpmpc_pack_reload_tuning(self._h), "gpmpc_pack_reload_tuning")
         self._graph_bufs = {}
+        self._ws = {}
         return self
+
+    @property
+    def shared_lambda(self):
+        """True when every GP of the pack has bit-identical length-scales (the shared-lambda pair kernel applies)."""
+        return lib().gpmpc_pack_shared_lambda(self._h) == 1
 
     @property
     def handle(self):

@@ -12,16 +12,20 @@ CONFIGS = {
 }
 
 
-def synth_problem(config_id, N, ds, da, H, B, sigma_n=1e-2, lam_range=(2.0, 6.0)):
+def synth_problem(config_id, N, ds, da, H, B, sigma_n=1e-2, lam_range=(2.0, 6.0), shared_lambda=False):
     """states ~ U(-2,2), actions ~ U(-1,1), next = s + 0.1 tanh(s) + 0.1 sum(a) (smooth, bounded);
     lambdas ~ U(lam_range) per GP and dimension (non-proportional on purpose); sigma_f = 1;
-    x0 ~ U(-1,1), U ~ U(-1,1); Q = 0.1 I, R = 0.01 I (so that 1 + gamma Q var > 0 for gamma = -1)."""
+    x0 ~ U(-1,1), U ~ U(-1,1); Q = 0.1 I, R = 0.01 I (so that 1 + gamma Q var > 0 for gamma = -1).
+    shared_lambda: every GP gets the length-scales drawn for GP 0 -- the regime of the reference's own experiments
+    (one lambda for all GPs: src/experiments/pretrain_uncertainty.py:100-105, pretrain_pendulum.py:54-55)."""
     rng = np.random.default_rng(1000 + config_id)
     D = ds + da
     S = rng.uniform(-2, 2, size=(N, ds))
     A = rng.uniform(-1, 1, size=(N, da))
     Y = S + 0.1 * np.tanh(S) + 0.1 * A.sum(axis=1, keepdims=True)
     lam = rng.uniform(lam_range[0], lam_range[1], size=(ds, D))
+    if shared_lambda:
+        lam = np.tile(lam[:1], (ds, 1))
     return {
         "X": np.concatenate((S, A), axis=1), "Y": Y, "lambdas": lam,
         "sigma_f": np.ones(ds), "sigma_n": np.full(ds, sigma_n),

@@ -116,6 +116,10 @@ int gpmpc_pack_enable_fullcov(gpmpc_pack* pack, void* stream);
  * beta_out dev [ds][n_padded] (beta_a = Ky_inv_a y_a, zero padded); weights_out dev
  * [ds][n_padded][n_padded], element (i <= j) of M_a at [a][j][i], zero elsewhere. */
 int gpmpc_pack_dims(const gpmpc_pack* pack, int* n_train, int* n_padded, int* state_dim, int* action_dim);
+/* 1 if the last gpmpc_pack_build* found bit-identical length-scales for every GP (the setting of all of the reference's
+ * experiments, e.g. src/experiments/pretrain_uncertainty.py:100-105): gpmpc_rollout then evaluates exponent and exp once
+ * per pair for a group of GPs.  0 otherwise, negative on error.  Diagnostic; no reference counterpart. */
+int gpmpc_pack_shared_lambda(const gpmpc_pack* pack);
 int gpmpc_pack_export(const gpmpc_pack* pack, double* beta_out, double* weights_out, void* stream);
 
 /* ---------------------------------------------------------------------------
