@@ -54,6 +54,16 @@ def parse_args():
     ap.add_argument("--shared-lambda", action="store_true",
                     help="every GP gets the same length-scales (the regime of the reference's experiments): exponent and exp "
                          "are evaluated once per pair for all GPs (pair_kernel_sbs.h)")
+    ap.add_argument("--closed-loop", action="store_true",
+                    help="time the CALLERS of the path instead (SURVEY.md 8 f1/f2): Simulator.run on the pendulum plant with the "
+                         "training set growing by one observation per step; prints ONE JSON line with ms per environment step "
+                         "split into solve / pack build / inverse update")
+    ap.add_argument("--cl-pretrain", type=int, default=200)
+    ap.add_argument("--cl-steps", type=int, default=200)
+    ap.add_argument("--cl-horizon", type=int, default=10)
+    ap.add_argument("--cl-distinct", action="store_true", help="closed loop: a different lambda per GP (no shared inverse)")
+    ap.add_argument("--cl-rebuild", action="store_true", help="closed loop: the reference's O(N^3) rebuild on every step")
+    ap.add_argument("--dist-timeout", type=float, default=120.0, help="process-group timeout in seconds (--gpus > 1)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="rehearsal only: allow more ranks than visible GPUs (ranks share cards; use --backend gloo)")
     return ap.parse_args()
@@ -62,41 +72,68 @@ def parse_args():
 # ----------------------------------------------------------------------------------------------------------------------
 # launcher: N fresh rank processes, created before this process initialises any GPU state
 # ----------------------------------------------------------------------------------------------------------------------
-def spawn_ranks(args):
+def spawn_ranks(args, argv=None, poll_s=0.2):
+    """Start the N rank processes and relay rank 0's JSON line.  ALL children are polled: a rank that dies -- any rank, not
+    only rank 0 -- ends the job within a second with a non-zero status (the survivors would otherwise sit in a collective until
+    the process-group timeout).  `argv`: the per-rank command (tests substitute a stand-in for bench.py)."""
+    import selectors
     import torch                                   # device_count() does not initialise the GPU on this image
     ndev = torch.cuda.device_count()
-    if ndev < args.gpus and not args.oversubscribe:
+    if argv is None and ndev < args.gpus and not args.oversubscribe:
         print(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) visible (pass --oversubscribe --backend gloo for a "
               f"rehearsal with several ranks per card)", file=sys.stderr)
         return 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    cmd = argv if argv is not None else [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         # rank 0's stdout is filtered down to the JSON line (gloo prints connection banners on stdout)
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
     rc = 0
+    sel = selectors.DefaultSelector()
+    sel.register(procs[0].stdout, selectors.EVENT_READ)
+    out_open = True
     try:
-        for line in procs[0].stdout:
-            if line.lstrip().startswith("{"):
-                sys.stdout.write(line)
-                sys.stdout.flush()
-        for p in procs:
-            code = p.wait()
-            rc = rc or code
-            if code != 0:                          # one rank died: the others would wait in a collective for ever
-                for q in procs:
-                    if q.poll() is None:
-                        q.terminate()
+        while True:
+            if out_open:
+                for _key, _ev in sel.select(timeout=poll_s):
+                    line = procs[0].stdout.readline()
+                    if not line:
+                        sel.unregister(procs[0].stdout)
+                        out_open = False
+                    elif line.lstrip().startswith("{"):
+                        sys.stdout.write(line)
+                        sys.stdout.flush()
+            else:
+                time.sleep(poll_s)
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:                                # one rank died: the others would wait in a collective
+                rc = bad[0][1]
+                print(f"bench.py: rank {bad[0][0]} exited with status {rc}; stopping the other ranks", file=sys.stderr)
+                break
+            if all(c == 0 for c in codes):
+                if out_open:                       # drain what rank 0 wrote before it exited
+                    for line in procs[0].stdout:
+                        if line.lstrip().startswith("{"):
+                            sys.stdout.write(line)
+                            sys.stdout.flush()
+                break
     finally:
         for q in procs:
             if q.poll() is None:
+                q.terminate()
+        deadline = time.time() + 5.0
+        for q in procs:
+            try:
+                q.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
                 q.kill()
-    return rc
+    return rc if rc else 0
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -113,6 +150,27 @@ def pair_work(D, ds, want_grad, fullcov):
     return 4 * D + 37, 2 * D + 23
 
 
+def pair_instr(D, ds, want_grad, fullcov, shared_ng=0):
+    """STATIC instruction mix of the pair kernel's column loop per pair-evaluation (one (i, j) term of one GP), read off
+    the ISA of the instances bench.py times: (fp64-rate VALU instructions, integer VALU instructions,
+    executed flops with FMA = 2 and add / mul = 1; cvt / fract / ldexp are fp64-rate issue slots but not flops).
+    pair_kernel_sb.h:  exponent 1 add + D fma | exp cvt, fract, 2 fma, mul, fma, ldexp | P = M e mul | r add | v D fma | w ds fma.
+    pair_kernel_sbs.h (shared lambda, groups of shared_ng GPs): exponent and exp once per pair and group.
+    pair_kernel_sbf.h (full S): v D fma, W ds(ds+1)/2 fma."""
+    exp_f64, exp_int = 7, 3                      # table exp: 7 fp64-rate (3 of them fma, 1 mul) + 3 integer
+    head_f64 = 1 + D + exp_f64                   # per pair, shared by the GPs of a group in the shared-lambda kernel
+    head_fl = 1 + 2 * D + (2 * 3 + 1)
+    if not want_grad:
+        per_f64, per_fl = 2, 2                   # P = M e, r += P
+    elif fullcov:
+        nw = ds * (ds + 1) // 2
+        per_f64, per_fl = 2 + D + nw, 2 + 2 * (D + nw)
+    else:
+        per_f64, per_fl = 2 + D + ds, 2 + 2 * (D + ds)
+    g = float(shared_ng) if shared_ng else 1.0
+    return head_f64 / g + per_f64, exp_int / g, head_fl / g + per_fl
+
+
 def build_kinv(pb, device):
     """Ky_inv of every GP on the device: Kf/Ky by the HIP kernel (src/gpr.py:163-170), inverse by
     torch.linalg.inv as the reference (src/gpr.py:171)."""
@@ -121,15 +179,13 @@ def build_kinv(pb, device):
     from gaussian_process_mpc_amd._lib import lib, ptr, stream_ptr, host_doubles, check
     X = torch.as_tensor(pb["X"], device=device)
     N, D = X.shape
-    out = torch.empty((pb["ds"], N, N), dtype=torch.float64, device=device)
-    Ky = torch.empty((N, N), dtype=torch.float64, device=device)
+    Ky = torch.empty((pb["ds"], N, N), dtype=torch.float64, device=device)
     for a in range(pb["ds"]):
         _, lp = host_doubles(pb["lambdas"][a])
         noise = float(np.float32(pb["sigma_n"][a] ** 2))          # src/gpr.py:170 adds a float32 diagonal
-        check(lib().gpmpc_build_ky(N, D, ptr(X), lp, float(pb["sigma_f"][a]), noise, None, ptr(Ky), stream_ptr()),
+        check(lib().gpmpc_build_ky(N, D, ptr(X), lp, float(pb["sigma_f"][a]), noise, None, ptr(Ky[a]), stream_ptr()),
               "gpmpc_build_ky")
-        out[a] = torch.linalg.inv(Ky)
-    return out
+    return torch.linalg.inv(Ky)                                   # ONE batched LU over the (ds, N, N) stack
 
 
 def cpu_model():
@@ -200,23 +256,44 @@ def cpu_baseline(pb, cfg, fullcov, reps):
     return res
 
 
+def reference_time_ratio(config):
+    """oracle-faithful time / reference time on identical inputs, measured in the build container by
+    tools/check_cpu_baseline_vs_reference.py (the reference cannot travel to the GPU box)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03", "cpu_baseline_vs_reference.json")) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None
+    row = d.get("configs", {}).get(config) or d.get("configs", {}).get("C3")
+    if not row:
+        return None
+    return {"ratio": row["oracle_over_reference_time"], "measured_on": f"{config if config in d['configs'] else 'C3'} sizes, H = {row['H_timed']}, "
+            f"{d.get('threads')} threads of {d.get('cpu')} (build container); reference {row['reference_s']:.3f} s, oracle "
+            f"{row['oracle_faithful_s']:.3f} s, costs agree to {row['cost_rel_diff']:.1e}"}
+
+
 def measured_traffic(config, B, want_grad, kernel_hint):
     """HBM-side bytes per launch of the dominant kernel from the tracked PMC summary of THIS workload
     (profiles/r02/pmc_<config>.json, written by tools/prof_pmc.sh: separate --pmc passes of `bench.py --config <config>`;
     FETCH_SIZE x 2 for the gfx950 wide-read correction + WRITE_SIZE, both in KiB).  None when no summary matches."""
-    path = os.path.join(ROOT, "profiles", "r02", f"pmc_{config}.json")
-    try:
-        with open(path) as f:
-            d = json.load(f)
-    except (OSError, ValueError):
+    d, rnd = None, None
+    for rnd in ("r03", "r02"):
+        try:
+            with open(os.path.join(ROOT, "profiles", rnd, f"pmc_{config}.json")) as f:
+                d = json.load(f)
+            break
+        except (OSError, ValueError):
+            continue
+    if d is None:
         return None, None
-    if d.get("batch_per_gpu") != B or bool(d.get("want_grad", True)) != bool(want_grad):
+    if d.get("batch_per_gpu") != B or bool(d.get("want_grad", True)) != bool(want_grad) or \
+            bool(d.get("shared_lambda", False)) != bool(kernel_hint == "sbs"):
         return None, None
     k = d.get("dominant_kernel", {})
     if "FETCH_SIZE" not in k or "WRITE_SIZE" not in k:
         return None, None
     traffic = (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
-    src = (f"profiles/r02/pmc_{config}.json (HEAD {d.get('head', '?')}; `{d.get('command', '?')}`; kernel {k.get('name', '?')}; "
+    src = (f"profiles/{rnd}/pmc_{config}.json (HEAD {d.get('head', '?')}; `{d.get('command', '?')}`; kernel {k.get('name', '?')}; "
            f"2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes; Infinity-Cache hits are included in FETCH_SIZE)")
     return traffic, src
 
@@ -246,10 +323,13 @@ def run_rank(args):
     dist = None
     if world > 1:
         import torch.distributed as dist
+        from datetime import timedelta
+        # a rank that never arrives must fail the job well inside the driver's 600 s, not after the 10-minute default
+        tmo = timedelta(seconds=args.dist_timeout)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, timeout=tmo)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=tmo)
         assert dist.get_world_size() == args.gpus
 
     import gaussian_process_mpc_amd as g
@@ -323,7 +403,7 @@ def run_rank(args):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     tcls = []
-    for cls in (0, 1):                                     # 0: the full pair kernel, 1: its horizon-step-1 variant
+    for cls in (0, 1, 2):                                  # 0: the full pair kernel, 1: its horizon-step-1 variant, 2: fused step kernel
         L.gpmpc_pair_kernel_time_class(cls, ctypes.byref(ms), ctypes.byref(nl))
         tcls.append((ms.value, nl.value))
     L.gpmpc_timing_enable(0)
@@ -340,11 +420,26 @@ def run_rank(args):
             pairs_per_launch += B * (ds * (ds - 1) / 2) * N * N
         fl, slots = pair_work(D, ds, want_grad, fullcov)
         full_ms, full_n = tcls[0]
+        fused_path = full_n == 0 and tcls[2][1] > 0            # small batches: one fused launch per horizon step
+        if fused_path:
+            full_ms, full_n = tcls[2]
         launch_s = (full_ms / full_n) * 1e-3 if full_n else float("nan")
         achieved = pairs_per_launch * fl / launch_s / 1e12
         m_bytes = 8 * (ds * N * (N + 1) / 2 + (ds * (ds - 1) / 2 * N * N if fullcov else 0))     # M read once per launch
-        traffic, traffic_src = measured_traffic(args.config, B, want_grad, None)
-        sm = "sbf" if fullcov else "sb"
+        shared = bool(pack.shared_lambda) and not fullcov and os.environ.get("GPMPC_SHARED", "") != "0"
+        sm = "sbf" if fullcov else ("sbs" if shared else "sb")
+        traffic, traffic_src = measured_traffic(args.config, B, want_grad, sm)
+        ng = 0
+        if shared:                                             # GPs per workgroup: gpmpc_sbs_group (gpmpc_internal.h)
+            cap = max(2, min(4, 48 // (1 + D + ds)))
+            groups = (ds + cap - 1) // cap
+            ng = (ds + groups - 1) // groups
+        i_f64, i_int, i_fl = pair_instr(D, ds, want_grad, fullcov, ng)
+        # every VALU instruction (fp64-rate or integer) occupies its SIMD for 4 cycles per wave64 at the spec clock
+        issue_util = (i_f64 + i_int) * 4.0 * pairs_per_launch / 64.0 / (1024 * launch_s * 2.4e9)
+        executed_frac = pairs_per_launch * i_fl / launch_s / 1e12 / FP64_PEAK_TFLOPS
+        kname = ("k_step_fused (one launch per horizon step: mean sums + finish work + pair tiles; NOT a pair-only time)" if fused_path
+                 else f"gpmpc_pair_kernel_{sm} (full variant; the cheaper horizon-step-1 variant is reported under first_step_variant)")
         out = {
             "metric": "GP-MPC rollouts/sec (N train pts x H horizon x d dims)",
             "value": value, "unit": "rollouts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -353,31 +448,41 @@ def run_rank(args):
             "config": {"workload": f"{args.config}: N={N}, d(state_dim)={ds}, action_dim={da}, H={H}, "
                                    f"B={B} trajectories per GPU, gamma={cfg['gamma']}, "
                                    + ("full covariance, " if fullcov else "")
+                                   + ("one lambda for all GPs (shared-lambda kernel), " if args.shared_lambda else "")
                                    + ("objective+gradient" if want_grad else "objective only"),
                        "N": N, "state_dim": ds, "action_dim": da, "H": H, "batch_per_gpu": B,
+                       "shared_lambda": bool(args.shared_lambda),
                        "parallelism": f"trajectory-sharded x{world}" if world > 1 else "single GPU"},
             "dist": {"world_size": dist.get_world_size() if world > 1 else 1,
                      "backend": dist.get_backend() if world > 1 else None,
                      "visible_devices": ndev, "launcher": "torch.distributed.run / external" if "TORCHELASTIC_RUN_ID" in os.environ
                      else ("bench.py spawn" if world > 1 else "single process")},
             "roofline": {
-                "kernel": f"gpmpc_pair_kernel_{sm} (full variant; the cheaper horizon-step-1 variant is reported under first_step_variant)",
+                "kernel": kname,
                 "bound": "valu_fp64",
                 "bound_note": "fp64 VALU issue: no MFMA instruction is executed (fp64 MFMA shares the fp64 VALU's issue capacity on "
                               "MI355X, profiles/r01/ubench_mfma_f64_overlap.txt) and HBM is not binding at B >= 4; priced against the "
                               "fp64 vector peak of 78.6 TFLOP/s",
                 "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
                 "traffic": traffic, "traffic_source": traffic_src,
-                "definition": "achieved = pairs_per_launch x algorithmic_flops_per_pair / avg_launch_ms of the full pair kernel "
+                "traffic_measured_in_run": False,
+                "traffic_note": "PMC counters need separate rocprofv3 --pmc passes: `traffic` is the per-launch figure of the tracked "
+                                "sidecar named in traffic_source (its HEAD is stated there), null when none matches this workload",
+                "definition": "achieved = pairs_per_launch x algorithmic_flops_per_pair / avg_launch_ms of the dominant kernel "
                               "(HIP events on its launch stream over the timed region); algorithmic flops per pair = 4D+37 "
-                              "(objective+gradient, SURVEY.md 8d; FMA = 2)",
-                "algorithmic_flops_per_pair": fl, "pairs_per_launch": pairs_per_launch,
+                              "(objective+gradient, SURVEY.md 8d; FMA = 2; prices a 19-slot libm exp where the kernel executes a "
+                              "7-slot table exp, so `frac` is an ALGORITHMIC rate, not a utilisation -- the two bounded figures are "
+                              "issue_util and executed_flops_frac)",
+                "algorithmic_flops_per_pair": fl, "algorithmic_slots_per_pair_survey_8d": slots, "pairs_per_launch": pairs_per_launch,
                 "avg_launch_ms": launch_s * 1e3, "launches": full_n,
                 "first_step_variant": {"avg_launch_ms": (tcls[1][0] / tcls[1][1]) if tcls[1][1] else None, "launches": tcls[1][1]},
-                "frac_survey_8d_slots": pairs_per_launch * slots / launch_s / 1e12 / FP64_PEAK_TSLOTS,
-                "frac_survey_8d_slots_note": f"SURVEY.md 8d's primary convention: {slots} algorithmic fp64 issue slots per pair "
-                                             f"against {FP64_PEAK_TSLOTS}e12 slots/s (counts ocml's 19-slot exp; the kernel's table exp "
-                                             f"issues 7)",
+                "issue_util": None if fused_path else issue_util,
+                "issue_util_note": f"static VALU instructions of the column loop per pair ({i_f64:g} fp64-rate + {i_int:g} integer) x 4 "
+                                   "cycles x pairs / 64 lanes over 1024 SIMDs x launch time x 2.4 GHz (spec clock; the chip holds "
+                                   "~2.25 GHz under this kernel): <= 1 by construction",
+                "executed_flops_frac": None if fused_path else executed_frac,
+                "executed_flops_note": f"flops the kernel EXECUTES per pair ({i_fl:g}: FMA = 2, add / mul = 1; conversions, fract and "
+                                       "ldexp are issue slots but not flops) against the 78.6 TFLOP/s peak",
                 "hbm_algorithmic_GBs": m_bytes / launch_s / 1e9, "hbm_frac": m_bytes / launch_s / 1e9 / HBM_PEAK_GBS,
             },
             "pack_build_ms": pack_ms,
@@ -423,6 +528,8 @@ def run_rank(args):
                 "c_port_value": res.get("cport"), "c_port_value_1_thread": res.get("cport_1_thread"),
                 "c_port_note": "plain-C / OpenMP port of the O(N^2) algorithm with the analytic adjoint (oracle/cport), whole "
                                "horizon, its own pack build excluded (3-trajectory minus 1-trajectory run), same thread count",
+                "oracle_over_reference_time": (reference_time_ratio(args.config) or {}).get("ratio"),
+                "oracle_over_reference_note": (reference_time_ratio(args.config) or {}).get("measured_on"),
                 "gpu_over_cpu": value / res["faithful"], "gpu_over_cpu_o2": value / res["o2"],
                 "gpu_over_c_port": (value / res["cport"]) if res.get("cport") else None,
             }
@@ -440,8 +547,76 @@ def run_rank(args):
     return 0
 
 
+def run_closed_loop(args):
+    """Simulator.run (src/simulator.py:37-60) on PendulumPlant, unrolled here so that every phase of an environment step
+    can be timed: solve (get_optimal_trajectory: ~50-300 objective+gradient callbacks of the B = 1 rollout), pack build
+    (O(N^2): beta, folded weights), and the update of Ky_inv for the new observation (src/simulator.py:55 ->
+    src/gpr.py:171: O(N^3) rebuild per GP in the reference; here one O(N^2) Schur append shared by the GPs with identical
+    hyper-parameters, and a full rebuild every 64 appends)."""
+    import numpy as np
+    import torch
+    import gaussian_process_mpc_amd as g
+    dev = g.require_gpu()
+    rng = np.random.default_rng(0)
+    plant = g.PendulumPlant()
+    H = args.cl_horizon
+    mpc = g.RiskSensitiveMPC(1e-5, H, 2, 1, Q=2 * np.eye(2), R=0.001 * np.eye(1))
+    for k, gp in enumerate(mpc.dynamics.gpr_err):         # hypers before data, as in pretrain_uncertainty.py:100-105
+        gp.set_lambdas(np.array([0.5, 0.5, 0.5]) * (1.0 + (0.1 * k if args.cl_distinct else 0.0)))
+        gp.set_sigma_n(1e-3)
+    n0 = args.cl_pretrain
+    S = np.column_stack((rng.uniform(-np.pi, np.pi, n0), rng.uniform(-8, 8, n0)))
+    A = rng.uniform(-2, 2, (n0, 1))
+    NS = np.empty_like(S)
+    for i in range(n0):
+        plant.state = S[i].copy()
+        NS[i] = plant.step(A[i])[0]
+    sync = lambda: torch.cuda.synchronize(dev)            # noqa: E731
+    t0 = time.perf_counter(); mpc.dynamics.append_train_data(S, A, NS); sync()
+    t_first_build = (time.perf_counter() - t0) * 1e3
+    mpc.set_lb([-2.0]); mpc.set_ub([2.0]); mpc.set_xref(np.zeros(2))
+    obs, _ = plant.reset()
+    mpc.dynamics.pack(); mpc.get_optimal_trajectory(obs)  # warm-up: library load, graph capture
+    rows = []
+    for it in range(args.cl_steps):
+        sync(); ta = time.perf_counter()
+        mpc.dynamics.pack(); sync(); tb = time.perf_counter()
+        action = mpc.get_optimal_trajectory(obs)[0, :]; tc = time.perf_counter()
+        nxt, _, _, _, _ = plant.step(action); td = time.perf_counter()
+        mpc.dynamics.append_train_data(obs, action, nxt, incremental=not args.cl_rebuild); sync(); te = time.perf_counter()
+        rows.append((tb - ta, tc - tb, td - tc, te - td, mpc.dynamics.gpr_err[0]._appends_since_rebuild == 0))
+        obs = nxt
+    r = np.array([[a, b, c, d] for a, b, c, d, _ in rows]) * 1e3
+    full = np.array([x[4] for x in rows])
+    total = r.sum(axis=1)
+    out = {
+        "metric": "closed-loop GP-MPC, ms per environment step (Simulator.run on the pendulum plant)", "unit": "ms",
+        "value": float(np.median(total)), "higher_is_better": False, "n_gpus": 1, "data": "synthetic", "dtype": "f64",
+        "config": {"workload": f"PendulumPlant, ds=2, da=1, H={H}, training set {n0} -> {n0 + args.cl_steps}, lambda = 0.5 "
+                               + ("x (1, 1.1) per GP (distinct)" if args.cl_distinct else "for every GP (the reference's regime)")
+                               + ", sigma_n = 1e-3, solver " + str(mpc.solver_used)
+                               + (", full O(N^3) rebuild per step (the reference's update)" if args.cl_rebuild else
+                                  ", O(N^2) Schur append per step, full rebuild every 64")},
+        "steps": args.cl_steps,
+        "step_ms": {"median": float(np.median(total)), "mean": float(total.mean()), "max": float(total.max()),
+                    "p95": float(np.percentile(total, 95)), "max_over_median": float(total.max() / np.median(total))},
+        "split_ms_mean": {"pack_build": float(r[:, 0].mean()), "solve": float(r[:, 1].mean()), "plant": float(r[:, 2].mean()),
+                          "inverse_update": float(r[:, 3].mean())},
+        "inverse_update_ms": {"append_mean": float(r[~full, 3].mean()) if (~full).any() else None,
+                              "full_rebuild_mean": float(r[full, 3].mean()) if full.any() else None,
+                              "full_rebuilds": int(full.sum())},
+        "first_build_ms": t_first_build,
+        "solve_callbacks_note": "solve = scipy L-BFGS-B stand-in on the objective / gradient callbacks (cyipopt absent): optimiser "
+                                "results are unpinned, the timing split is what is reported",
+    }
+    print(json.dumps(out), flush=True)
+    return 0
+
+
 def main():
     args = parse_args()
+    if args.closed_loop:
+        return run_closed_loop(args)
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -179,7 +179,8 @@ static inline int gpmpc_check_device(const gpmpc_pack* p) {
     return dev == p->device ? GPMPC_OK : GPMPC_E_DEVICE;
 }
 // pair-kernel timing classes (gpmpc_pair_kernel_time_class): the horizon-step-1 variant is cheaper than the full kernel
-enum { GPMPC_TIME_FULL = 0, GPMPC_TIME_FIRST = 1, GPMPC_TIME_CLASSES = 2 };
+// (the fused small-batch step kernel -- mean sums, finish work and tiles of one horizon step in one launch -- has its own class)
+enum { GPMPC_TIME_FULL = 0, GPMPC_TIME_FIRST = 1, GPMPC_TIME_FUSED = 2, GPMPC_TIME_CLASSES = 3 };
 void gpmpc_graph_cache_free(void* cache);
 void gpmpc_cb_cache_free(void* cache);
 #define GPMPC_HIP(call)                                              \

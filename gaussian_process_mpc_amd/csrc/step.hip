@@ -763,8 +763,8 @@ struct EvPair { hipEvent_t a, b; int cls; };
 static struct {
     std::mutex mu;
     int on = 0;
-    double ms[GPMPC_TIME_CLASSES] = {0.0, 0.0};
-    long long n[GPMPC_TIME_CLASSES] = {0, 0};
+    double ms[GPMPC_TIME_CLASSES] = {0.0, 0.0, 0.0};
+    long long n[GPMPC_TIME_CLASSES] = {0, 0, 0};
     std::vector<EvPair> pending;
 } g_time;
 
@@ -783,8 +783,8 @@ extern "C" int gpmpc_timing_enable(int on) { std::lock_guard<std::mutex> lk(g_ti
 extern "C" int gpmpc_pair_kernel_time(double* total_ms, long long* launches, int reset) {
     std::lock_guard<std::mutex> lk(g_time.mu);
     drain_events_locked();
-    if (total_ms) *total_ms = g_time.ms[0] + g_time.ms[1];
-    if (launches) *launches = g_time.n[0] + g_time.n[1];
+    if (total_ms) *total_ms = g_time.ms[0] + g_time.ms[1] + g_time.ms[2];
+    if (launches) *launches = g_time.n[0] + g_time.n[1] + g_time.n[2];
     if (reset) for (int c = 0; c < GPMPC_TIME_CLASSES; ++c) { g_time.ms[c] = 0.0; g_time.n[c] = 0; }
     return GPMPC_OK;
 }
@@ -1007,7 +1007,7 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
         F.sp = A.sp; F.part = A.part; F.partz = (double*)(ws + r.off_partz);
         F.sps = r.sps; F.nm = r.nm;
         for (int t = 1; t <= H; ++t) {
-            const int rc = timed_launch(GPMPC_TIME_FULL, s, [&] { return launch_step_fused(p->D, grad, p->ds, r.fq, F, t, s); });
+            const int rc = timed_launch(GPMPC_TIME_FUSED, s, [&] { return launch_step_fused(p->D, grad, p->ds, r.fq, F, t, s); });
             if (rc != GPMPC_OK) return rc;
         }
         A.part += (size_t)(H & 1) * B * nwg * r.nm;          // the tail finishes step H from the parity the last launch wrote
@@ -1187,7 +1187,8 @@ extern "C" int gpmpc_objective_gradient(gpmpc_pack* p, int H, const double* x0_h
     if (!p || !x0_host || !U_host || !cost || !out_host || H < 1) return GPMPC_E_ARG;
     if (!p->built) return GPMPC_E_STATE;
     if (int rc_dev = gpmpc_check_device(p)) return rc_dev;
-    if (timing_on()) return GPMPC_E_STATE;                 // per-kernel events cannot be recorded inside a captured graph
+    // per-kernel events cannot be recorded inside a captured graph: with timing on the same work is enqueued uncaptured
+    const bool eager = timing_on();
     flags &= GPMPC_WANT_GRAD;
     const bool grad = (flags & GPMPC_WANT_GRAD) != 0;
     const int nin = p->ds + H * p->da, nout = 1 + (grad ? H * p->da : 0);
@@ -1195,9 +1196,11 @@ extern "C" int gpmpc_objective_gradient(gpmpc_pack* p, int H, const double* x0_h
     if (!g) {
         g = (gpmpc_cb_cache*)calloc(1, sizeof(gpmpc_cb_cache));
         if (!g) return GPMPC_E_ALLOC;
+        // published only when complete: a half-initialised cache (null stream) must never be found by a later call
+        hipError_t e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_in, hipEventDisableTiming);
+        if (e != hipSuccess) { gpmpc_set_error("gpmpc_objective_gradient: stream / event creation", e); gpmpc_cb_cache_free(g); return GPMPC_E_LAUNCH; }
         p->cb_cache = g;
-        GPMPC_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
-        GPMPC_HIP(hipEventCreateWithFlags(&g->ev_in, hipEventDisableTiming));
     }
     if (H > g->cap_H) {                                   // (re)allocate for the longer horizon
         (void)hipStreamSynchronize(g->stream);
@@ -1210,13 +1213,28 @@ extern "C" int gpmpc_objective_gradient(gpmpc_pack* p, int H, const double* x0_h
         if (g->ws) (void)hipFree(g->ws);
         g->h_in = g->h_out = g->d_in = g->d_out = nullptr; g->ws = nullptr; g->cap_H = 0;
         const size_t bin = sizeof(double) * (p->ds + (size_t)H * p->da), bout = sizeof(double) * (1 + (size_t)H * p->da);
-        if (hipHostMalloc((void**)&g->h_in, bin, hipHostMallocDefault) != hipSuccess ||
-            hipHostMalloc((void**)&g->h_out, bout, hipHostMallocDefault) != hipSuccess ||
-            hipMalloc((void**)&g->d_in, bin) != hipSuccess || hipMalloc((void**)&g->d_out, bout) != hipSuccess)
-            return GPMPC_E_ALLOC;
+        hipError_t ea = hipHostMalloc((void**)&g->h_in, bin, hipHostMallocDefault);
+        if (ea == hipSuccess) ea = hipHostMalloc((void**)&g->h_out, bout, hipHostMallocDefault);
+        if (ea == hipSuccess) ea = hipMalloc((void**)&g->d_in, bin);
+        if (ea == hipSuccess) ea = hipMalloc((void**)&g->d_out, bout);
         g->ws_bytes = gpmpc_rollout_workspace_bytes(p, 1, H, GPMPC_WANT_GRAD);
-        if (hipMalloc(&g->ws, g->ws_bytes) != hipSuccess) return GPMPC_E_ALLOC;
+        if (ea == hipSuccess) ea = hipMalloc(&g->ws, g->ws_bytes);
+        if (ea != hipSuccess) { gpmpc_set_error("gpmpc_objective_gradient: staging allocation", ea); return GPMPC_E_ALLOC; }   // cap_H stays 0: retried next call
         g->cap_H = H;
+    }
+    if (eager) {                                          // timing on: upload, the H + 1 launches, download -- uncaptured
+        memcpy(g->h_in, x0_host, sizeof(double) * p->ds);
+        memcpy(g->h_in + p->ds, U_host, sizeof(double) * (size_t)H * p->da);
+        GPMPC_HIP(hipEventRecord(g->ev_in, (hipStream_t)stream));
+        GPMPC_HIP(hipStreamWaitEvent(g->stream, g->ev_in, 0));
+        GPMPC_HIP(hipMemcpyAsync(g->d_in, g->h_in, sizeof(double) * nin, hipMemcpyHostToDevice, g->stream));
+        const int rc = enqueue_rollout(p, 1, H, g->d_in, g->d_in + p->ds, cost, flags, nullptr, nullptr, g->d_out,
+                                       grad ? g->d_out + 1 : nullptr, g->ws, g->ws_bytes, g->stream);
+        if (rc != GPMPC_OK) return rc;
+        GPMPC_HIP(hipMemcpyAsync(g->h_out, g->d_out, sizeof(double) * nout, hipMemcpyDeviceToHost, g->stream));
+        GPMPC_HIP(hipStreamSynchronize(g->stream));
+        memcpy(out_host, g->h_out, sizeof(double) * nout);
+        return GPMPC_OK;
     }
     if (!g->valid || g->H != H || g->flags != flags || memcmp(&g->cost, cost, sizeof(*cost)) != 0) {
         (void)hipStreamSynchronize(g->stream);

@@ -31,16 +31,41 @@ class Dynamics(object):
         """(state, action, next_state) observations, one or many (src/dynamics.py:39-60).  incremental=True: O(N^2)
         update of every Ky_inv for a single new observation (see GaussianProcessRegression.append_train_data)."""
         state, action, next_state = np.asarray(state), np.asarray(action), np.asarray(next_state)
+        # Every GP receives the same input rows; GPs whose hyper-parameters are bit-identical then have identical Ky /
+        # Ky_inv and share one build (GaussianProcessRegression.update_many).  That only holds while ALL data went through
+        # this method: once a GP was fed on its own (its X_train is no longer the tensor left here), each is updated by itself.
+        uniform = getattr(self, "_uniform_ok", True)
+        if uniform:
+            seen = getattr(self, "_seen_X", None)       # the input tensors this method left in the GPs last time
+            if seen is None:
+                uniform = all(g.num_train == 0 for g in self.gpr_err)
+            else:
+                uniform = all(g.X_train is sx for g, sx in zip(self.gpr_err, seen))
+        self._uniform_ok = uniform                       # once a GP was fed on its own, never again
         if len(state.shape) == 1:
             x = np.concatenate((state, action))
-            for i in range(self.state_dim):
-                self.gpr_err[i].append_train_data(x, next_state[i], incremental=incremental)
+            ys = [next_state[i] for i in range(self.state_dim)]
         else:
             if len(action.shape) == 1:
                 action = action[:, None]
             x = np.concatenate((state, action), axis=1)
-            for i in range(self.state_dim):
-                self.gpr_err[i].append_train_data(x, next_state[:, i])
+            ys = [next_state[:, i] for i in range(self.state_dim)]
+            incremental = False
+        if not uniform:
+            for g, y in zip(self.gpr_err, ys):
+                g.append_train_data(x, y, incremental=incremental)
+        else:
+            modes = []
+            for g, y in zip(self.gpr_err, ys):
+                if not np.isscalar(y) and np.ndim(y) > 0:
+                    n_obs, yy = len(y), np.asarray(y)[:, None]
+                    xx = x
+                else:
+                    n_obs, yy = 1, np.array([y])[:, None]
+                    xx = np.reshape(x, (1, g.x_dim))
+                modes.append(g._ingest(xx, yy, n_obs, incremental))
+            GaussianProcessRegression.update_many(self.gpr_err, modes)
+        self._seen_X = [g.X_train for g in self.gpr_err]
 
     # -- device pack -----------------------------------------------------------------------
     def _key(self):

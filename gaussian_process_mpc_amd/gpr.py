@@ -91,6 +91,14 @@ class GaussianProcessRegression(object):
             y = np.array([y])[:, None]
         if num_obs == 1:
             x = np.reshape(x, (1, self.x_dim))
+        mode = self._ingest(x, y, num_obs, incremental)
+        if mode == "incremental":
+            self._append_one_incremental(self.X_train[-1:])
+        else:
+            self.build_Ky_inv_mat()
+
+    def _ingest(self, x, y, num_obs, incremental):
+        """Store the new rows (src/gpr.py:109-119) and say how the matrices have to follow: "incremental" or "full"."""
         x = torch.tensor(np.asarray(x), requires_grad=False).type(torch.float64).to(self.device)
         y = torch.tensor(y, requires_grad=False).type(torch.float64).to(self.device)
         if self.num_train == 0:
@@ -101,14 +109,19 @@ class GaussianProcessRegression(object):
         # The O(N^2) append is only valid on matrices built with the CURRENT hyper-parameters (the setters do not
         # rebuild, src/gpr.py:53; the reference's append always does, so an edit takes effect there), and its round-off
         # accumulates: fall back to the reference's full rebuild when the hypers changed and every `rebuild_every` appends.
-        if (incremental and num_obs == 1 and self.num_train > 0 and self.Ky_inv is not None
-                and self._built_hypers == self._current_hypers() and self._appends_since_rebuild < self.rebuild_every):
-            self._append_one_incremental(x)
-            self.num_train += 1
-            self._appends_since_rebuild += 1
-            return
+        inc = (incremental and num_obs == 1 and self.num_train > 0 and self.Ky_inv is not None
+               and self._built_hypers == self._current_hypers() and self._appends_since_rebuild < self.rebuild_every)
         self.num_train += num_obs
-        self.build_Ky_inv_mat()
+        return "incremental" if inc else "full"
+
+    def _adopt(self, other):
+        """Share the matrices of `other`, a GP with bit-identical training inputs and hyper-parameters (the tensors are
+        never modified in place: every update assigns new ones)."""
+        self.Kf, self.Ky, self.Ky_inv = other.Kf, other.Ky, other.Ky_inv
+        self._beta = None
+        self.version += 1
+        self._built_hypers = other._built_hypers
+        self._appends_since_rebuild = other._appends_since_rebuild
 
     def _current_hypers(self):
         return (tuple(float(v) for v in self.get_lambdas()), float(self.get_sigma_f()), self._noise_var())
@@ -128,8 +141,9 @@ class GaussianProcessRegression(object):
         return out.reshape(())
 
     def _append_one_incremental(self, x_new):
-        """self.X_train / y_train already hold the new row (last); Kf, Ky, Ky_inv still have the old size n."""
-        n = self.num_train
+        """self.X_train / y_train already hold the new row (last) and num_train counts it; Kf, Ky, Ky_inv still have the
+        old size n."""
+        n = self.num_train - 1
         X_old = self.X_train[:n].contiguous()
         sigma_f = self.get_sigma_f()
         noise = float((torch.exp(self._host("log_sigma_n")) ** 2 * torch.ones(1)).item())
@@ -153,30 +167,68 @@ class GaussianProcessRegression(object):
         self.Ky_inv = out
         self._beta = None
         self.version += 1
+        self._appends_since_rebuild += 1
 
     def build_Ky_inv_mat(self):
         """Kf, Ky, Ky_inv from scratch (src/gpr.py:159-171)."""
+        self._build_kf_ky()
+        self._finish_build(self._invert(self.Ky))
+
+    def _build_kf_ky(self):
         n = self.num_train
         X = self.X_train.contiguous()
-        lam, lp = host_doubles(self.get_lambdas())
-        sigma_f = self.get_sigma_f()
+        _, lp = host_doubles(self.get_lambdas())
         # src/gpr.py:170: sigma_n**2 (0-dim float64) * torch.eye (float32) is a float32 tensor
-        noise = float((torch.exp(self._host("log_sigma_n")) ** 2 * torch.ones(1)).item())
+        noise = self._noise_var()
         self.Kf = torch.empty((n, n), dtype=torch.float64, device=self.device)
         self.Ky = torch.empty((n, n), dtype=torch.float64, device=self.device)
         with torch.cuda.device(self.device):
-            check(lib().gpmpc_build_ky(n, self.x_dim, ptr(X), lp, sigma_f, noise, ptr(self.Kf), ptr(self.Ky),
+            check(lib().gpmpc_build_ky(n, self.x_dim, ptr(X), lp, self.get_sigma_f(), noise, ptr(self.Kf), ptr(self.Ky),
                                        stream_ptr()), "gpmpc_build_ky")
+
+    def _invert(self, Ky):
+        """Explicit inverse of one matrix or of a (k, n, n) stack (one batched factorisation)."""
         if self.inverse == "lu":
-            self.Ky_inv = torch.linalg.inv(self.Ky)
-        elif self.inverse == "cholesky":
-            self.Ky_inv = torch.cholesky_inverse(torch.linalg.cholesky(self.Ky))
-        else:
-            raise ValueError("GaussianProcessRegression.inverse must be 'lu' or 'cholesky', got %r" % (self.inverse,))
+            return torch.linalg.inv(Ky)
+        if self.inverse == "cholesky":
+            return torch.cholesky_inverse(torch.linalg.cholesky(Ky))
+        raise ValueError("GaussianProcessRegression.inverse must be 'lu' or 'cholesky', got %r" % (self.inverse,))
+
+    def _finish_build(self, Ky_inv):
+        self.Ky_inv = Ky_inv
         self._beta = None
         self.version += 1
-        self._built_hypers = (tuple(float(v) for v in lam), float(sigma_f), noise)
+        self._built_hypers = self._current_hypers()
         self._appends_since_rebuild = 0
+
+    @staticmethod
+    def update_many(gps, modes):
+        """Bring the matrices of several GPs that were fed the SAME inputs (Dynamics.append_train_data) up to date:
+        GPs with bit-identical hyper-parameters share ONE set of matrices (every experiment of the reference sets the
+        same lambda / sigma_f / sigma_n on all GPs: ds identical O(N^3) inversions per Simulator step there,
+        src/simulator.py:55, src/gpr.py:171), and the distinct ones that need a full rebuild are inverted as one batched
+        factorisation of the (k, n, n) stack instead of k in a Python loop."""
+        leaders = {}
+        for g, mode in zip(gps, modes):
+            leaders.setdefault((g._current_hypers(), g.inverse, mode, g.num_train), []).append(g)
+        full = [grp[0] for (_, _, mode, _), grp in leaders.items() if mode == "full"]
+        for (_, _, mode, _), grp in leaders.items():
+            if mode == "incremental":
+                grp[0]._append_one_incremental(grp[0].X_train[-1:])
+        by_kind = {}
+        for g in full:
+            g._build_kf_ky()
+            by_kind.setdefault((g.inverse, g.num_train), []).append(g)
+        for grp in by_kind.values():
+            if len(grp) == 1:
+                grp[0]._finish_build(grp[0]._invert(grp[0].Ky))
+            else:
+                inv = grp[0]._invert(torch.stack([g.Ky for g in grp]))
+                for k, g in enumerate(grp):
+                    g._finish_build(inv[k])
+        for grp in leaders.values():
+            for g in grp[1:]:
+                g._adopt(grp[0])
 
     # -- prediction
     def _targets(self):

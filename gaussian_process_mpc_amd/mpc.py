@@ -141,9 +141,11 @@ class RiskSensitiveMPC:
             else:
                 # B = 1 is pure latency: upload, the H + 1 kernels and the download are ONE captured hipGraph owned by the
                 # pack (C ABI gpmpc_objective_gradient) -- one launch and one wait per callback pair
-                if held[0] is not cs or getattr(self, "_cs_host_version", None) != cs._version:
+                # host copy of the state, keyed on ITS OWN source tensor + version (the full-covariance branch also
+                # refreshes _cache_held, so that cannot vouch for this copy)
+                if getattr(self, "_cs_host_src", None) is not cs or getattr(self, "_cs_host_version", None) != cs._version:
                     self._cs_host = cs.detach().cpu().numpy().astype(np.float64).reshape(-1)
-                    self._cs_host_version = cs._version
+                    self._cs_host_src, self._cs_host_version = cs, cs._version
                 cg = pack.objective_gradient(self._cs_host, x.reshape(self.horizon, self.input_dim), cp)
                 self.curr_cost = float(cg[0])
                 self.curr_grad = cg[1:].reshape(self.horizon, self.input_dim).copy()

@@ -141,8 +141,13 @@ class GPPack:
         key = torch.cuda.current_stream(self.device).cuda_stream
         ws = self._ws.get(key)
         if ws is None or ws.numel() < nbytes:
+            if ws is None and len(self._ws) >= 8:            # bounded: drop the workspace of the longest-unused stream
+                torch.cuda.synchronize(self.device)
+                self._ws.pop(next(iter(self._ws)))
             ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
-            self._ws[key] = ws
+        else:
+            self._ws.pop(key)
+        self._ws[key] = ws                                   # most recently used last
         return ws
 
     def beta(self):

@@ -246,7 +246,8 @@ int gpmpc_objective_gradient(gpmpc_pack* pack, int H, const double* x0_host, con
 int gpmpc_timing_enable(int on);
 int gpmpc_pair_kernel_time(double* total_ms, long long* launches, int reset);
 /* The same totals per kernel class: 0 = the full pair kernel, 1 = its horizon-step-1 variant (constant state inputs:
- * fewer moments, cheaper), so that a roofline figure can be quoted for the dominant kernel alone.  Reset with
+ * fewer moments, cheaper), 2 = the fused small-batch step kernel (one launch per horizon step: mean sums, finish work and
+ * pair tiles together -- NOT a pair-only time), so that a roofline figure can be quoted for the dominant kernel alone.  Reset with
  * gpmpc_pair_kernel_time(..., 1). */
 int gpmpc_pair_kernel_time_class(int kernel_class, double* total_ms, long long* launches);
 

@@ -23,15 +23,25 @@ def main():
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    from datetime import timedelta
+    backend = os.environ.get("GPMPC_TEST_BACKEND", "gloo")        # "nccl" (= RCCL): one rank per GPU
+    dev_index = rank if backend == "nccl" else 0
+    torch.cuda.set_device(dev_index)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index),
+                                timeout=timedelta(seconds=120))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(seconds=120))
     pb = synth_problem(23, 140, 3, 1, 5, 8)
     # the inverse comes from rank 0 only (replicas are built from the same bits)
     if rank == 0:
         kinv = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"]).Ky_inv.clone()
     else:
         kinv = torch.zeros((3, 140, 140), dtype=torch.float64)
+    if backend == "nccl":                                         # RCCL moves device tensors
+        kinv = kinv.cuda()
     broadcast_kinv(kinv, dist, src=0)
+    kinv = kinv.cpu()
     pack = g.GPPack(pb["X"], pb["Y"], kinv.numpy(), pb["lambdas"], pb["sigma_f"])
     cost = g.CostParams(-1.0, pb["Q"], pb["R"])
     fn = lambda x0b, Ub: g.rollout(pack, x0b, Ub, cost, want_traj=False)      # noqa: E731

@@ -24,6 +24,11 @@ Fixtures:
                        environments (cart-pole stepPhysics, pendulum step / step_static) on seeded inputs, and the data
                        file triple of the README experiment (src/experiments/data/*.npy, stored as arrays)
 
+  g10_readme_regime.npz  the reference's own regime: README experiment data, lambda = 0.5 for every GP, H = 6,
+                       sigma_n in {1e-3, 1e-5}: means / variances / cost / gradient of four candidate plans
+  g11_fullsize_pin.npz reference-produced mean / variance of every GP at N = 2048 (C3 training set re-derived from the
+                       seed) for two single-step queries
+
 g9 imports src/environments/*, which need ``gym`` (absent here).  A minimal stand-in module (``gym.Env`` as a bare base
 class, ``spaces.Box`` recording its arguments, ``seeding.np_random``, ``error.DependencyNotInstalled``) is registered
 for that import only; none of the arithmetic captured below goes through it.
@@ -398,10 +403,90 @@ def g9():
     np.savez(os.path.join(OUT, "g9_closed_loop.npz"), **out)
 
 
+def g10():
+    """The reference's OWN regime (src/experiments/pretrain_uncertainty.py:86-121): its data files, one lambda = 0.5 for
+    every GP, sigma_f = 1, Q = 2 I, R = 0, H = 6, curr_state = [4, -4], gamma in {-1, 1e-5}, at the experiment's
+    sigma_n = 1e-5 and at 1e-3.  Every GP has the same hyper-parameters and the same X, so Ky_inv is ONE matrix per
+    sigma_n (stored once).  Candidates: the zero plan, a plan along the data corridor, and seeded plans in the action box."""
+    data = {k: np.load(os.path.join(REF, "src", "experiments", "data", k + ".npy")) for k in ("states", "actions", "next_states")}
+    ds = da = 2
+    H = 6
+    Q, R = 2 * np.identity(2), np.zeros((2, 2))
+    rng = np.random.default_rng(1010)
+    U = np.stack([np.zeros((H, da)),
+                  np.array([[0.0, 1.0]] * 4 + [[-1.0, 0.0]] * 2),               # up the corridor, then left
+                  rng.uniform(-1, 1, (H, da)), 0.5 * rng.uniform(-1, 1, (H, da))])
+    x0 = np.array([4.0, -4.0])
+    gammas = [-1.0, 1e-5]
+    out = {"X": np.concatenate((data["states"], data["actions"]), axis=1), "Y": data["next_states"], "x0": x0, "U": U,
+           "Q": Q, "R": R, "gammas": np.array(gammas), "lambdas": np.full((ds, ds + da), 0.5), "sigma_f": np.ones(ds),
+           "dims": np.array([data["states"].shape[0], ds, da, H]), "sigma_ns": np.array([1e-3, 1e-5])}
+    for si, sn in enumerate(out["sigma_ns"]):
+        mpc = RiskSensitiveMPC(gammas[0], H, ds, da, Q, R, None)
+        for a in range(ds):
+            g = mpc.dynamics.gpr_err[a]
+            g.set_sigma_n(float(sn)); g.set_lambdas([0.5, 0.5, 0.5, 0.5]); g.set_sigma_f(1.)
+        mpc.dynamics.append_train_data(data["states"], data["actions"], data["next_states"])
+        mpc.set_xref(np.array([0., 0.])); mpc.set_uref(np.array([0., 0.]))
+        k0 = mpc.dynamics.gpr_err[0].Ky_inv.detach().numpy()
+        assert np.array_equal(k0, mpc.dynamics.gpr_err[1].Ky_inv.detach().numpy())
+        # what the rollout reads (src/dynamics.py:170): exp of the float32 log the setter stored (src/gpr.py:51-60) -- NOT 0.5
+        out["lambdas"] = np.stack([torch.exp(g.log_lambdas).detach().numpy() for g in mpc.dynamics.gpr_err])
+        out["lambdas_set"] = np.full((ds, ds + da), 0.5)
+        out[f"s{si}_Ky_inv"] = k0
+        nb = U.shape[0]
+        means = np.zeros((nb, H + 1, ds)); vars_ = np.zeros((nb, H + 1, ds))
+        costs = np.zeros((len(gammas), nb)); grads = np.zeros((len(gammas), nb, H, da))
+        mpc.curr_state = torch.tensor(x0).type(torch.float64)
+        for b in range(nb):
+            for gi, gm in enumerate(gammas):
+                mpc.gamma = gm
+                mpc.curr_cost = None
+                costs[gi, b] = mpc.objective(U[b].reshape(-1).copy())
+                grads[gi, b] = np.asarray(mpc.gradient(U[b].reshape(-1).copy())).reshape(H, da)
+            sm, sc = mpc.dynamics.forward_propagate_torch(H, mpc.curr_state, torch.tensor(U[b]).type(torch.float64))
+            means[b] = torch.stack(sm).detach().numpy()
+            vars_[b] = torch.stack([torch.diag(s) for s in sc]).detach().numpy()
+        out.update({f"s{si}_means": means, f"s{si}_vars": vars_, f"s{si}_costs": costs, f"s{si}_grads": grads})
+    np.savez(os.path.join(OUT, "g10_readme_regime.npz"), **out)
+
+
+def g11():
+    """Reference-produced scalars at FULL size (N = 2048, the C3 training set of gaussian_process_mpc_amd/synth.py, seed
+    1003): mean_prop_torch + variance_prop_torch (N^3 trace and all) of every GP for the first-step input of trajectory 0
+    and for a later-step-like input with distinct state variances.  Inputs are re-derived from the seed by the tests; only
+    the queries and the reference's outputs are stored (Ky_inv would be 4 x 33.5 MB)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from gaussian_process_mpc_amd.synth import synth_problem
+    N, ds, da = 2048, 4, 1
+    pb = synth_problem(3, N, ds, da, 20, 8)
+    gps = []
+    for a in range(ds):
+        g = GaussianProcessRegression(ds + da)
+        g.set_lambdas(pb["lambdas"][a]); g.set_sigma_f(1.0); g.set_sigma_n(float(pb["sigma_n"][a]))
+        g.append_train_data(pb["X"], pb["Y"][:, a])
+        gps.append(g)
+    act_var = float(np.float32(1e-3))
+    queries = [(np.concatenate((pb["x0"][0], pb["U"][0, 0])), np.diag([1e-3] * ds + [act_var])),
+               (np.concatenate((0.7 * pb["x0"][1], pb["U"][1, 3])), np.diag([2.3e-3, 4.1e-3, 1.7e-3, 3.2e-3, act_var]))]
+    out = {"u": np.stack([q[0] for q in queries]), "S": np.stack([q[1] for q in queries]),
+           "mean": np.zeros((2, ds)), "var": np.zeros((2, ds)), "beta_sum": np.zeros(ds), "beta_abs_sum": np.zeros(ds),
+           "dims": np.array([N, ds, da]), "seed": np.array([3])}
+    for qi, (u, S) in enumerate(queries):
+        for a, g in enumerate(gps):
+            m, aux = mean_prop_torch(g.Ky_inv.detach(), torch.exp(g.log_lambdas).detach(), T(u), T(S), g.X_train, g.y_train.squeeze(),
+                                     sigma_f=g.get_sigma_f())
+            v = variance_prop_torch(g.Ky_inv.detach(), torch.exp(g.log_lambdas).detach(), T(u), T(S), g.X_train, m,
+                                    aux["beta"], sigma_f=g.get_sigma_f())
+            out["mean"][qi, a], out["var"][qi, a] = float(m), float(v)
+            out["beta_sum"][a], out["beta_abs_sum"][a] = float(aux["beta"].sum()), float(aux["beta"].abs().sum())
+    np.savez(os.path.join(OUT, "g11_fullsize_pin.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11):
         if only and fn.__name__ not in only:
             continue
         fn()

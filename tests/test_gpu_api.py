@@ -163,6 +163,24 @@ def test_dynamics_and_mpc_callbacks(G, golden, name):
     assert mpc.constraints(x) == 0 and np.all(mpc.jacobian(x) == 0) and mpc.jacobian(x).shape == x.shape
 
 
+def test_state_host_copy_survives_a_full_covariance_detour(G, golden):
+    """The host copy of curr_state behind the B = 1 callback entry is keyed on its own source tensor: toggling
+    full_covariance after curr_state was REPLACED by a new tensor of the same version must not upload the old state."""
+    z = golden("g3_rollout_c1.npz")
+    mpc = _mpc_from(G, z, -1.0)
+    x = z["U"][0].reshape(-1).copy()
+    mpc.curr_state = torch.tensor(z["x0"][0]).to(mpc.device)
+    c_a = mpc.objective(x)
+    mpc.full_covariance = True
+    mpc.curr_state = torch.tensor(z["x0"][1]).to(mpc.device)            # new tensor, _version 0 like the old one
+    mpc.objective(x)                                                     # full-covariance branch refreshes _cache_held only
+    mpc.full_covariance = False
+    c_b = mpc.objective(x)
+    fresh = _mpc_from(G, z, -1.0)
+    fresh.curr_state = torch.tensor(z["x0"][1]).to(fresh.device)
+    assert c_b == pytest.approx(fresh.objective(x), rel=1e-12) and c_b != c_a
+
+
 def test_objective_cache_semantics(G, golden):
     z = golden("g3_rollout_c1.npz")
     mpc = _mpc_from(G, z, -1.0)
@@ -500,3 +518,64 @@ def test_ml_grad_abi_errors(G):
     torch.cuda.synchronize()
     # alpha = 0, Ky_inv = I, X = 0: B = -I, Kf = sigma_f^2 -> d/dlog sigma_f = -n, d/dlog sigma_n = -n * noise, lambda terms 0
     np.testing.assert_allclose(out.cpu().numpy(), [0.0, 0.0, -n, -n * 0.01, 0.0], atol=1e-12)
+
+
+@pytest.mark.parametrize("si", [0, 1])
+def test_g10_readme_regime_through_the_library_and_the_classes(G, golden, si):
+    """The reference's own regime (README experiment data, lambda = 0.5 for every GP, H = 6; sigma_n = 1e-3 / the
+    experiments' 1e-5), reference-produced means / variances / cost / gradient of four candidate plans:
+    (i) gpmpc_rollout on the fixture's Ky_inv -- the shared-lambda pack is detected; per quantity the HIP path meets
+        means 1e-7, variances 1e-6, cost 1e-7, gradient 1e-5 (north star: 1e-5 / 1e-4) at BOTH noise levels: this regime is
+        benign (variances 0.02-0.06 against sigma_f^2 = 1), unlike the dense synthetic sets of the accuracy sweep;
+    (ii) the mirror classes with the experiment's setter calls (src/experiments/pretrain_uncertainty.py:100-105), Ky_inv
+        rebuilt on the device: the float32 log of the setters is reproduced (effective lambda != 0.5) and the callbacks agree
+        with the reference to the north-star tolerances; the NaN candidate (log det <= 0) passes through as NaN."""
+    z = golden("g10_readme_regime.npz")
+    N, ds, da, H = (int(v) for v in z["dims"])
+    sn = float(z["sigma_ns"][si])
+    kinv = np.stack([z[f"s{si}_Ky_inv"]] * ds)
+    pack = G.GPPack(z["X"], z["Y"], kinv, z["lambdas"], z["sigma_f"])
+    assert pack.shared_lambda
+    nb = z["U"].shape[0]
+    for gi, gamma in enumerate(z["gammas"]):
+        cost = G.CostParams(float(gamma), z["Q"], z["R"])
+        for r in (G.rollout(pack, np.tile(z["x0"], (nb, 1)), z["U"], cost),):
+            np.testing.assert_allclose(r["means"].cpu().numpy(), z[f"s{si}_means"], rtol=1e-7, atol=1e-10)
+            np.testing.assert_allclose(r["vars"].cpu().numpy(), z[f"s{si}_vars"], rtol=1e-6)
+            np.testing.assert_allclose(r["cost"].cpu().numpy(), z[f"s{si}_costs"][gi], rtol=1e-7, equal_nan=True)
+            fin = np.isfinite(z[f"s{si}_costs"][gi])
+            np.testing.assert_allclose(r["grad"].cpu().numpy()[fin], z[f"s{si}_grads"][gi][fin], rtol=1e-5, atol=1e-8)
+            assert np.isnan(r["cost"].cpu().numpy()[~fin]).all()
+    # a large batch of the same candidates takes the shared-lambda pair kernel: same values
+    reps = 600
+    big = G.rollout(pack, np.tile(z["x0"], (nb * reps, 1)), np.tile(z["U"], (reps, 1, 1)), G.CostParams(1e-5, z["Q"], z["R"]))
+    np.testing.assert_allclose(big["vars"][-nb:].cpu().numpy(), z[f"s{si}_vars"], rtol=1e-6)
+    np.testing.assert_allclose(big["grad"][-nb:].cpu().numpy(), z[f"s{si}_grads"][1], rtol=1e-5, atol=1e-8)
+    # (ii) the classes, as the experiment drives them
+    mpc = G.RiskSensitiveMPC(-1.0, H, ds, da, z["Q"], z["R"], None)
+    for i in range(ds):
+        mpc.dynamics.gpr_err[i].set_sigma_n(sn)
+        mpc.dynamics.gpr_err[i].set_lambdas([0.5, 0.5, 0.5, 0.5])
+        mpc.dynamics.gpr_err[i].set_sigma_f(1.)
+    mpc.dynamics.append_train_data(z["X"][:, :ds], z["X"][:, ds:], z["Y"])
+    mpc.set_xref(np.array([0., 0.])); mpc.set_uref(np.array([0., 0.]))
+    np.testing.assert_array_equal(np.stack([g.get_lambdas() for g in mpc.dynamics.gpr_err]), z["lambdas"])
+    assert mpc.dynamics.pack().shared_lambda
+    mpc.curr_state = torch.tensor(z["x0"], device=mpc.device).type(torch.float64)
+    # the inverse is rebuilt here (rocSOLVER LU instead of the reference's CPU LAPACK LU): cond(Ky) ~ 1 / sigma_n^2
+    vtol, gtol = (1e-6, 1e-5) if sn >= 1e-3 else (1e-4, 1e-3)
+    for b in range(nb):
+        means, covs = mpc.dynamics.forward_propagate_torch(H, mpc.curr_state, torch.tensor(z["U"][b]))
+        np.testing.assert_allclose(torch.stack(means).cpu().numpy(), z[f"s{si}_means"][b], rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(torch.stack([torch.diag(c) for c in covs]).cpu().numpy(), z[f"s{si}_vars"][b], rtol=vtol)
+        for gi, gamma in enumerate(z["gammas"]):
+            mpc.gamma = float(gamma)
+            mpc._cache_key = None
+            c = mpc.objective(z["U"][b].reshape(-1).copy())
+            g = mpc.gradient(z["U"][b].reshape(-1).copy())
+            want = z[f"s{si}_costs"][gi, b]
+            if np.isnan(want):
+                assert np.isnan(c)
+            else:
+                np.testing.assert_allclose(c, want, rtol=max(1e-6, 10 * vtol))
+                np.testing.assert_allclose(g, z[f"s{si}_grads"][gi, b], rtol=max(1e-4, 10 * gtol), atol=1e-7)

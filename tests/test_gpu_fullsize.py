@@ -288,3 +288,14 @@ def test_small_configs_exact_workload_against_cport(G, cid):
         np.testing.assert_allclose(r["grad"].cpu().numpy(), c["grad"], rtol=1e-4, atol=1e-7)
     cg = pack.objective_gradient(pb["x0"][0], pb["U"][0], cost)
     assert cg[0] == r["cost"][0].item() and np.array_equal(cg[1:], r["grad"][0].cpu().numpy().reshape(-1))
+
+
+def test_g11_reference_scalars_at_n2048(G, c3, golden):
+    """One hop from the reference at full size: gpmpc_moment_match on the C3 pack against mean / variance values the
+    REFERENCE produced at N = 2048 (tests/golden/g11_fullsize_pin.npz; inputs re-derived from the seed, inverse rebuilt
+    on the CPU as src/gpr.py:171)."""
+    pb, gp, pack = c3
+    z = golden("g11_fullsize_pin.npz")
+    r = G.moment_match(pack, z["u"], z["S"])
+    np.testing.assert_allclose(r["mean"].cpu().numpy(), z["mean"], rtol=1e-7)          # north star 1e-5
+    np.testing.assert_allclose(r["var"].cpu().numpy(), z["var"], rtol=1e-5)            # north star 1e-4

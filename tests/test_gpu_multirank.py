@@ -56,3 +56,34 @@ def test_rccl_backend_code_path_world1():
     r = subprocess.run([sys.executable, os.path.join(HERE, "_nccl_world1_worker.py"), str(port)], env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and "rccl world-1 ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_two_rccl_ranks_through_sharded_rollout(tmp_path):
+    """Two RCCL ("nccl") ranks, one per GPU, through parallel.sharded_rollout: the gathered [cost | grad] equals the
+    single-process batch bit for bit.  Needs two visible GPUs: SKIPPED on the one-GPU test box, runs on a multi-GPU node."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL with two ranks cannot run on one card)")
+    import gaussian_process_mpc_amd as g
+    from gaussian_process_mpc_amd.synth import synth_problem
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "rank0.npz")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), GPMPC_TEST_BACKEND="nccl")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_multirank_worker.py"), str(r), "2", str(port), out], env=env)
+             for r in range(2)]
+    try:
+        codes = [p.wait(timeout=600) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert codes == [0, 0]
+    z = np.load(out)
+    pb = synth_problem(23, 140, 3, 1, 5, 8)
+    pack = g.GPPack(pb["X"], pb["Y"], z["kinv"], pb["lambdas"], pb["sigma_f"])
+    cost = g.CostParams(-1.0, pb["Q"], pb["R"])
+    for tag, B in (("even", 8), ("ragged", 7), ("fewer_than_ranks", 1)):
+        r = g.rollout(pack, pb["x0"][:B], pb["U"][:B], cost, want_traj=False)
+        assert np.array_equal(z[tag + "_cost"], r["cost"].cpu().numpy()), tag
+        assert np.array_equal(z[tag + "_grad"], r["grad"].cpu().numpy()), tag

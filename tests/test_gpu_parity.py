@@ -517,6 +517,33 @@ def test_objective_gradient_callback_entry(G, golden):
     np.testing.assert_allclose(only[0], G.rollout(pack, z["x0"][1], z["U"][1], cost, want_grad=False)["cost"][0].item(), rtol=1e-12)
 
 
+def test_callback_entry_with_timing_enabled_falls_back_to_uncaptured_launches(G, golden):
+    """gpmpc_timing_enable(1) and the solver callback together: per-kernel events cannot be recorded inside a captured
+    graph, so the entry enqueues the same work uncaptured -- same bits, no error -- and the fused step kernel's launches are
+    accounted under their own timing class (2), not as pair-kernel time."""
+    import ctypes
+    from gaussian_process_mpc_amd._lib import lib
+    z = golden("g4_rollout_c2.npz")
+    pack = _pack_from(G, z)
+    cost = _cost_from(G, z, -1.0)
+    H = z["U"].shape[1]
+    ref = pack.objective_gradient(z["x0"][0], z["U"][0], cost)
+    ms, nl = ctypes.c_double(), ctypes.c_longlong()
+    lib().gpmpc_timing_enable(1)
+    try:
+        lib().gpmpc_pair_kernel_time(ctypes.byref(ms), ctypes.byref(nl), 1)
+        got = pack.objective_gradient(z["x0"][0], z["U"][0], cost)
+        assert np.array_equal(got, ref)
+        lib().gpmpc_pair_kernel_time_class(2, ctypes.byref(ms), ctypes.byref(nl))
+        assert nl.value == H and ms.value > 0.0                      # one fused launch per horizon step
+        lib().gpmpc_pair_kernel_time_class(0, ctypes.byref(ms), ctypes.byref(nl))
+        assert nl.value == 0
+    finally:
+        lib().gpmpc_timing_enable(0)
+        lib().gpmpc_pair_kernel_time(ctypes.byref(ms), ctypes.byref(nl), 1)
+    assert np.array_equal(pack.objective_gradient(z["x0"][0], z["U"][0], cost), ref)      # and captured again afterwards
+
+
 def test_scalar_broadcast_kernels_match_staged(G, golden, monkeypatch):
     """The scalar-broadcast pair kernels (pair_kernel_sb.h / pair_kernel_sbf.h: expanded exponent, row-grouped moments)
     take over once the grid fills the chip; force both forms on the same large batch and compare them with each other

@@ -228,6 +228,26 @@ def test_bench_refuses_to_mislabel_the_rank_count():
     assert r.returncode != 0 and '"n_gpus"' not in r.stdout
 
 
+def test_bench_launcher_notices_a_dead_rank_within_seconds():
+    """bench.py's launcher polls every child: when rank 1 dies while rank 0 would sit in a collective for minutes, the job
+    ends non-zero in well under 30 s (it used to block on rank 0's stdout until the process-group timeout)."""
+    import time
+    import types
+    sys.path.insert(0, ROOT)
+    import bench
+    worker = ("import os, sys, time\n"
+              "r = int(os.environ['RANK'])\n"
+              "assert os.environ['WORLD_SIZE'] == '3' and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+              "if r == 1:\n    time.sleep(1.0); sys.exit(7)\n"
+              "print('{\"rank\": %d}' % r, flush=True)\n"
+              "time.sleep(600)\n")
+    t0 = time.time()
+    rc = bench.spawn_ranks(types.SimpleNamespace(gpus=3, oversubscribe=True), argv=[sys.executable, "-c", worker])
+    assert rc == 7 and time.time() - t0 < 30.0
+    ok = "import os\nprint('{\"n\": %s}' % os.environ['RANK'], flush=True)\n"
+    assert bench.spawn_ranks(types.SimpleNamespace(gpus=2, oversubscribe=True), argv=[sys.executable, "-c", ok]) == 0
+
+
 def test_plants_match_the_reference_environments(golden):
     """the plant updates either side of the path, as plain classes, against the reference's own
     environment classes run by tests/golden/gen_golden.py (g9): cart-pole stepPhysics / step

@@ -312,3 +312,64 @@ def test_g8_update_hyperparams(golden, tag, x_dim, nominal):
         np.testing.assert_allclose(h["log_lambdas"], d[tag + "_log_lambdas"][k], rtol=1e-8, atol=1e-10)
         assert h["log_sigma_f"] == pytest.approx(d[tag + "_log_sigma_f"][k], rel=1e-8, abs=1e-10)
         assert h["log_sigma_n"] == pytest.approx(d[tag + "_log_sigma_n"][k], rel=1e-8, abs=1e-10)
+
+
+def test_g10_readme_regime(golden):
+    """The reference's OWN regime (README experiment data, one lambda for every GP, sigma_n = 1e-3 and the experiments'
+    1e-5): oracle (both modes) and C port against the reference's rollout / cost / gradient, NaN candidate included
+    (gamma = -1 with Q = 2 I: a plan that leaves the data has log det <= 0; passed through, src/mpc.py:183).
+    The fixture's lambdas are what the rollout READS (exp of the float32 log the setter stores, src/gpr.py:51-60), not 0.5."""
+    from oracle import cport
+    z = golden("g10_readme_regime.npz")
+    N, ds, da, H = (int(v) for v in z["dims"])
+    assert np.all(z["lambdas_set"] == 0.5) and np.all(z["lambdas"] != 0.5) and np.allclose(z["lambdas"], 0.5, rtol=1e-7)
+    for si, sn in enumerate(z["sigma_ns"]):
+        kinv = np.stack([z[f"s{si}_Ky_inv"]] * ds)
+        gp = O.GPBundle(z["X"], z["Y"], z["lambdas"], z["sigma_f"], np.full(ds, sn), Ky_inv=kinv)
+        for mode in ("faithful", "o2"):
+            for gi, gamma in enumerate(z["gammas"]):
+                for b in range(z["U"].shape[0]):
+                    r = O.objective_and_gradient(gp, H, z["x0"], z["U"][b], np.zeros(ds), np.zeros(da), z["Q"], z["R"],
+                                                 float(gamma), None, None, mode)
+                    np.testing.assert_allclose(r["means"], z[f"s{si}_means"][b], rtol=1e-8, atol=1e-11)
+                    np.testing.assert_allclose(r["vars"], z[f"s{si}_vars"][b], rtol=1e-7)
+                    np.testing.assert_allclose(r["cost"], z[f"s{si}_costs"][gi, b], rtol=1e-8, equal_nan=True)
+                    np.testing.assert_allclose(r["grad"], z[f"s{si}_grads"][gi, b], rtol=1e-6, atol=1e-9, equal_nan=True)
+        pb = {"X": z["X"], "Y": z["Y"], "lambdas": z["lambdas"], "sigma_f": z["sigma_f"], "ds": ds, "da": da, "Q": z["Q"],
+              "R": z["R"], "x_ref": np.zeros(ds), "u_ref": np.zeros(da), "x0": np.tile(z["x0"], (z["U"].shape[0], 1)), "U": z["U"]}
+        for gi, gamma in enumerate(z["gammas"]):
+            c = cport.rollout(pb, kinv, float(gamma), nthreads=4)
+            np.testing.assert_allclose(c["means"], z[f"s{si}_means"], rtol=1e-8, atol=1e-11)
+            np.testing.assert_allclose(c["vars"], z[f"s{si}_vars"], rtol=1e-7)
+            np.testing.assert_allclose(c["cost"], z[f"s{si}_costs"][gi], rtol=1e-8, equal_nan=True)
+            fin = np.isfinite(z[f"s{si}_costs"][gi])
+            np.testing.assert_allclose(c["grad"][fin], z[f"s{si}_grads"][gi][fin], rtol=1e-6, atol=1e-9)
+        # this regime is benign: the reference's fp64 variances sit within 1e-7 of the extended-precision evaluation at both
+        # noise levels (predictive variances of 0.02-0.06 against sigma_f^2 = 1: mild cancellation)
+        e = cport.rollout_extended(pb, kinv, nthreads=4)
+        np.testing.assert_allclose(z[f"s{si}_vars"], e["vars"], rtol=1e-7)
+
+
+def test_g11_reference_scalars_at_full_size(golden):
+    """One hop from the reference at N = 2048: mean / variance of every GP for two single-step queries, produced by the
+    reference itself on the C3 training set (re-derived here from the seed; the inverse is rebuilt on the CPU as the
+    reference does, src/gpr.py:171) -- against the oracle's O(N^2) mode for all of them and its faithful mode (N^3 trace)
+    for one."""
+    from gaussian_process_mpc_amd.synth import synth_problem
+    z = golden("g11_fullsize_pin.npz")
+    N, ds, da = (int(v) for v in z["dims"])
+    pb = synth_problem(int(z["seed"][0]), N, ds, da, 20, 8)
+    torch.set_num_threads(8)
+    gp = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"])
+    T = lambda a: torch.as_tensor(a, dtype=torch.float64)     # noqa: E731
+    for q in range(2):
+        for a in range(ds):
+            m, beta, _ = O.mean_prop(gp.Ky_inv[a], gp.lambdas[a], T(z["u"][q]), T(z["S"][q]), gp.X, gp.Y[:, a])
+            if q == 0:
+                # the reference's setters store float32 logs (src/gpr.py:51-88): its effective lambda / sigma_n differ from the
+                # set values by ~6e-8 relative, which is what is left here
+                np.testing.assert_allclose(float(beta.abs().sum()), z["beta_abs_sum"][a], rtol=1e-6)
+            v = O.variance_prop(gp.Ky_inv[a], gp.lambdas[a], T(z["u"][q]), T(z["S"][q]), gp.X, m, beta,
+                                mode="faithful" if (q, a) == (1, 2) else "o2")
+            np.testing.assert_allclose(m.item(), z["mean"][q, a], rtol=1e-7)
+            np.testing.assert_allclose(v.item(), z["var"][q, a], rtol=1e-5)
