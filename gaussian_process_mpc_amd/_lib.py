@@ -10,7 +10,8 @@ import os
 import torch  # noqa: F401  (loads the HIP runtime the library binds to)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgpmpc_hip.so")
+# GPMPC_LIB_PATH: another build of the SAME library (diagnostic builds with in-kernel stamps, A/B runs); never a fallback
+LIB_PATH = os.environ.get("GPMPC_LIB_PATH") or os.path.join(_HERE, "csrc", "libgpmpc_hip.so")
 
 MAX_D = 8
 MAX_DS = 8

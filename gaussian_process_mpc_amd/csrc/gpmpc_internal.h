@@ -42,6 +42,8 @@ struct gpmpc_tuning {
     int no_xcd_sort; // GPMPC_NO_XCD_SORT natural tile order of the 256x256 work list (takes effect at pack creation only)
     int hchunks;     // GPMPC_HEAD_CHUNKS row chunks of the head kernel: 0 / 1 none | 2..16 | -1 unset (chosen per call)
     int sbf_min;     // GPMPC_SBF_MIN     workgroups from which the full-S path uses 256x256 tiles + pair_kernel_sbf.h | 0 unset
+    int colunroll;   // GPMPC_SB_UNROLL   1 | 4 columns per iteration of the scalar-broadcast kernel on the 256x64 tiling | -1 unset (4)
+    int split;       // GPMPC_SPLIT       sub-batches (parallel graph branches) of a graph-replayed rollout: 1 none | 2..4 | -1 unset (2 for mid-size batches)
     int shared;      // GPMPC_SHARED      0: never use the shared-lambda kernel (pair_kernel_sbs.h) | -1 unset (used when lambdas are shared)
 };
 void gpmpc_read_tuning(gpmpc_tuning* t);
@@ -49,6 +51,7 @@ void gpmpc_read_tuning(gpmpc_tuning* t);
 struct gpmpc_pack {
     int N, Np, ds, da, D;
     int device;     // HIP device ordinal the pack's memory lives on (hipGetDevice at creation)
+    int num_cu;     // compute units of that device
     gpmpc_tuning tune;
     int built;
     int npairs;     // ds (ds - 1) / 2 cross-covariance units (a < b, lexicographic)
@@ -105,6 +108,7 @@ struct PairSbArgs {
     int Np, B, ds, nwork, pps, nm;
     int rgroup;           // work items interleaved per trajectory in dispatch order (1 = item-major), see pair_kernel_sb.h
     int first_step;       // horizon step 1: derivatives w.r.t. the (constant) state inputs are not needed
+    int colunroll;        // 4: four columns per loop iteration (the 256x64 tiling of mid-size batches, TB = 1); else one
 };
 static inline int gpmpc_sb_gw(int D, int ns2) { return (D + 1 + ns2 + 1) & ~1; }
 int gpmpc_launch_pair_sb(int D, bool grad, int tb, int ns2, int waves, const PairSbArgs& a, hipStream_t s);

@@ -190,6 +190,8 @@ void gpmpc_read_tuning(gpmpc_tuning* t) {
     t->hchunks = geti("GPMPC_HEAD_CHUNKS", -1);
     t->sbf_min = geti("GPMPC_SBF_MIN", 0);
     t->shared = geti("GPMPC_SHARED", -1);
+    t->colunroll = geti("GPMPC_SB_UNROLL", -1);
+    t->split = geti("GPMPC_SPLIT", -1);
 }
 
 extern "C" int gpmpc_pack_reload_tuning(gpmpc_pack* p) {
@@ -212,6 +214,7 @@ extern "C" int gpmpc_pack_create(gpmpc_pack** out, int n_train, int state_dim, i
     p->N = n_train; p->Np = ((n_train + 63) / 64) * 64; p->ds = state_dim; p->da = action_dim; p->D = D;
     gpmpc_read_tuning(&p->tune);
     if (hipGetDevice(&p->device) != hipSuccess) { free(p); return GPMPC_E_LAUNCH; }
+    if (hipDeviceGetAttribute(&p->num_cu, hipDeviceAttributeMultiprocessorCount, p->device) != hipSuccess || p->num_cu < 1) p->num_cu = 256;
     for (int a = 0; a < state_dim; ++a)
         for (int b = a + 1; b < state_dim; ++b) { p->pair_a[p->npairs] = a; p->pair_b[p->npairs] = b; ++p->npairs; }
     const size_t Np = p->Np;

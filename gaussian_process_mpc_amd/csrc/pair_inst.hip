@@ -11,3 +11,10 @@ template int gpmpc_launch_pair_D<GPMPC_PAIR_D>(bool, bool, int, int, const PairA
 template int gpmpc_launch_pair_sb_D<GPMPC_PAIR_D>(bool, int, int, int, const PairSbArgs&, hipStream_t);
 template int gpmpc_launch_pair_sbf_D<GPMPC_PAIR_D>(bool, int, int, const PairSbfArgs&, hipStream_t);
 template int gpmpc_launch_pair_sbs_D<GPMPC_PAIR_D>(bool, int, int, const PairSbsArgs&, hipStream_t);
+
+#if defined(GPMPC_SB_STAMPS) && GPMPC_PAIR_D == 5
+// diagnostic build: per-workgroup stamps of the last D = 5 scalar-broadcast pair launch (tools/sb_stamps.py)
+extern "C" int gpmpc_debug_sb_stamps(unsigned long long* host_out, int n) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_sb_stamps), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : -3;
+}
+#endif

@@ -43,6 +43,16 @@
 #define GPMPC_SB_TB2_WAVES 5
 #endif
 
+// Diagnostic build (make EXTRA=-DGPMPC_SB_STAMPS, tools/sb_stamps.py): per-workgroup timeline of the D = 5 instances -- dispatch
+// time, prologue, column loop, reduction -- to see where a mid-size launch spends its time.  Not compiled otherwise.
+#if defined(GPMPC_SB_STAMPS) && GPMPC_PAIR_D == 5
+#define GPMPC_SB_NSTAMP 8
+static __device__ unsigned long long g_sb_stamps[8192 * GPMPC_SB_NSTAMP];
+#define GPMPC_SBST(slot, val) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_sb_stamps[blockIdx.x * GPMPC_SB_NSTAMP + (slot)] = (val); } while (0)
+#else
+#define GPMPC_SBST(slot, val) do { } while (0)
+#endif
+
 template <int D, int NS2>
 struct PairSbTraits {
     static constexpr int GW = (D + 1 + NS2 + 1) & ~1;     // doubles per G row (even: rows stay 16-byte aligned)
@@ -51,12 +61,20 @@ struct PairSbTraits {
 // GRAD = false: objective only (Z0), NM = 1.  (A two-rows-per-lane shape was measured 15 % slower: occupancy wins.)
 // FIRST: horizon step 1, whose state inputs (x0, Sigma_0) are constants: only the derivatives w.r.t. the action dimensions
 // (k >= NS2) are needed, so the w and the state-dimension v accumulations are dropped (8 of 30 VALU instructions at D = 5).
-template <int D, int TB, int NS2, bool GRAD, bool FIRST = false>
+// CUV: columns per iteration of the column loop.  1 for full launches (see GPMPC_SB_CU above).  4 for the 256x64 tiling of
+// MID-SIZE batches: there the chip is not full for most of a launch (the last generation of workgroups runs at 1-2 waves per
+// SIMD), and a lone wave of the one-column loop is bound by the latency of its M_ij load -- measured per workgroup with
+// tools/sb_stamps.py (profiles/r03/sb_stamps_mid.txt): 64 columns take 23 us at 8 waves per SIMD AND on an empty chip (~360 ns
+// per column either way: issue-bound when full, one L2 round trip per column when alone).  Four columns in flight give a wave
+// four loads per round trip and four independent dependency chains.
+template <int D, int TB, int NS2, bool GRAD, bool FIRST = false, int CUV = 1>
 __global__ __launch_bounds__(256, (TB == 2 && D <= 5) ? GPMPC_SB_TB2_WAVES : 1) void gpmpc_pair_kernel_sb(PairSbArgs A) {
     constexpr int GW = PairSbTraits<D, NS2>::GW;
     constexpr int NM = GRAD ? 1 + 2 * D : 1, NA = GRAD ? 1 + D + NS2 : 1;
     __shared__ double s_red[16 * TB * NM];        // [wave][row of 16 lanes][trajectory][moment]
     __shared__ double s_tab[GPMPC_EXP_N];
+    GPMPC_SBST(0, __builtin_amdgcn_s_memrealtime());
+    GPMPC_SBST(1, __builtin_amdgcn_s_memtime());
     gpmpc_exp_table_to_lds(s_tab);
 
     // XCD-aware decode (pair_kernel.h): position p of the work list runs on XCD p % 8.  Within an XCD the dispatch
@@ -115,6 +133,7 @@ __global__ __launch_bounds__(256, (TB == 2 && D <= 5) ? GPMPC_SB_TB2_WAVES : 1) 
 
     const double* __restrict__ Ma = A.M + (size_t)unit * Np * Np;
     __syncthreads();                                      // exp table ready
+    GPMPC_SBST(2, __builtin_amdgcn_s_memtime());
 
     if (iw0 < Np) {
         // columns left of every row of this wave carry zero weight (upper-triangular M): start at the wave's diagonal chunk
@@ -124,7 +143,7 @@ __global__ __launch_bounds__(256, (TB == 2 && D <= 5) ? GPMPC_SB_TB2_WAVES : 1) 
         for (int r = 0; r < RI; ++r)
             Mrs[r] = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Ma + (size_t)jstart * Np + iw0 + 64 * r), 0, 0x7fffffff, 0x00020000);
         const int lane8 = lane * 8;
-        constexpr int CU = GPMPC_SB_CU(GW);      // columns per loop iteration
+        constexpr int CU = CUV > 1 ? CUV : GPMPC_SB_CU(GW);      // columns per loop iteration
         for (int jc = jstart; jc < j1; jc += CU) {
             double mij[RI][CU];
 #pragma unroll
@@ -143,7 +162,13 @@ __global__ __launch_bounds__(256, (TB == 2 && D <= 5) ? GPMPC_SB_TB2_WAVES : 1) 
             for (int q = 0; q < CU; ++q) {
 #pragma unroll
                 for (int tb = 0; tb < TB; ++tb) {
-                    const double* __restrict__ g = Gt[tb] + (size_t)(jc + q) * GW;     // wave-uniform address -> SGPRs
+                    // wave-uniform address -> SGPRs.  The rows were written by the head kernel of this step and are constant for
+                    // the whole launch: read through the CONSTANT address space, so that the scalar loads do not depend on the
+                    // compiler proving that no earlier store of this kernel can alias them (any global store ahead of the loop
+                    // -- the stamps of the diagnostic build, a persistent-loop variant -- turns them into per-lane vector loads
+                    // of one address otherwise: 2.5x slower).
+                    typedef const double __attribute__((address_space(4))) gpmpc_cdouble;
+                    const gpmpc_cdouble* __restrict__ g = (const gpmpc_cdouble*)(Gt[tb] + (size_t)(jc + q) * GW);
 #pragma unroll
                     for (int r = 0; r < RI; ++r) {
                         if (r > 0 && jc + CU - 1 < iw0 + 64 * r) continue;                  // row block r is still below the diagonal
@@ -164,6 +189,7 @@ __global__ __launch_bounds__(256, (TB == 2 && D <= 5) ? GPMPC_SB_TB2_WAVES : 1) 
         }
     }
 
+    GPMPC_SBST(3, __builtin_amdgcn_s_memtime());
     // per-lane combination into the m-moments, then the fixed-order workgroup reduction
 #pragma unroll
     for (int tb = 0; tb < TB; ++tb) {
@@ -203,6 +229,8 @@ __global__ __launch_bounds__(256, (TB == 2 && D <= 5) ? GPMPC_SB_TB2_WAVES : 1) 
             A.part[((size_t)b * A.nwork + wi) * A.nm + m] = s;
         }
     }
+    GPMPC_SBST(4, __builtin_amdgcn_s_memtime());
+    GPMPC_SBST(5, __builtin_amdgcn_s_memrealtime());
 }
 
 // `rows` = rows per tile of the work list (64 or 256) = threads per workgroup.
@@ -212,6 +240,10 @@ __global__ __launch_bounds__(256, (TB == 2 && D <= 5) ? GPMPC_SB_TB2_WAVES : 1) 
 template <int D, int TB, int NS2, bool GRAD, bool FIRST = false>
 static int launch_pair_sb_one(int rows, const PairSbArgs& a, hipStream_t s) {
     dim3 grid(((a.B + TB - 1) / TB) * a.nwork), block(rows);
+    if constexpr (TB == 1) {
+        if (a.colunroll == 4) hipLaunchKernelGGL((gpmpc_pair_kernel_sb<D, TB, NS2, GRAD, FIRST, 4>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((gpmpc_pair_kernel_sb<D, TB, NS2, GRAD, FIRST>), grid, block, 0, s, a);
+    } else
     hipLaunchKernelGGL((gpmpc_pair_kernel_sb<D, TB, NS2, GRAD, FIRST>), grid, block, 0, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { gpmpc_set_error("pair kernel (scalar broadcast) launch", e); return GPMPC_E_LAUNCH; }

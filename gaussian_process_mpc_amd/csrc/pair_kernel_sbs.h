@@ -29,7 +29,7 @@ struct PairSbsTraits {
 
 // waves per SIMD the instance is compiled for: 2 VGPRs per accumulator + ~48 for everything else, out of 512
 constexpr int gpmpc_sbs_waves(int NG, int NA) {
-    const int regs = 2 * NG * NA + 48;
+    const int r0 = 2 * NG * NA + 48, regs = r0 < 80 ? 80 : r0;     // (row transform, weights and exp temporaries alone take ~70)
     const int w = 512 / regs;
     return w > 8 ? 8 : (w < 1 ? 1 : w);
 }

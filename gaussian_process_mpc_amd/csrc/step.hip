@@ -828,9 +828,13 @@ int gpmpc_timed_pair_sbf(int D, bool grad, int ns2, int waves, const PairSbfArgs
     return timed_launch(GPMPC_TIME_FULL, s, [&] { return gpmpc_launch_pair_sbf(D, grad, ns2, waves, a, s); });
 }
 
-struct RollPlan { int tiling, tb, waves, nwork, nm, pps, sps, sb, gw, rgroup, fused, fq, hchunks, hrows, shared, sh_list; size_t off_mpart; size_t off_G; size_t off_pp, off_sp, off_part, off_partz, off_jac, off_means, off_vars, total; };
+struct RollPlan { int tiling, tb, waves, nwork, nm, pps, sps, sb, gw, rgroup, fused, fq, hchunks, hrows, shared, sh_list, persist /* columns per iteration of the sb kernel */; size_t off_mpart; size_t off_G; size_t off_pp, off_sp, off_part, off_partz, off_jac, off_means, off_vars, total; };
 
-static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag, RollPlan* r, bool lowprec = false) {
+// shape (optional): take every SHAPE decision (tiling, kernel, trajectories per wave, row chunks ...) from this plan of a larger
+// batch and only size the buffers for B: the sub-batches of a split call then run exactly the launches the whole batch would,
+// so their results are bit-identical to the unsplit call.
+static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag, RollPlan* r, bool lowprec = false,
+                         const RollPlan* shape = nullptr) {
     const int D = p->D;
     // Shapes, by how many workgroups they give (>= 1024 fills the 256 CUs four deep):
     //   256x256 tiles, scalar-broadcast kernel   large batches (C3: 2.2 ms per launch; staged kernel TB 2: 2.82)
@@ -896,6 +900,16 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
         r->nwork = p->ds * p->sh_tiles[r->sh_list];           // partial sums per trajectory: [GP][tile]
         r->rgroup = r->sh_list == 0 ? ((tn.rgroup >= 1 && tn.rgroup <= 16) ? tn.rgroup : 4) : 1;
     }
+    // Columns per iteration of the scalar-broadcast kernel: 4 on the 256x64 tiling (mid-size batches: latency tolerance of
+    // the partly filled generations, pair_kernel_sb.h), 1 on full launches.
+    // (tools/env_ab.py --var GPMPC_SB_UNROLL: +8...14 % up to ~2 generations of workgroups, -4 % from ~4 on)
+    r->persist = (r->sb && !r->shared && !lowprec && r->tiling == 2 && r->tb == 1 && tn.colunroll != 1 &&
+                  ((long)B * r->nwork <= 4096 || tn.colunroll == 4)) ? 4 : 1;
+    if (shape) {
+        r->tiling = shape->tiling; r->tb = shape->tb; r->waves = shape->waves; r->nwork = shape->nwork; r->sb = shape->sb;
+        r->rgroup = shape->rgroup; r->fused = shape->fused; r->fq = shape->fq; r->shared = shape->shared; r->sh_list = shape->sh_list;
+        r->persist = shape->persist;
+    }
     r->nm = gpmpc_num_moments(D, diag, grad);
     r->pps = D + D * D;
     r->sps = sps_of(D);
@@ -915,6 +929,7 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
         if (tn.hchunks >= 0) c = tn.hchunks;
         if (c > 1) { r->hrows = ((p->Np + c - 1) / c + 255) & ~255; r->hchunks = (p->Np + r->hrows - 1) / r->hrows; if (r->hchunks <= 1) r->hchunks = 0; }
     }
+    if (shape) { r->hchunks = shape->hchunks; r->hrows = shape->hrows; }
     r->off_mpart = take(r->hchunks > 1 ? (size_t)2 * B * p->ds * r->hchunks * (1 + 2 * D) : 0);
     r->off_jac = take(grad ? (size_t)B * H * 2 * p->ds * (2 * p->ds + p->da) : 0);
     r->gw = gpmpc_sb_gw(D, p->ds);
@@ -924,11 +939,49 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     r->total = off;
 }
 
+// Graph replay of a MID-SIZE batch (256x64 tiling): the batch is captured as S sub-batches on S parallel branches of the graph.
+// A horizon step is a serial chain head kernel -> pair kernel, and at these sizes neither fills the chip for long (the head
+// kernel runs B ds workgroups, the pair kernel ends in a partly filled generation: tools/sb_stamps.py); two independent chains
+// fill each other's gaps.  Eager calls stay on the caller's stream.
+#define GPMPC_MAX_SPLIT 4
+static int split_count(const gpmpc_pack* p, const RollPlan& r, int B, bool lowprec) {
+    if (lowprec || !r.sb) return 1;
+    const bool mid = r.shared ? r.sh_list == 1 : r.tiling == 2;
+    // measured (tools/env_ab.py --var GPMPC_SPLIT, profiles/r03/split_ab.txt): N = 1024, B = 16: 11.3 -> 13.8 (2 branches) -> 14.3 k
+    // rollouts/s (4); N = 2048, B = 4 / 16: +15 % / +13 %; a branch must keep at least two trajectories, and branches whose
+    // pair launch alone fills the chip twice over gain nothing unless they are wide (N = 4096, B = 2 as 1 + 1: -20 %)
+    int S = 1;
+    if (mid && B >= 4) {
+        S = B / 2 < GPMPC_MAX_SPLIT ? B / 2 : GPMPC_MAX_SPLIT;
+        while (S > 1 && (long)(B / S) * r.nwork >= 4096 && B / S < 8) --S;
+    }
+    if (p->tune.split >= 1) S = p->tune.split;
+    if (S > GPMPC_MAX_SPLIT) S = GPMPC_MAX_SPLIT;
+    if (S > B) S = B;
+    return S;
+}
+static size_t split_bytes(const gpmpc_pack* p, const RollPlan& r, int B, int H, bool grad, int S) {
+    size_t sum = 0;
+    for (int k = 0; k < S; ++k) {
+        const int b0 = (int)((long)B * k / S), b1 = (int)((long)B * (k + 1) / S);
+        RollPlan q;
+        plan_rollout(p, b1 - b0, H, grad, true, &q, false, &r);
+        sum += q.total;
+    }
+    return sum;
+}
+
 extern "C" size_t gpmpc_rollout_workspace_bytes(const gpmpc_pack* p, int B, int H, unsigned flags) {
     if (!p || B < 1 || H < 1) return 0;
     RollPlan r;
-    plan_rollout(p, B, H, (flags & GPMPC_WANT_GRAD) != 0, true, &r, (flags & (GPMPC_FP32_ACCUM | GPMPC_FP32_ALL)) != 0);
-    return r.total;
+    const bool grad = (flags & GPMPC_WANT_GRAD) != 0, lowprec = (flags & (GPMPC_FP32_ACCUM | GPMPC_FP32_ALL)) != 0;
+    plan_rollout(p, B, H, grad, true, &r, lowprec);
+    size_t need = r.total;
+    if (flags & GPMPC_USE_GRAPH) {
+        const int S = split_count(p, r, B, lowprec);
+        if (S > 1) { const size_t sb = split_bytes(p, r, B, H, grad, S); if (sb > need) need = sb; }
+    }
+    return need;
 }
 
 static int launch_step_fused(int D, bool grad, int ns2, int q, const FusedArgs& a, int t, hipStream_t s) {
@@ -955,7 +1008,7 @@ static void launch_head(const RollArgs& A, int t, hipStream_t s) {
 static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, const double* U,
                            const gpmpc_cost_params* cost, unsigned flags, double* out_means, double* out_vars,
                            double* out_cost, double* out_grad, void* workspace, size_t workspace_bytes, void* stream,
-                           double* ext_jac = nullptr, bool full_first = false) {
+                           double* ext_jac = nullptr, bool full_first = false, const RollPlan* shape = nullptr) {
     if (!p || !x0 || !U || !cost || !out_cost || !workspace || B < 1 || H < 1) return GPMPC_E_ARG;
     if (!p->built) return GPMPC_E_STATE;
     const bool grad = (flags & GPMPC_WANT_GRAD) != 0;
@@ -963,7 +1016,7 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
     const int lowprec = (flags & GPMPC_FP32_ALL) ? 2 : ((flags & GPMPC_FP32_ACCUM) ? 1 : 0);
     if (lowprec && grad) return GPMPC_E_ARG;                   // the sweep modes are objective only
     RollPlan r;
-    plan_rollout(p, B, H, grad, true, &r, lowprec != 0);
+    plan_rollout(p, B, H, grad, true, &r, lowprec != 0, shape);
     if (workspace_bytes < r.total) return GPMPC_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace;
@@ -1040,6 +1093,7 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
             Q.M = p->M; Q.XT = p->XT; Q.pp = A.pp; Q.G = A.G; Q.part = A.part; Q.work = P.work;
             Q.Np = p->Np; Q.B = B; Q.ds = p->ds; Q.nwork = r.nwork; Q.pps = r.pps; Q.nm = r.nm; Q.rgroup = r.rgroup;
             Q.first_step = (t == 1 && !p->tune.no_first && !full_first) ? 1 : 0;
+            Q.colunroll = r.persist;
             rc = gpmpc_timed_pair_sb(p->D, grad, r.tb, p->ds, r.waves, Q, s);
         } else {
             rc = gpmpc_timed_pair(p->D, true, grad, r.tb, P.colsplit ? 4 : r.waves, P, s);
@@ -1079,6 +1133,7 @@ struct gpmpc_graph_key {
 #define GPMPC_GRAPH_SLOTS 4
 struct gpmpc_graph_cache {
     hipStream_t stream; hipEvent_t ev_in, ev_out;
+    hipStream_t aux[GPMPC_MAX_SPLIT - 1]; hipEvent_t ev_fork, ev_join[GPMPC_MAX_SPLIT - 1];     // parallel branches of a split capture
     hipGraphExec_t exec[GPMPC_GRAPH_SLOTS]; int valid[GPMPC_GRAPH_SLOTS]; unsigned long long used[GPMPC_GRAPH_SLOTS];
     gpmpc_graph_key key[GPMPC_GRAPH_SLOTS];
     unsigned long long tick; long long captures;
@@ -1091,6 +1146,11 @@ void gpmpc_graph_cache_free(void* c) {
     for (int k = 0; k < GPMPC_GRAPH_SLOTS; ++k) if (g->exec[k]) (void)hipGraphExecDestroy(g->exec[k]);
     if (g->ev_in) (void)hipEventDestroy(g->ev_in);
     if (g->ev_out) (void)hipEventDestroy(g->ev_out);
+    if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
+    for (int k = 0; k < GPMPC_MAX_SPLIT - 1; ++k) {
+        if (g->ev_join[k]) (void)hipEventDestroy(g->ev_join[k]);
+        if (g->aux[k]) (void)hipStreamDestroy(g->aux[k]);
+    }
     if (g->stream) (void)hipStreamDestroy(g->stream);
     free(g);
 }
@@ -1110,9 +1170,15 @@ static int graph_rollout(gpmpc_pack* p, int B, int H, const double* x0, const do
     if (!g) {
         g = (gpmpc_graph_cache*)calloc(1, sizeof(gpmpc_graph_cache));
         if (!g) return GPMPC_E_ALLOC;
-        GPMPC_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
-        GPMPC_HIP(hipEventCreateWithFlags(&g->ev_in, hipEventDisableTiming));
-        GPMPC_HIP(hipEventCreateWithFlags(&g->ev_out, hipEventDisableTiming));
+        hipError_t ec = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
+        if (ec == hipSuccess) ec = hipEventCreateWithFlags(&g->ev_in, hipEventDisableTiming);
+        if (ec == hipSuccess) ec = hipEventCreateWithFlags(&g->ev_out, hipEventDisableTiming);
+        if (ec == hipSuccess) ec = hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming);
+        for (int k = 0; k < GPMPC_MAX_SPLIT - 1 && ec == hipSuccess; ++k) {
+            ec = hipStreamCreateWithFlags(&g->aux[k], hipStreamNonBlocking);
+            if (ec == hipSuccess) ec = hipEventCreateWithFlags(&g->ev_join[k], hipEventDisableTiming);
+        }
+        if (ec != hipSuccess) { gpmpc_set_error("graph cache: stream / event creation", ec); gpmpc_graph_cache_free(g); return GPMPC_E_LAUNCH; }
         p->graph_cache = g;
     }
     gpmpc_graph_key k;
@@ -1133,9 +1199,44 @@ static int graph_rollout(gpmpc_pack* p, int B, int H, const double* x0, const do
         }
         g->valid[slot] = 0;
         hipGraph_t graph = nullptr;
+        const bool grad = (flags & GPMPC_WANT_GRAD) != 0, lowprec = (flags & (GPMPC_FP32_ACCUM | GPMPC_FP32_ALL)) != 0;
+        RollPlan whole;
+        plan_rollout(p, B, H, grad, true, &whole, lowprec);
+        const int S = split_count(p, whole, B, lowprec);
+        if (S > 1 && split_bytes(p, whole, B, H, grad, S) > workspace_bytes) return GPMPC_E_WORKSPACE;
         GPMPC_HIP(hipStreamBeginCapture(g->stream, hipStreamCaptureModeThreadLocal));
-        int rc = enqueue_rollout(p, B, H, x0, U, cost, flags, out_means, out_vars, out_cost, out_grad, workspace,
+        int rc = GPMPC_OK;
+        if (S <= 1) {
+            rc = enqueue_rollout(p, B, H, x0, U, cost, flags, out_means, out_vars, out_cost, out_grad, workspace,
                                  workspace_bytes, g->stream);
+        } else {
+            // fork: sub-batch k > 0 on its own stream behind the capture origin; join: the origin waits for all of them
+            hipError_t ef = hipEventRecord(g->ev_fork, g->stream);
+            char* wsp = (char*)workspace;
+            const int ds = p->ds, da = p->da;
+            for (int k = S - 1; k >= 0 && rc == GPMPC_OK && ef == hipSuccess; --k) {
+                const int b0 = (int)((long)B * k / S), b1 = (int)((long)B * (k + 1) / S);
+                size_t woff = 0;
+                for (int q = 0; q < k; ++q) {
+                    RollPlan pq;
+                    plan_rollout(p, (int)((long)B * (q + 1) / S) - (int)((long)B * q / S), H, grad, true, &pq, false, &whole);
+                    woff += pq.total;
+                }
+                RollPlan pk;
+                plan_rollout(p, b1 - b0, H, grad, true, &pk, false, &whole);
+                hipStream_t sk = k == 0 ? g->stream : g->aux[k - 1];
+                if (k > 0) ef = hipStreamWaitEvent(sk, g->ev_fork, 0);
+                if (ef != hipSuccess) break;
+                rc = enqueue_rollout(p, b1 - b0, H, x0 + (size_t)b0 * ds, U + (size_t)b0 * H * da, cost, flags,
+                                     out_means ? out_means + (size_t)b0 * (H + 1) * ds : nullptr,
+                                     out_vars ? out_vars + (size_t)b0 * (H + 1) * ds : nullptr, out_cost + b0,
+                                     out_grad ? out_grad + (size_t)b0 * H * da : nullptr, wsp + woff, pk.total, sk, nullptr, false,
+                                     &whole);
+                if (k > 0 && rc == GPMPC_OK) ef = hipEventRecord(g->ev_join[k - 1], sk);
+            }
+            for (int k = 1; k < S && ef == hipSuccess; ++k) ef = hipStreamWaitEvent(g->stream, g->ev_join[k - 1], 0);
+            if (ef != hipSuccess && rc == GPMPC_OK) { gpmpc_set_error("split capture (fork / join)", ef); rc = GPMPC_E_LAUNCH; }
+        }
         hipError_t e = hipStreamEndCapture(g->stream, &graph);
         if (rc != GPMPC_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
         if (e != hipSuccess) { gpmpc_set_error("hipStreamEndCapture", e); return GPMPC_E_LAUNCH; }

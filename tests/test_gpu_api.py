@@ -165,7 +165,9 @@ def test_dynamics_and_mpc_callbacks(G, golden, name):
 
 def test_state_host_copy_survives_a_full_covariance_detour(G, golden):
     """The host copy of curr_state behind the B = 1 callback entry is keyed on its own source tensor: toggling
-    full_covariance after curr_state was REPLACED by a new tensor of the same version must not upload the old state."""
+    full_covariance after curr_state was REPLACED by a new tensor of the same version must not upload the old state; and
+    the value cache behind objective / gradient follows the full_covariance switch (the two propagations differ by ~5e-5
+    in this cost: a full-covariance value must not be served to a diagonal-covariance call)."""
     z = golden("g3_rollout_c1.npz")
     mpc = _mpc_from(G, z, -1.0)
     x = z["U"][0].reshape(-1).copy()
@@ -173,9 +175,10 @@ def test_state_host_copy_survives_a_full_covariance_detour(G, golden):
     c_a = mpc.objective(x)
     mpc.full_covariance = True
     mpc.curr_state = torch.tensor(z["x0"][1]).to(mpc.device)            # new tensor, _version 0 like the old one
-    mpc.objective(x)                                                     # full-covariance branch refreshes _cache_held only
+    c_full = mpc.objective(x)                                            # full-covariance branch refreshes _cache_held only
     mpc.full_covariance = False
     c_b = mpc.objective(x)
+    assert c_b != c_full
     fresh = _mpc_from(G, z, -1.0)
     fresh.curr_state = torch.tensor(z["x0"][1]).to(fresh.device)
     assert c_b == pytest.approx(fresh.objective(x), rel=1e-12) and c_b != c_a
