@@ -12,6 +12,12 @@ _LIB = None
 def lib():
     global _LIB
     if _LIB is None:
+        alt = os.environ.get("GPMPC_CPORT_LIB")           # the sanitizer build (make -C oracle/cport asan), tools/run_sanitizers.sh
+        if alt:
+            _LIB = ctypes.CDLL(alt)
+            _LIB.gpmpc_cpu_rollout.restype = ctypes.c_int
+            _LIB.gpmpc_cpu_rollout_fullcov.restype = ctypes.c_int
+            return _LIB
         so = os.path.join(_HERE, "libgpmpc_cpu.so")
         srcs = [os.path.join(_HERE, f) for f in ("gpmpc_cpu.c", "gpmpc_cpu_fullcov.c", "gpmpc_cpu_ld.c")]
         if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
