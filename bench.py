@@ -279,7 +279,7 @@ def measured_traffic(config, B, want_grad, kernel_hint):
     d, rnd = None, None
     for rnd in ("r03", "r02"):
         try:
-            with open(os.path.join(ROOT, "profiles", rnd, f"pmc_{config}.json")) as f:
+            with open(os.path.join(ROOT, "profiles", rnd, f"pmc_{config}{'_shared' if kernel_hint == 'sbs' else ''}.json")) as f:
                 d = json.load(f)
             break
         except (OSError, ValueError):
@@ -293,7 +293,7 @@ def measured_traffic(config, B, want_grad, kernel_hint):
     if "FETCH_SIZE" not in k or "WRITE_SIZE" not in k:
         return None, None
     traffic = (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
-    src = (f"profiles/{rnd}/pmc_{config}.json (HEAD {d.get('head', '?')}; `{d.get('command', '?')}`; kernel {k.get('name', '?')}; "
+    src = (f"profiles/{rnd}/pmc_{config}{'_shared' if kernel_hint == 'sbs' else ''}.json (HEAD {d.get('head', '?')}; `{d.get('command', '?')}`; kernel {k.get('name', '?')}; "
            f"2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes; Infinity-Cache hits are included in FETCH_SIZE)")
     return traffic, src
 

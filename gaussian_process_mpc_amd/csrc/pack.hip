@@ -246,6 +246,7 @@ extern "C" int gpmpc_pack_create(gpmpc_pack** out, int n_train, int state_dim, i
     // shared-lambda work lists (pair_kernel_sbs.h): "units" are groups of sh_ng GPs
     if (ok && state_dim >= 2 && action_dim >= 1 && action_dim <= 2) {
         p->sh_ng = gpmpc_sbs_group(state_dim, D);
+        if (const char* ev = getenv("GPMPC_SHARED_NG")) { const int v = atoi(ev); if (v >= 2 && v <= 4 && v <= state_dim) p->sh_ng = v; }   // A/B (at pack creation)
         const int groups = (state_dim + p->sh_ng - 1) / p->sh_ng;
         ok = build_worklist(p->Np, 256, cfg[0][1], groups, 0, !p->tune.no_xcd_sort, &p->wl_sh[0], true, &p->sh_tiles[0]) == 0 &&
              build_worklist(p->Np, 256, 64, groups, 0, false, &p->wl_sh[1], true, &p->sh_tiles[1]) == 0;

@@ -1,0 +1,48 @@
+#!/bin/bash
+# Collects the judged artefacts of the round-3 build into gpurun_out/r03/ (run through gpurun from the repo root; tools/.githead
+# must hold the HEAD the snapshot was taken at).  Copy the result into profiles/r03/ afterwards.
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r03
+mkdir -p $O
+cd $R
+STEP=${1:-all}
+if [ $STEP = all ] || [ $STEP = prof ]; then
+for c in C3 C4 C5; do bash tools/prof_pmc.sh $c > $O/pmc_$c.log 2>&1; cp gpurun_out/pmc_$c/pmc_$c.txt gpurun_out/pmc_$c/pmc_$c.json $O/ 2>/dev/null; done
+bash tools/prof_pmc.sh C3 --shared-lambda > $O/pmc_C3_shared.log 2>&1; cp gpurun_out/pmc_C3/pmc_C3.txt $O/pmc_C3_shared.txt; cp gpurun_out/pmc_C3/pmc_C3.json $O/pmc_C3_shared.json
+for c in C3 C4 C5; do bash tools/prof_trace.sh $c > $O/trace_$c.log 2>&1; cp gpurun_out/trace_$c/kernel_stats_$c.csv gpurun_out/trace_$c/bench_traced_$c.json $O/ 2>/dev/null; done
+bash tools/prof_trace.sh C3 --shared-lambda > $O/trace_C3_shared.log 2>&1; cp gpurun_out/trace_C3/kernel_stats_C3.csv $O/kernel_stats_C3_shared.csv; cp gpurun_out/trace_C3/bench_traced_C3.json $O/bench_traced_C3_shared.json
+mkdir -p profiles/r03 && cp $O/pmc_C3.json $O/pmc_C4.json $O/pmc_C5.json $O/pmc_C3_shared.json profiles/r03/ 2>/dev/null
+fi
+if [ $STEP = all ] || [ $STEP = bench ]; then
+python bench.py > $O/bench_C3.json 2> $O/bench_C3.err || echo "bench C3 failed"
+python bench.py --config C3 --shared-lambda --no-cpu-baseline > $O/bench_C3_shared.json 2>/dev/null || echo "bench C3 shared failed"
+for c in C4 C5; do python bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_$c.json 2>/dev/null || echo "bench $c failed"; done
+for c in C1 C2; do
+  python bench.py --config $c --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_$c.json 2>/dev/null
+  python bench.py --config $c --steps 200 --warmup 20 --no-cpu-baseline --graph > $O/bench_${c}_graph.json 2>/dev/null
+done
+python bench.py --config C3 --steps 5 --warmup 2 --no-cpu-baseline --forward-only > $O/bench_C3_fwd.json 2>/dev/null
+for b in 1 4 16 32; do python bench.py --config C3 --batch $b --steps 20 --warmup 5 --no-cpu-baseline --graph > $O/bench_C3_B$b.json 2>/dev/null; done
+python bench.py --gpus 2 --oversubscribe --backend gloo --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_2rank_gloo_one_card.json 2>/dev/null
+python bench.py --gpus 6 --config C4 --batch 2 --oversubscribe --backend gloo --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_C4_6rank_gloo_one_card.json 2>$O/bench_C4_6rank.err
+for v in "" "--cl-distinct" "--cl-rebuild"; do python bench.py --closed-loop $v > "$O/closed_loop$(echo $v | tr -d ' ').json" 2>/dev/null; done
+python tools/callback_latency.py 2>/dev/null | tail -2 > $O/callback_latency.txt
+fi
+if [ $STEP = all ] || [ $STEP = maps ]; then
+python tools/batch_map.py > $O/batch_size_map.txt 2>&1
+python tools/batch_map.py --shapes 1024:4:1:20,2048:4:1:20 --batches 8,12,16,24,32,48,64 >> $O/batch_size_map.txt 2>&1
+python tools/accuracy_seeds.py 9 > $O/accuracy_seeds.txt 2>&1
+python tools/shared_ng_ab.py > $O/shared_ng_ab.txt 2>&1
+fi
+for f in $O/bench_*.json; do python - "$f" <<'PY'
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]) if l.lstrip().startswith("{")][-1]); r = d["roofline"]
+except Exception as e:
+    print(sys.argv[1].split("/")[-1], "unreadable", e); sys.exit(0)
+g = lambda v, n=3: None if v is None or v != v else round(v, n)
+print(sys.argv[1].split("/")[-1], g(d["value"], 1), d["unit"], "ms/step", g(d["ms_per_step"]), "kernel ms", g(r["avg_launch_ms"], 4),
+      "frac", g(r["frac"]), "issue_util", g(r.get("issue_util")), "exec_flops", g(r.get("executed_flops_frac")), "traffic", r["traffic"], "n_gpus", d["n_gpus"])
+PY
+done

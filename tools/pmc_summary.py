@@ -41,7 +41,7 @@ if a.json:
         n = max(v["_launches"].values())
         return n * v.get("GRBM_GUI_ACTIVE", 1.0)
     dom = max(kernels, key=weight) if kernels else None
-    out = {"head": a.head, "command": a.command, "config": a.config, "batch_per_gpu": a.batch, "want_grad": not a.forward_only,
+    out = {"head": a.head, "command": a.command, "config": a.config, "batch_per_gpu": a.batch, "want_grad": not a.forward_only, "shared_lambda": "--shared-lambda" in a.command,
            "units": "FETCH_SIZE / WRITE_SIZE in KiB per launch (rocprofv3 derived counters); other counters raw, per launch",
            "kernels": {k: {c: v for c, v in d.items() if c != "_launches"} for k, d in kernels.items()},
            "launches_profiled": {k: max(d["_launches"].values()) for k, d in kernels.items()}}
