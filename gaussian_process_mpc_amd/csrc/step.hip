@@ -939,10 +939,10 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     r->total = off;
 }
 
-// Graph replay of a MID-SIZE batch (256x64 tiling): the batch is captured as S sub-batches on S parallel branches of the graph.
+// A MID-SIZE batch (256x64 tiling) runs as S sub-batches on S streams (parallel branches of the graph under graph replay).
 // A horizon step is a serial chain head kernel -> pair kernel, and at these sizes neither fills the chip for long (the head
 // kernel runs B ds workgroups, the pair kernel ends in a partly filled generation: tools/sb_stamps.py); two independent chains
-// fill each other's gaps.  Eager calls stay on the caller's stream.
+// fill each other's gaps.
 #define GPMPC_MAX_SPLIT 4
 static int split_count(const gpmpc_pack* p, const RollPlan& r, int B, bool lowprec) {
     if (lowprec || !r.sb) return 1;
@@ -977,10 +977,8 @@ extern "C" size_t gpmpc_rollout_workspace_bytes(const gpmpc_pack* p, int B, int 
     const bool grad = (flags & GPMPC_WANT_GRAD) != 0, lowprec = (flags & (GPMPC_FP32_ACCUM | GPMPC_FP32_ALL)) != 0;
     plan_rollout(p, B, H, grad, true, &r, lowprec);
     size_t need = r.total;
-    if (flags & GPMPC_USE_GRAPH) {
-        const int S = split_count(p, r, B, lowprec);
-        if (S > 1) { const size_t sb = split_bytes(p, r, B, H, grad, S); if (sb > need) need = sb; }
-    }
+    const int S = split_count(p, r, B, lowprec);           // mid-size batches run as S concurrent sub-batches, each with its own slice
+    if (S > 1) { const size_t sb = split_bytes(p, r, B, H, grad, S); if (sb > need) need = sb; }
     return need;
 }
 
@@ -1161,11 +1159,8 @@ extern "C" long long gpmpc_pack_graph_captures(const gpmpc_pack* p) {
     return g ? g->captures : 0;
 }
 
-// Replay the launches of a rollout as ONE hipGraph on a stream owned by the pack (the caller's stream may be the
-// legacy default stream, which cannot be captured); ordered against the caller's stream with two events.
-static int graph_rollout(gpmpc_pack* p, int B, int H, const double* x0, const double* U, const gpmpc_cost_params* cost,
-                         unsigned flags, double* out_means, double* out_vars, double* out_cost, double* out_grad,
-                         void* workspace, size_t workspace_bytes, hipStream_t user) {
+// The pack's private streams / events (graph replay and split launches), created on first use.
+static int ensure_graph_cache(gpmpc_pack* p, gpmpc_graph_cache** out) {
     gpmpc_graph_cache* g = (gpmpc_graph_cache*)p->graph_cache;
     if (!g) {
         g = (gpmpc_graph_cache*)calloc(1, sizeof(gpmpc_graph_cache));
@@ -1181,6 +1176,54 @@ static int graph_rollout(gpmpc_pack* p, int B, int H, const double* x0, const do
         if (ec != hipSuccess) { gpmpc_set_error("graph cache: stream / event creation", ec); gpmpc_graph_cache_free(g); return GPMPC_E_LAUNCH; }
         p->graph_cache = g;
     }
+    *out = g;
+    return GPMPC_OK;
+}
+
+// One rollout call as S sub-batches: sub-batch 0 on `origin`, the others on the pack's auxiliary streams, forked from and
+// joined back into `origin` with events (inside a stream capture these become parallel branches of the graph).  The
+// fork / join pairs of one pack are serialised (two host threads sharing a pack must not interleave them).
+static std::mutex g_split_mu;
+static int enqueue_split(gpmpc_pack* p, gpmpc_graph_cache* g, int S, const RollPlan& whole, hipStream_t origin, int B, int H,
+                         const double* x0, const double* U, const gpmpc_cost_params* cost, unsigned flags, double* out_means,
+                         double* out_vars, double* out_cost, double* out_grad, void* workspace) {
+    std::lock_guard<std::mutex> lk(g_split_mu);
+    const bool grad = (flags & GPMPC_WANT_GRAD) != 0;
+    int rc = GPMPC_OK;
+    hipError_t ef = hipEventRecord(g->ev_fork, origin);
+    char* wsp = (char*)workspace;
+    const int ds = p->ds, da = p->da;
+    for (int k = S - 1; k >= 0 && rc == GPMPC_OK && ef == hipSuccess; --k) {
+        const int b0 = (int)((long)B * k / S), b1 = (int)((long)B * (k + 1) / S);
+        size_t woff = 0;
+        for (int q = 0; q < k; ++q) {
+            RollPlan pq;
+            plan_rollout(p, (int)((long)B * (q + 1) / S) - (int)((long)B * q / S), H, grad, true, &pq, false, &whole);
+            woff += pq.total;
+        }
+        RollPlan pk;
+        plan_rollout(p, b1 - b0, H, grad, true, &pk, false, &whole);
+        hipStream_t sk = k == 0 ? origin : g->aux[k - 1];
+        if (k > 0) ef = hipStreamWaitEvent(sk, g->ev_fork, 0);
+        if (ef != hipSuccess) break;
+        rc = enqueue_rollout(p, b1 - b0, H, x0 + (size_t)b0 * ds, U + (size_t)b0 * H * da, cost, flags,
+                             out_means ? out_means + (size_t)b0 * (H + 1) * ds : nullptr,
+                             out_vars ? out_vars + (size_t)b0 * (H + 1) * ds : nullptr, out_cost + b0,
+                             out_grad ? out_grad + (size_t)b0 * H * da : nullptr, wsp + woff, pk.total, sk, nullptr, false, &whole);
+        if (k > 0 && rc == GPMPC_OK) ef = hipEventRecord(g->ev_join[k - 1], sk);
+    }
+    for (int k = 1; k < S && ef == hipSuccess; ++k) ef = hipStreamWaitEvent(origin, g->ev_join[k - 1], 0);
+    if (ef != hipSuccess && rc == GPMPC_OK) { gpmpc_set_error("split launch (fork / join)", ef); rc = GPMPC_E_LAUNCH; }
+    return rc;
+}
+
+// Replay the launches of a rollout as ONE hipGraph on a stream owned by the pack (the caller's stream may be the
+// legacy default stream, which cannot be captured); ordered against the caller's stream with two events.
+static int graph_rollout(gpmpc_pack* p, int B, int H, const double* x0, const double* U, const gpmpc_cost_params* cost,
+                         unsigned flags, double* out_means, double* out_vars, double* out_cost, double* out_grad,
+                         void* workspace, size_t workspace_bytes, hipStream_t user) {
+    gpmpc_graph_cache* g = nullptr;
+    if (int rcg = ensure_graph_cache(p, &g)) return rcg;
     gpmpc_graph_key k;
     memset(&k, 0, sizeof(k));
     k.B = B; k.H = H; k.flags = flags; k.x0 = x0; k.U = U; k.means = out_means; k.vars = out_vars; k.cost_out = out_cost;
@@ -1210,32 +1253,7 @@ static int graph_rollout(gpmpc_pack* p, int B, int H, const double* x0, const do
             rc = enqueue_rollout(p, B, H, x0, U, cost, flags, out_means, out_vars, out_cost, out_grad, workspace,
                                  workspace_bytes, g->stream);
         } else {
-            // fork: sub-batch k > 0 on its own stream behind the capture origin; join: the origin waits for all of them
-            hipError_t ef = hipEventRecord(g->ev_fork, g->stream);
-            char* wsp = (char*)workspace;
-            const int ds = p->ds, da = p->da;
-            for (int k = S - 1; k >= 0 && rc == GPMPC_OK && ef == hipSuccess; --k) {
-                const int b0 = (int)((long)B * k / S), b1 = (int)((long)B * (k + 1) / S);
-                size_t woff = 0;
-                for (int q = 0; q < k; ++q) {
-                    RollPlan pq;
-                    plan_rollout(p, (int)((long)B * (q + 1) / S) - (int)((long)B * q / S), H, grad, true, &pq, false, &whole);
-                    woff += pq.total;
-                }
-                RollPlan pk;
-                plan_rollout(p, b1 - b0, H, grad, true, &pk, false, &whole);
-                hipStream_t sk = k == 0 ? g->stream : g->aux[k - 1];
-                if (k > 0) ef = hipStreamWaitEvent(sk, g->ev_fork, 0);
-                if (ef != hipSuccess) break;
-                rc = enqueue_rollout(p, b1 - b0, H, x0 + (size_t)b0 * ds, U + (size_t)b0 * H * da, cost, flags,
-                                     out_means ? out_means + (size_t)b0 * (H + 1) * ds : nullptr,
-                                     out_vars ? out_vars + (size_t)b0 * (H + 1) * ds : nullptr, out_cost + b0,
-                                     out_grad ? out_grad + (size_t)b0 * H * da : nullptr, wsp + woff, pk.total, sk, nullptr, false,
-                                     &whole);
-                if (k > 0 && rc == GPMPC_OK) ef = hipEventRecord(g->ev_join[k - 1], sk);
-            }
-            for (int k = 1; k < S && ef == hipSuccess; ++k) ef = hipStreamWaitEvent(g->stream, g->ev_join[k - 1], 0);
-            if (ef != hipSuccess && rc == GPMPC_OK) { gpmpc_set_error("split capture (fork / join)", ef); rc = GPMPC_E_LAUNCH; }
+            rc = enqueue_split(p, g, S, whole, g->stream, B, H, x0, U, cost, flags, out_means, out_vars, out_cost, out_grad, workspace);
         }
         hipError_t e = hipStreamEndCapture(g->stream, &graph);
         if (rc != GPMPC_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
@@ -1378,6 +1396,21 @@ extern "C" int gpmpc_rollout(const gpmpc_pack* p, int B, int H, const double* x0
     if ((flags & GPMPC_USE_GRAPH) && !timing_on() && p->built && x0 && U && out_cost && workspace && B >= 1 && H >= 1)
         return graph_rollout(const_cast<gpmpc_pack*>(p), B, H, x0, U, cost, flags, out_means, out_vars, out_cost, out_grad,
                              workspace, workspace_bytes, (hipStream_t)stream);
+    if (p->built && x0 && U && out_cost && workspace && B >= 4 && H >= 1 && !(flags & (GPMPC_FP32_ACCUM | GPMPC_FP32_ALL)) &&
+        (!(flags & GPMPC_WANT_GRAD) || out_grad)) {
+        // mid-size batch launched plainly: the same split into concurrent sub-batches as under graph replay, on the pack's
+        // auxiliary streams, forked from / joined into the caller's stream
+        const bool grad = (flags & GPMPC_WANT_GRAD) != 0;
+        RollPlan whole;
+        plan_rollout(p, B, H, grad, true, &whole, false);
+        const int S = split_count(p, whole, B, false);
+        if (S > 1 && split_bytes(p, whole, B, H, grad, S) <= workspace_bytes) {
+            gpmpc_graph_cache* g = nullptr;
+            if (int rcg = ensure_graph_cache(const_cast<gpmpc_pack*>(p), &g)) return rcg;
+            return enqueue_split(const_cast<gpmpc_pack*>(p), g, S, whole, (hipStream_t)stream, B, H, x0, U, cost, flags, out_means,
+                                 out_vars, out_cost, out_grad, workspace);
+        }
+    }
     return enqueue_rollout(p, B, H, x0, U, cost, flags, out_means, out_vars, out_cost, out_grad, workspace,
                            workspace_bytes, stream);
 }

@@ -83,25 +83,33 @@ def test_fuzz_fullcov_rollout_vs_cport(G, seed):
 
 @pytest.mark.parametrize("sigma_n", [1e-2, 1e-3, 1e-4, 1e-5])
 def test_accuracy_against_the_extended_precision_yardstick(G, sigma_n):
-    """At smaller noise levels no fp64 evaluation of the variance is reproducible to 1e-4 (cond(Ky) ~ 1 / sigma_n^2; the
-    reference's experiments use sigma_n = 1e-5).  Yardstick: the same rollout with EVERY operation in x87 extended precision
-    on the same fp64 inputs (oracle/cport/gpmpc_cpu_ld.c).  The HIP path must be as close to it as the reference's own op
-    order evaluated in fp64 is (oracle, faithful mode: the N^3 trace of src/tools/uncertainty_prop.py:399) -- within a
-    factor 10 -- and inside the north-star tolerance at the benchmark's sigma_n = 1e-2."""
+    """At smaller noise levels no fp64 evaluation of the variance is reproducible to 1e-4 on dense synthetic training sets
+    (cond(Ky) ~ 1 / sigma_n^2).  Yardstick: the same rollout with EVERY operation in x87 extended precision on the same fp64
+    inputs (oracle/cport/gpmpc_cpu_ld.c).  The HIP path must be as close to it as the reference's own op order evaluated in
+    fp64 is (oracle, faithful mode: the N^3 trace of src/tools/uncertainty_prop.py:399).  Both deviations are rounding noise
+    of the same size (profiles/r03/accuracy_seeds.txt: ratio HIP / reference has median 0.8-1.07 and spreads 0.2-5 from
+    problem to problem), so the comparison is made on the MEDIAN over five seeded problems: <= 1.6 (round 2 compared one
+    draw and needed a factor 10); inside the north-star tolerance at the benchmark's sigma_n = 1e-2.  (The reference's own
+    regime -- the README experiment's data -- is benign at every noise level: tests/test_gpu_api.py, g10.)"""
     from oracle import cport, gpmpc_oracle as O
     from gaussian_process_mpc_amd.synth import synth_problem
     N, ds, da, H = 400, 3, 1, 3
-    pb = synth_problem(77, N, ds, da, H, 2, sigma_n=sigma_n)
-    gp = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"])
-    kinv = gp.Ky_inv.numpy()
-    pack = G.GPPack(pb["X"], pb["Y"], kinv, pb["lambdas"], pb["sigma_f"])
-    r = G.rollout(pack, pb["x0"], pb["U"], G.CostParams(1e-5, pb["Q"], pb["R"]), want_grad=False)
-    e = cport.rollout_extended(pb, kinv, nthreads=8)
-    ref = np.stack([O.objective_and_gradient(gp, H, pb["x0"][b], pb["U"][b], pb["x_ref"], pb["u_ref"], pb["Q"], pb["R"], 1e-5,
-                                             mode="faithful", want_grad=False)["vars"] for b in range(2)])
-    dev = lambda a: float(np.abs(a[:, 1:] / e["vars"][:, 1:] - 1).max())      # noqa: E731
-    dev_hip, dev_ref = dev(r["vars"].cpu().numpy()), dev(ref)
-    np.testing.assert_allclose(r["means"].cpu().numpy(), e["means"], rtol=1e-5 if sigma_n >= 1e-3 else 1e-3, atol=1e-8)
-    assert dev_hip <= max(10 * dev_ref, 1e-9), (sigma_n, dev_hip, dev_ref)
-    if sigma_n == 1e-2:
-        assert dev_hip < 1e-4 and dev_ref < 1e-4
+    ratios, worst_hip = [], 0.0
+    for seed in range(5):
+        pb = synth_problem(77 + seed, N, ds, da, H, 2, sigma_n=sigma_n)
+        gp = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"])
+        kinv = gp.Ky_inv.numpy()
+        pack = G.GPPack(pb["X"], pb["Y"], kinv, pb["lambdas"], pb["sigma_f"])
+        r = G.rollout(pack, pb["x0"], pb["U"], G.CostParams(1e-5, pb["Q"], pb["R"]), want_grad=False)
+        e = cport.rollout_extended(pb, kinv, nthreads=8)
+        ref = np.stack([O.objective_and_gradient(gp, H, pb["x0"][b], pb["U"][b], pb["x_ref"], pb["u_ref"], pb["Q"], pb["R"], 1e-5,
+                                                 mode="faithful", want_grad=False)["vars"] for b in range(2)])
+        dev = lambda a: float(np.abs(a[:, 1:] / e["vars"][:, 1:] - 1).max())      # noqa: E731
+        dev_hip, dev_ref = dev(r["vars"].cpu().numpy()), dev(ref)
+        np.testing.assert_allclose(r["means"].cpu().numpy(), e["means"], rtol=1e-5 if sigma_n >= 1e-3 else 1e-3, atol=1e-8)
+        ratios.append(dev_hip / max(dev_ref, 1e-12))
+        worst_hip = max(worst_hip, dev_hip)
+        assert dev_hip <= max(10 * dev_ref, 1e-9), (sigma_n, seed, dev_hip, dev_ref)      # no single draw far off
+        if sigma_n == 1e-2:
+            assert dev_hip < 1e-4 and dev_ref < 1e-4
+    assert np.median(ratios) <= 1.6, (sigma_n, ratios)
