@@ -139,10 +139,16 @@ def spawn_ranks(args, argv=None, poll_s=0.2):
 # ----------------------------------------------------------------------------------------------------------------------
 # helpers
 # ----------------------------------------------------------------------------------------------------------------------
-def pair_work(D, ds, want_grad, fullcov):
+def pair_work(D, ds, want_grad, fullcov, shared=False):
     """Algorithmic work per pair-evaluation of the FULL pair kernel: forward+gradient
     2D+23 fp64 issue slots = 4D+37 flops (FMA = 2); objective only D+22 / 2D+37; the full-covariance
-    rollout accumulates D(D+1)/2 second moments instead of D."""
+    rollout accumulates D(D+1)/2 second moments instead of D.  With one lambda for all GPs the exponent and the exp of a
+    pair are common to its ds GPs: of the 4D+37 flops, 2D+3 (weight x exp, row sum, P.V) are per GP and 2D+34 per pair, so
+    the algorithmic count per pair-and-GP is (2D+34)/ds + 2D+3 (slots: (D+21)/ds + D+2)."""
+    if shared and want_grad and not fullcov:
+        return (2 * D + 34) / ds + 2 * D + 3, (D + 21) / ds + D + 2
+    if shared and not want_grad and not fullcov:
+        return (2 * D + 35) / ds + 2, (D + 21) / ds + 1
     if not want_grad:
         return 2 * D + 37, D + 22
     if fullcov:
@@ -418,7 +424,8 @@ def run_rank(args):
         pairs_per_launch = B * ds * N * (N + 1) / 2                 # one horizon step, all trajectories and GPs
         if fullcov:                                                 # + ds(ds-1)/2 cross units over all N^2 ordered pairs
             pairs_per_launch += B * (ds * (ds - 1) / 2) * N * N
-        fl, slots = pair_work(D, ds, want_grad, fullcov)
+        shared = bool(pack.shared_lambda) and not fullcov and os.environ.get("GPMPC_SHARED", "") != "0"
+        fl, slots = pair_work(D, ds, want_grad, fullcov, shared)
         full_ms, full_n = tcls[0]
         fused_path = full_n == 0 and tcls[2][1] > 0            # small batches: one fused launch per horizon step
         if fused_path:
@@ -426,7 +433,6 @@ def run_rank(args):
         launch_s = (full_ms / full_n) * 1e-3 if full_n else float("nan")
         achieved = pairs_per_launch * fl / launch_s / 1e12
         m_bytes = 8 * (ds * N * (N + 1) / 2 + (ds * (ds - 1) / 2 * N * N if fullcov else 0))     # M read once per launch
-        shared = bool(pack.shared_lambda) and not fullcov and os.environ.get("GPMPC_SHARED", "") != "0"
         sm = "sbf" if fullcov else ("sbs" if shared else "sb")
         traffic, traffic_src = measured_traffic(args.config, B, want_grad, sm)
         ng = 0
@@ -576,7 +582,13 @@ def run_closed_loop(args):
     t_first_build = (time.perf_counter() - t0) * 1e3
     mpc.set_lb([-2.0]); mpc.set_ub([2.0]); mpc.set_xref(np.zeros(2))
     obs, _ = plant.reset()
-    mpc.dynamics.pack(); mpc.get_optimal_trajectory(obs)  # warm-up: library load, graph capture
+    # warm-up, untimed: library load, graph capture, and ONE whole environment step (the first incremental append pays the
+    # one-time load of its kernels: 15-60 ms)
+    mpc.dynamics.pack(); a0 = mpc.get_optimal_trajectory(obs)[0, :]
+    nxt0 = plant.step(a0)[0]
+    mpc.dynamics.append_train_data(obs, a0, nxt0, incremental=not args.cl_rebuild); sync()
+    obs = nxt0
+    n0 += 1
     rows = []
     for it in range(args.cl_steps):
         sync(); ta = time.perf_counter()
@@ -603,6 +615,8 @@ def run_closed_loop(args):
         # the solve's share varies with the stand-in optimiser's iteration count; what the data path adds per step is this:
         "step_ms_excluding_solve": {"median": float(np.median(total - r[:, 1])), "max": float((total - r[:, 1]).max()),
                                     "max_on_full_rebuild_steps": float((total - r[:, 1])[full].max()) if full.any() else None},
+        "worst_non_solve_step": (lambda k: {"index": int(k), "n_train": int(n0 + k), "pack_build": float(r[k, 0]), "plant": float(r[k, 2]),
+                                             "inverse_update": float(r[k, 3]), "full_rebuild": bool(full[k])})(int(np.argmax(total - r[:, 1]))),
         "worst_step_with_median_solve_over_median_step": float((np.median(r[:, 1]) + (total - r[:, 1]).max()) / np.median(total)),
         "split_ms_mean": {"pack_build": float(r[:, 0].mean()), "solve": float(r[:, 1].mean()), "plant": float(r[:, 2].mean()),
                           "inverse_update": float(r[:, 3].mean())},

@@ -187,6 +187,8 @@ static inline int gpmpc_check_device(const gpmpc_pack* p) {
 enum { GPMPC_TIME_FULL = 0, GPMPC_TIME_FIRST = 1, GPMPC_TIME_FUSED = 2, GPMPC_TIME_CLASSES = 3 };
 void gpmpc_graph_cache_free(void* cache);
 void gpmpc_cb_cache_free(void* cache);
+void gpmpc_graph_cache_invalidate(void* cache);     // drop the captured graphs, keep streams / events / buffers
+void gpmpc_cb_cache_invalidate(void* cache);
 #define GPMPC_HIP(call)                                              \
     do {                                                             \
         hipError_t e_ = (call);                                      \

@@ -1153,6 +1153,18 @@ void gpmpc_graph_cache_free(void* c) {
     free(g);
 }
 
+// The pack changed under its captured launch sequences (gpmpc_pack_resize: N is baked into the kernel arguments): drop the
+// instantiated graphs, keep the streams, events and staging buffers.
+void gpmpc_graph_cache_invalidate(void* c) {
+    gpmpc_graph_cache* g = (gpmpc_graph_cache*)c;
+    if (!g) return;
+    if (g->stream) (void)hipStreamSynchronize(g->stream);
+    for (int k = 0; k < GPMPC_GRAPH_SLOTS; ++k) {
+        if (g->exec[k]) { (void)hipGraphExecDestroy(g->exec[k]); g->exec[k] = nullptr; }
+        g->valid[k] = 0;
+    }
+}
+
 // number of graph captures this pack has done so far (tests: alternating shapes must not re-capture)
 extern "C" long long gpmpc_pack_graph_captures(const gpmpc_pack* p) {
     const gpmpc_graph_cache* g = p ? (const gpmpc_graph_cache*)p->graph_cache : nullptr;
@@ -1299,6 +1311,14 @@ void gpmpc_cb_cache_free(void* c) {
     if (g->ws) (void)hipFree(g->ws);
     if (g->stream) (void)hipStreamDestroy(g->stream);
     free(g);
+}
+
+void gpmpc_cb_cache_invalidate(void* c) {
+    gpmpc_cb_cache* g = (gpmpc_cb_cache*)c;
+    if (!g) return;
+    if (g->stream) (void)hipStreamSynchronize(g->stream);
+    if (g->exec) { (void)hipGraphExecDestroy(g->exec); g->exec = nullptr; }
+    g->valid = 0;
 }
 
 extern "C" int gpmpc_objective_gradient(gpmpc_pack* p, int H, const double* x0_host, const double* U_host,

@@ -94,7 +94,9 @@ class Dynamics(object):
             Kinv = torch.stack([g.Ky_inv.detach() for g in self.gpr_err])
             lam = np.stack([g.get_lambdas() for g in self.gpr_err])
             sf = np.array([g.get_sigma_f() for g in self.gpr_err])
-            self._pack = GPPack(g0.X_train, Y, Kinv, lam, sf, device=self.device)
+            # the closed loop appends one observation per step: refill the existing pack while its padded size fits
+            if self._pack is None or not self._pack.rebuild(g0.X_train, Y, Kinv, lam, sf):
+                self._pack = GPPack(g0.X_train, Y, Kinv, lam, sf, device=self.device)
             self._pack_key = key
         return self._pack
 

@@ -131,7 +131,7 @@ class RiskSensitiveMPC:
     def _evaluate(self, x):
         x = np.array(x, dtype=np.float64, copy=True).reshape(-1)
         cs, pack, cp = self.curr_state, self.dynamics.pack(), self._cost_params()
-        key = (x.tobytes(), None if cs is None else cs._version, bool(self.full_covariance))
+        key = (x.tobytes(), None if cs is None else cs._version, bool(self.full_covariance), pack.generation)
         held = getattr(self, "_cache_held", (None, None, None))    # kept alive so that `is` cannot alias later objects
         if key != self._cache_key or cs is not held[0] or pack is not held[1] or cp is not held[2]:
             if self.full_covariance:

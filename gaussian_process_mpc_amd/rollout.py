@@ -56,6 +56,14 @@ class GPPack:
         """Y: (N, ds) targets, or the beta vectors themselves when ``y_is_beta`` (then Ky_inv may be
         None: only means and cross-covariances are meaningful)."""
         self.device = device if device is not None else require_gpu()
+        self._h = None
+        self.generation = 0          # bumped by every (re)build: caches keyed on the pack object include it
+        self._ws = {}
+        self._graph_bufs = {}
+        self.fullcov = False
+        self._fill(X, Y, Ky_inv, lambdas, sigma_f, y_is_beta)
+
+    def _fill(self, X, Y, Ky_inv, lambdas, sigma_f, y_is_beta):
         self.X = _dev(X, self.device)
         Y = _dev(Y, self.device)
         self.Y = Y.reshape(self.X.shape[0], -1)
@@ -66,10 +74,11 @@ class GPPack:
             Ky_inv = _dev(Ky_inv, self.device).reshape(self.ds, self.N, self.N)
         self.lambdas = np.ascontiguousarray(np.asarray(lambdas, dtype=np.float64).reshape(self.ds, self.D))
         self.sigma_f = np.ascontiguousarray(np.asarray(sigma_f, dtype=np.float64).reshape(self.ds))
-        h = ctypes.c_void_p()
-        with torch.cuda.device(self.device):       # the pack's HBM buffers belong to THIS device, whatever is current
-            check(lib().gpmpc_pack_create(ctypes.byref(h), self.N, self.ds, self.da), "gpmpc_pack_create")
-        self._h = h
+        if self._h is None:
+            h = ctypes.c_void_p()
+            with torch.cuda.device(self.device):       # the pack's HBM buffers belong to THIS device, whatever is current
+                check(lib().gpmpc_pack_create(ctypes.byref(h), self.N, self.ds, self.da), "gpmpc_pack_create")
+            self._h = h
         _, lp = host_doubles(self.lambdas)
         _, sp = host_doubles(self.sigma_f)
         with torch.cuda.device(self.device):
@@ -78,9 +87,22 @@ class GPPack:
         n, npad, ds, da = (ctypes.c_int() for _ in range(4))
         lib().gpmpc_pack_dims(self._h, ctypes.byref(n), ctypes.byref(npad), ctypes.byref(ds), ctypes.byref(da))
         self.Np = npad.value
-        self._ws = {}
-        self._graph_bufs = {}
-        self.fullcov = False
+        self.generation += 1
+
+    def rebuild(self, X, Y, Ky_inv, lambdas, sigma_f):
+        """Refill THIS pack for new data / hyper-parameters when its allocation fits (same device, dimensions and padded
+        size): no allocation, the library handle survives.  Returns False (pack untouched) when it does not fit."""
+        Xs = X.shape
+        n, D = int(Xs[0]), int(Xs[1])
+        ds = int(Y.shape[1]) if len(Y.shape) > 1 else 1
+        if self._h is None or D != self.D or ds != self.ds or ((n + 63) // 64) * 64 != self.Np:
+            return False
+        with torch.cuda.device(self.device):
+            if n != self.N:
+                check(lib().gpmpc_pack_resize(self._h, n), "gpmpc_pack_resize")
+            self._graph_bufs = {}
+        self._fill(X, Y, Ky_inv, lambdas, sigma_f, False)      # (cross-covariance weights, if enabled, follow every build)
+        return True
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -113,7 +135,7 @@ class GPPack:
         dp = ctypes.POINTER(ctypes.c_double)
         with torch.cuda.device(self.device):
             check(lib().gpmpc_objective_gradient(self._h, H, x0.ctypes.data_as(dp), U.ctypes.data_as(dp), ctypes.byref(cost.c),
-                                                 _lib.WANT_GRAD if want_grad else 0, out.ctypes.data_as(dp), stream_ptr()),
+                                                 _lib.WANT_GRAD if want_grad else 0, out.ctypes.data_as(dp), stream_ptr(self.device)),
                   "gpmpc_objective_gradient")
         return out
 
@@ -138,7 +160,7 @@ class GPPack:
     def workspace(self, nbytes):
         """Scratch for one call, one buffer per stream: calls on different streams may overlap on the device (the C ABI is
         re-entrant across streams as long as the workspaces differ)."""
-        key = torch.cuda.current_stream(self.device).cuda_stream
+        key = torch.cuda.current_stream(self.device.index).cuda_stream
         ws = self._ws.get(key)
         if ws is None or ws.numel() < nbytes:
             if ws is None and len(self._ws) >= 8:            # bounded: drop the workspace of the longest-unused stream

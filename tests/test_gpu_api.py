@@ -582,3 +582,33 @@ def test_g10_readme_regime_through_the_library_and_the_classes(G, golden, si):
             else:
                 np.testing.assert_allclose(c, want, rtol=max(1e-6, 10 * vtol))
                 np.testing.assert_allclose(g, z[f"s{si}_grads"][gi, b], rtol=max(1e-4, 10 * gtol), atol=1e-7)
+
+
+def test_pack_is_refilled_in_place_while_the_padded_size_fits(G, golden):
+    """The closed loop appends one observation per step (src/simulator.py:55): Dynamics.pack() refills the SAME device pack
+    (gpmpc_pack_resize + gpmpc_pack_build: no allocation) while the padded training-set size is unchanged, and allocates a new
+    one when it grows past a multiple of 64.  Values: identical to a pack built from scratch on the same data; the value
+    cache behind objective / gradient notices the refill although the pack object is the same."""
+    z = golden("g3_rollout_c1.npz")
+    N, ds, da, H = (int(v) for v in z["dims"])          # N = 100: padded 128
+    mpc = _mpc_from(G, z, -1.0)
+    mpc.curr_state = torch.tensor(z["x0"][0]).to(mpc.device)
+    x = z["U"][0].reshape(-1).copy()
+    p0 = mpc.dynamics.pack()
+    c0 = mpc.objective(x)
+    rng = np.random.default_rng(3)
+    for k in range(30):                                   # 100 -> 130 points: the padded size changes at 129
+        s, a = rng.uniform(-1, 1, ds), rng.uniform(-1, 1, da)
+        mpc.dynamics.append_train_data(s, a, s + 0.1 * np.tanh(s) + 0.1 * a.sum(), incremental=False)
+        pk = mpc.dynamics.pack()
+        n = mpc.dynamics.gpr_err[0].num_train
+        assert (pk is p0) == (n <= 128), n
+        c = mpc.objective(x)
+        if k == 0:
+            assert c != c0                                # same pack object, new contents: not served from the cache
+        if n in (101, 128, 129, 130):
+            fresh = G.GPPack(mpc.dynamics.gpr_err[0].X_train, torch.cat([g.y_train.reshape(-1, 1) for g in mpc.dynamics.gpr_err], dim=1),
+                             torch.stack([g.Ky_inv for g in mpc.dynamics.gpr_err]), np.stack([g.get_lambdas() for g in mpc.dynamics.gpr_err]),
+                             np.array([g.get_sigma_f() for g in mpc.dynamics.gpr_err]))
+            r = G.rollout(fresh, z["x0"][0], z["U"][0], mpc._cost_params())
+            assert c == r["cost"][0].item(), n

@@ -26,6 +26,7 @@ int main() {
     EXPECT_NEG(gpmpc_pack_create(&pk, 10, 2, -1));
     EXPECT_ZERO(gpmpc_pack_destroy(nullptr));
     EXPECT_NEG(gpmpc_pack_reload_tuning(nullptr));
+    EXPECT_NEG(gpmpc_pack_resize(nullptr, 10));
     EXPECT_ZERO(gpmpc_pack_graph_captures(nullptr));
     EXPECT_NEG(gpmpc_pack_build(nullptr, dummy, dummy, dummy, dummy, dummy, nullptr));
     EXPECT_NEG(gpmpc_pack_build_beta(nullptr, dummy, dummy, nullptr, dummy, dummy, nullptr));

@@ -10,13 +10,13 @@ mkdir -p profiles/r03
 {
 echo "# tools/run_sanitizers.sh  $(date -u +%Y-%m-%dT%H:%MZ)  HEAD $(git rev-parse --short HEAD 2>/dev/null)"
 echo "== (1) host side of the library, -fsanitize=address,undefined (-Xarch_host: host code of csrc/*.hip only)"
-make -C gaussian_process_mpc_amd/csrc -j8 asan-host > /tmp/asan_host_build.log 2>&1 || { echo "BUILD FAILED"; tail -20 /tmp/asan_host_build.log; }
+make -C gaussian_process_mpc_amd/csrc -f Makefile.san -j8 asan-host > /tmp/asan_host_build.log 2>&1 || { echo "BUILD FAILED"; tail -20 /tmp/asan_host_build.log; }
 /opt/rocm/lib/llvm/bin/clang++ -O1 -g -std=c++17 -fsanitize=address,undefined -shared-libsan tools/abi_argcheck.cpp \
     -Lgaussian_process_mpc_amd/csrc -lgpmpc_hip_host_asan -L/opt/rocm/lib -lamdhip64 -Wl,--allow-shlib-undefined -Wl,-rpath,$PWD/gaussian_process_mpc_amd/csrc -o /tmp/abi_argcheck 2>&1 | tail -5
 LD_LIBRARY_PATH=$(dirname $(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)):/opt/rocm/lib:${LD_LIBRARY_PATH:-} ASAN_OPTIONS=detect_leaks=1:abort_on_error=0 UBSAN_OPTIONS=print_stacktrace=1 /tmp/abi_argcheck 2>&1 | tail -40
 echo "exit status: $?"
 echo "== (2) oracle/cport under -fsanitize=address,undefined: CPU tests that drive the C checker"
-make -C oracle/cport asan > /tmp/asan_cport_build.log 2>&1 || { echo "BUILD FAILED"; tail -20 /tmp/asan_cport_build.log; }
+make -C oracle/cport -f Makefile.san asan > /tmp/asan_cport_build.log 2>&1 || { echo "BUILD FAILED"; tail -20 /tmp/asan_cport_build.log; }
 LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 \
     GPMPC_CPORT_LIB=$PWD/oracle/cport/libgpmpc_cpu_asan.so OMP_NUM_THREADS=4 \
     python -m pytest tests/test_oracle_golden.py -q -m "not gpu" -k "cport or yardstick or g10" -p no:cacheprovider 2>&1 | tail -15
