@@ -258,13 +258,12 @@ extern "C" int gpmpc_pack_create(gpmpc_pack** out, int n_train, int state_dim, i
 
 // Re-use a pack for a training set of a different size with the SAME padded size (the closed loop grows the set by one
 // observation per step, src/simulator.py:55: the padded size changes every 64 steps only).  Everything allocated at creation
-// depends on the padded size alone; the captured launch sequences carry N by value and are dropped.
+// depends on the padded size alone, and so do the rollout's launches (rows >= N carry zero weights; no rollout kernel reads
+// N): the captured launch sequences of the pack stay valid and are replayed on the refilled buffers.
 extern "C" int gpmpc_pack_resize(gpmpc_pack* p, int n_train) {
     if (!p || n_train < 1) return GPMPC_E_ARG;
     if (int rc_dev = gpmpc_check_device(p)) return rc_dev;
     if (((n_train + 63) / 64) * 64 != p->Np) return GPMPC_E_ARG;
-    gpmpc_graph_cache_invalidate(p->graph_cache);        // streams, events, pinned staging and workspace (sized by Np) survive
-    gpmpc_cb_cache_invalidate(p->cb_cache);
     p->N = n_train;
     p->built = 0;
     return GPMPC_OK;

@@ -955,6 +955,10 @@ static int split_count(const gpmpc_pack* p, const RollPlan& r, int B, bool lowpr
         S = B / 2 < GPMPC_MAX_SPLIT ? B / 2 : GPMPC_MAX_SPLIT;
         while (S > 1 && (long)(B / S) * r.nwork >= 4096 && B / S < 8) --S;
     }
+    // 256x256 tiling with two trajectories per wave, up to ~8 generations of workgroups: two sub-batches fill each other's partly
+    // filled last generation (N = 2048: B = 48 / 64 / 128 +11 / +9 / +4 %, B = 256 +-0; N = 1024, B = 128 / 256 +6 / +5 %;
+    // one trajectory per wave (D >= 6, N = 4096): -3...-7 %, not split) -- profiles/r03/split_big_ab.txt
+    if (!mid && !r.shared && r.tiling == 0 && r.tb == 2 && B >= 16 && (long)((B + 1) / 2) * r.nwork <= 10000) S = 2;
     if (p->tune.split >= 1) S = p->tune.split;
     if (S > GPMPC_MAX_SPLIT) S = GPMPC_MAX_SPLIT;
     if (S > B) S = B;

@@ -79,7 +79,8 @@ const char* gpmpc_last_error(void);     /* thread-local text of the last failing
 int gpmpc_pack_create(gpmpc_pack** out, int n_train, int state_dim, int action_dim);
 int gpmpc_pack_destroy(gpmpc_pack* pack);
 /* Re-use the pack for n_train points when the padded size (multiple of 64) is unchanged -- GPMPC_E_ARG otherwise --; the pack
- * is "not built" until the next gpmpc_pack_build*.  For the closed loop, where Dynamics.append_train_data adds one
+ * is "not built" until the next gpmpc_pack_build*; captured launch sequences (GPMPC_USE_GRAPH, gpmpc_objective_gradient) stay
+ * valid (no rollout launch depends on the unpadded size).  For the closed loop, where Dynamics.append_train_data adds one
  * observation per step (src/simulator.py:55): no allocation per step. */
 int gpmpc_pack_resize(gpmpc_pack* pack, int n_train);
 /* Re-read the GPMPC_* tuning environment variables for this pack (they are otherwise read once, at
