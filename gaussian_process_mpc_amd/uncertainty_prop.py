@@ -24,6 +24,11 @@ _PACKS = []          # [(key objects, versions, extra, pack)], most recent last
 _PACKS_MAX = 4
 
 
+def clear_pack_cache():
+    """Drop the device packs kept for the functional interface (each holds the N x N weights of one GP)."""
+    _PACKS.clear()
+
+
 def _cached_pack(objs, extra, build):
     """Pack for the tensors `objs` (identity + version) and the hashable `extra`; `build()` makes it."""
     if not all(isinstance(o, torch.Tensor) for o in objs):

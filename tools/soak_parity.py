@@ -17,11 +17,16 @@ from oracle import cport, gpmpc_oracle as O
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 torch.set_num_threads(16)
-KNOBS = ("GPMPC_PAIR_SB", "GPMPC_PAIR_TB", "GPMPC_TILING", "GPMPC_FUSED", "GPMPC_NO_FIRST", "GPMPC_HEAD_CHUNKS")
+KNOBS = ("GPMPC_PAIR_SB", "GPMPC_PAIR_TB", "GPMPC_TILING", "GPMPC_FUSED", "GPMPC_NO_FIRST", "GPMPC_HEAD_CHUNKS", "GPMPC_SHARED",
+         "GPMPC_SB_UNROLL", "GPMPC_SPLIT", "GPMPC_SHARED_NG")
 SHAPES = {"auto": {}, "sb256": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "0"}, "sb64": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "2"},
           "sb_tb1": {"GPMPC_PAIR_SB": "1", "GPMPC_PAIR_TB": "1"}, "staged": {"GPMPC_PAIR_SB": "0", "GPMPC_FUSED": "0"},
           "staged_tb4": {"GPMPC_PAIR_SB": "0", "GPMPC_FUSED": "0", "GPMPC_PAIR_TB": "4"}, "nofirst": {"GPMPC_NO_FIRST": "1"},
-          "chunks3": {"GPMPC_FUSED": "0", "GPMPC_HEAD_CHUNKS": "3"}, "sb64_chunks8": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "2", "GPMPC_HEAD_CHUNKS": "8"}}
+          "chunks3": {"GPMPC_FUSED": "0", "GPMPC_HEAD_CHUNKS": "3"}, "sb64_chunks8": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "2", "GPMPC_HEAD_CHUNKS": "8"},
+          # round 3: four columns in flight / one, concurrent sub-batches forced on and off, shared-lambda group sizes
+          "sb64_u4": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "2", "GPMPC_SB_UNROLL": "4"}, "sb64_u1_split4": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "2", "GPMPC_SB_UNROLL": "1", "GPMPC_SPLIT": "4"},
+          "sb256_split2": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "0", "GPMPC_SPLIT": "2"}, "nosplit": {"GPMPC_SPLIT": "1"},
+          "sh_ng2": {"GPMPC_PAIR_SB": "1", "GPMPC_SHARED_NG": "2"}, "sh_off": {"GPMPC_SHARED": "0"}, "sh_sb64": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "2", "GPMPC_SPLIT": "3"}}
 worst = {"means": 0.0, "vars": 0.0, "cost": 0.0, "grad": 0.0}
 bad = 0
 t_start = time.time()
@@ -36,12 +41,13 @@ for case in range(n_cases):
         B = min(B, 130)
     gamma = float(rng.choice([-1.0, 1e-5, 0.0, 0.5]))
     shape = str(rng.choice(list(SHAPES)))
-    entry = str(rng.choice(["eager", "graph", "callback"] if B == 1 else ["eager", "eager", "graph"]))
-    grad = bool(rng.random() < 0.8) or entry == "callback"
+    entry = str(rng.choice(["eager", "graph", "callback", "autograd"] if B == 1 else ["eager", "eager", "graph", "autograd"]))
+    grad = bool(rng.random() < 0.8) or entry in ("callback", "autograd")
+    shared = bool(rng.random() < 0.45)            # one lambda for every GP: the shared-lambda kernel wherever the sb path runs
     for k in KNOBS:
         os.environ.pop(k, None)
     os.environ.update(SHAPES[shape])
-    pb = synth_problem(5000 + case, N, ds, da, H, B)
+    pb = synth_problem(5000 + case, N, ds, da, H, B, shared_lambda=shared)
     pb["Q"] = pb["Q"] + 0.01 * (np.ones((ds, ds)) - np.eye(ds))
     kinv = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"]).Ky_inv.numpy()
     pack = g.GPPack(pb["X"], pb["Y"], kinv, pb["lambdas"], pb["sigma_f"])          # reads the overrides
@@ -49,6 +55,13 @@ for case in range(n_cases):
     if entry == "callback":
         cg = pack.objective_gradient(pb["x0"][0], pb["U"][0], cp)
         r = {"cost": torch.tensor(cg[:1]), "grad": torch.tensor(cg[1:]).reshape(1, H, da)}
+    elif entry == "autograd":                      # the differentiable boundary: RolloutFunction -> CostFunction -> backward
+        from gaussian_process_mpc_amd.autograd import CostFunction, RolloutFunction
+        Ut = torch.tensor(pb["U"], device=pack.device, requires_grad=True)
+        m, v = RolloutFunction.apply(torch.tensor(pb["x0"], device=pack.device), Ut, pack)
+        cst = CostFunction.apply(m, torch.diag_embed(v), Ut, cp)
+        cst.sum().backward()
+        r = {"means": m.detach(), "vars": v.detach(), "cost": cst.detach(), "grad": Ut.grad}
     else:
         r = g.rollout(pack, pb["x0"], pb["U"], cp, want_grad=grad, graph=(entry == "graph"))
         if entry == "graph":                       # replay once more: the captured graph, not the capture run
@@ -66,7 +79,7 @@ for case in range(n_cases):
     finite = all(bool(torch.isfinite(v).all()) for v in r.values())
     ok = finite and err["means"] < 1e-5 and err["vars"] < 1e-4 and err["cost"] < 1e-6 and err["grad"] < 1e-4
     bad += 0 if ok else 1
-    print(f"case {case:3d}: N={N:4d} ds={ds} da={da} H={H} B={B:4d} gamma={gamma:g} {shape:10s} {entry:8s} grad={int(grad)} "
+    print(f"case {case:3d}: N={N:4d} ds={ds} da={da} H={H} B={B:4d} gamma={gamma:g} {shape:14s} {entry:8s} shared={int(shared)} grad={int(grad)} "
           + " ".join(f"{k} {v:.1e}" for k, v in err.items()) + ("" if ok else "   <-- FAIL"), flush=True)
     for k in worst:
         worst[k] = max(worst[k], err[k])
