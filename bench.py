@@ -62,6 +62,7 @@ def parse_args():
     ap.add_argument("--cl-steps", type=int, default=200)
     ap.add_argument("--cl-horizon", type=int, default=10)
     ap.add_argument("--cl-distinct", action="store_true", help="closed loop: a different lambda per GP (no shared inverse)")
+    ap.add_argument("--cl-async", action="store_true", help="closed loop: the every-64 full rebuild on a side stream (catch-up + swap)")
     ap.add_argument("--cl-rebuild", action="store_true", help="closed loop: the reference's O(N^3) rebuild on every step")
     ap.add_argument("--dist-timeout", type=float, default=120.0, help="process-group timeout in seconds (--gpus > 1)")
     ap.add_argument("--oversubscribe", action="store_true",
@@ -577,7 +578,8 @@ def run_closed_loop(args):
     for i in range(n0):
         plant.state = S[i].copy()
         NS[i] = plant.step(A[i])[0]
-    sync = lambda: torch.cuda.synchronize(dev)            # noqa: E731
+    # phase boundaries: the whole device, or -- with the side-stream rebuild -- the stream the loop itself works on
+    sync = (lambda: torch.cuda.current_stream(dev.index).synchronize()) if args.cl_async else (lambda: torch.cuda.synchronize(dev))  # noqa: E731
     t0 = time.perf_counter(); mpc.dynamics.append_train_data(S, A, NS); sync()
     t_first_build = (time.perf_counter() - t0) * 1e3
     mpc.set_lb([-2.0]); mpc.set_ub([2.0]); mpc.set_xref(np.zeros(2))
@@ -586,7 +588,7 @@ def run_closed_loop(args):
     # one-time load of its kernels: 15-60 ms)
     mpc.dynamics.pack(); a0 = mpc.get_optimal_trajectory(obs)[0, :]
     nxt0 = plant.step(a0)[0]
-    mpc.dynamics.append_train_data(obs, a0, nxt0, incremental=not args.cl_rebuild); sync()
+    mpc.dynamics.append_train_data(obs, a0, nxt0, incremental=not args.cl_rebuild, async_rebuild=args.cl_async); sync()
     obs = nxt0
     n0 += 1
     rows = []
@@ -595,8 +597,9 @@ def run_closed_loop(args):
         mpc.dynamics.pack(); sync(); tb = time.perf_counter()
         action = mpc.get_optimal_trajectory(obs)[0, :]; tc = time.perf_counter()
         nxt, _, _, _, _ = plant.step(action); td = time.perf_counter()
+        before = mpc.dynamics.gpr_err[0]._appends_since_rebuild
         mpc.dynamics.append_train_data(obs, action, nxt, incremental=not args.cl_rebuild); sync(); te = time.perf_counter()
-        rows.append((tb - ta, tc - tb, td - tc, te - td, mpc.dynamics.gpr_err[0]._appends_since_rebuild == 0))
+        rows.append((tb - ta, tc - tb, td - tc, te - td, mpc.dynamics.gpr_err[0]._appends_since_rebuild <= before))
         obs = nxt
     r = np.array([[a, b, c, d] for a, b, c, d, _ in rows]) * 1e3
     full = np.array([x[4] for x in rows])
@@ -608,7 +611,8 @@ def run_closed_loop(args):
                                + ("x (1, 1.1) per GP (distinct)" if args.cl_distinct else "for every GP (the reference's regime)")
                                + ", sigma_n = 1e-3, solver " + str(mpc.solver_used)
                                + (", full O(N^3) rebuild per step (the reference's update)" if args.cl_rebuild else
-                                  ", O(N^2) Schur append per step, full rebuild every 64")},
+                                  ", O(N^2) Schur append per step, full rebuild every 64"
+                                  + (" on a side stream (catch-up + swap)" if args.cl_async else ""))},
         "steps": args.cl_steps,
         "step_ms": {"median": float(np.median(total)), "mean": float(total.mean()), "max": float(total.max()),
                     "p95": float(np.percentile(total, 95)), "max_over_median": float(total.max() / np.median(total))},

@@ -857,7 +857,10 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     // (round 2: 2048 instead of 1024 work items -- below that the one-launch-per-step kernel of step_fused.h wins: N = 2048,
     // B = 2: 1.03 vs 1.19 ms per rollout; N = 1536, B = 4: 1.07 vs 1.23; N = 1024, B = 4: 0.67 vs 1.01)
     // (1700 since the head kernel is split over row chunks: N = 2048, B = 3: 1.16 vs 1.33 ms; N = 1536, B = 6: 1.31 vs 1.40)
-    const bool mid = !big && sb_ok && (long)B * p->wl[0][2].nwork >= 1700;
+    // (round 3, with four columns in flight and concurrent sub-batches on the 256x64 path: from 1250 work items for N >= 1024 --
+    // N = 1024, B = 8 / 10: 0.92 vs 0.99 / 1.00 vs 1.18 ms; smaller training sets stay at 1700: N = 600, B = 16 0.89 vs 0.86 ms,
+    // N = 400, B = 64 0.43 vs 0.38 ms -- profiles/r03/ab_fused_vs_sb_threshold.txt)
+    const bool mid = !big && sb_ok && (long)B * p->wl[0][2].nwork >= (p->Np >= 1024 ? 1250 : 1700);
     r->sb = (sb_ok && (big || mid)) ? 1 : 0;
     const bool many = (long)p->wl[0][1].nwork > 256L * p->ds;        // > 256 one-wave tiles per GP (N >= 1472)
     r->tiling = big ? 0 : (mid ? 2 : (many ? 3 : 1));

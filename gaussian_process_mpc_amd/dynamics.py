@@ -27,9 +27,14 @@ class Dynamics(object):
         self._pack = None
         self._pack_key = None
 
-    def append_train_data(self, state, action, next_state, incremental=False):
+    def append_train_data(self, state, action, next_state, incremental=False, async_rebuild=None):
         """(state, action, next_state) observations, one or many (src/dynamics.py:39-60).  incremental=True: O(N^2)
-        update of every Ky_inv for a single new observation (see GaussianProcessRegression.append_train_data)."""
+        update of every Ky_inv for a single new observation (see GaussianProcessRegression.append_train_data);
+        async_rebuild (True / False; None leaves the GPs' setting): the periodic full rebuild of the incremental path on a
+        side stream instead of on the step that reaches `rebuild_every`."""
+        if async_rebuild is not None:
+            for g in self.gpr_err:
+                g.async_rebuild = bool(async_rebuild)
         state, action, next_state = np.asarray(state), np.asarray(action), np.asarray(next_state)
         # Every GP receives the same input rows; GPs whose hyper-parameters are bit-identical then have identical Ky /
         # Ky_inv and share one build (GaussianProcessRegression.update_many).  That only holds while ALL data went through

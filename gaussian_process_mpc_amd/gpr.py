@@ -35,6 +35,11 @@ class GaussianProcessRegression(object):
         self._built_hypers = None   # (lambdas, sigma_f, noise variance) the current Kf / Ky / Ky_inv were built with
         self._appends_since_rebuild = 0
         self.rebuild_every = 64     # incremental appends between two full rebuilds (bounds the accumulated round-off)
+        # True: the periodic full rebuild runs on a SIDE stream while the appends go on (and the solver keeps using the
+        # incrementally updated inverse); when it has finished, the observations appended meanwhile are re-applied to its
+        # result (O(N^2) each) and the matrices are swapped -- the O(N^3) inverse never sits on an environment step.
+        self.async_rebuild = False
+        self._pending = None        # (n, hypers, Kf, Ky, Ky_inv, event, stream) of a rebuild in flight
         # "lu": torch.linalg.inv, the reference's own call (src/gpr.py:171) and the default, so that Ky_inv carries the
         # reference's round-off.  "cholesky": potrf + potri (SURVEY 8 f1 as sketched): a third of the flops and a symmetric
         # result, but NOT the reference's numerics -- the variances move by ~1e-5 relative at sigma_n = 1e-5.
@@ -110,7 +115,10 @@ class GaussianProcessRegression(object):
         # rebuild, src/gpr.py:53; the reference's append always does, so an edit takes effect there), and its round-off
         # accumulates: fall back to the reference's full rebuild when the hypers changed and every `rebuild_every` appends.
         inc = (incremental and num_obs == 1 and self.num_train > 0 and self.Ky_inv is not None
-               and self._built_hypers == self._current_hypers() and self._appends_since_rebuild < self.rebuild_every)
+               and self._built_hypers == self._current_hypers()
+               and (self._appends_since_rebuild < self.rebuild_every or self.async_rebuild))
+        if not inc:
+            self._pending = None                               # a full rebuild supersedes one in flight
         self.num_train += num_obs
         return "incremental" if inc else "full"
 
@@ -122,6 +130,7 @@ class GaussianProcessRegression(object):
         self.version += 1
         self._built_hypers = other._built_hypers
         self._appends_since_rebuild = other._appends_since_rebuild
+        self._pending = None
 
     def _current_hypers(self):
         return (tuple(float(v) for v in self.get_lambdas()), float(self.get_sigma_f()), self._noise_var())
@@ -140,34 +149,88 @@ class GaussianProcessRegression(object):
                                       ctypes.c_void_p(ws.data_ptr()), ws.numel(), stream_ptr()), "gpmpc_predict")
         return out.reshape(())
 
-    def _append_one_incremental(self, x_new):
-        """self.X_train / y_train already hold the new row (last) and num_train counts it; Kf, Ky, Ky_inv still have the
-        old size n."""
-        n = self.num_train - 1
-        X_old = self.X_train[:n].contiguous()
+    def _schur_append(self, X_old, x_new, Kf, Ky, Kinv):
+        """(Kf, Ky, Ky_inv) of the n points X_old -> the same for X_old + x_new: one O(N^2) Schur-complement step
+        (C ABI ``gpmpc_kinv_append``), on the current stream."""
+        n = X_old.shape[0]
+        X_old = X_old.contiguous()
         sigma_f = self.get_sigma_f()
-        noise = float((torch.exp(self._host("log_sigma_n")) ** 2 * torch.ones(1)).item())
+        noise = self._noise_var()
         _, lp = host_doubles(self.get_lambdas())
         k = torch.empty((1, n), dtype=torch.float64, device=self.device)
         xn = x_new.reshape(1, self.x_dim).contiguous()
         nb = lib().gpmpc_predict_workspace_bytes(n, self.x_dim, 1)
         ws = torch.empty(nb, dtype=torch.uint8, device=self.device)
-        kinv_old = self.Ky_inv.contiguous()
+        kinv_old = Kinv.contiguous()
         out = torch.empty((n + 1, n + 1), dtype=torch.float64, device=self.device)
         nb2 = lib().gpmpc_kinv_append_workspace_bytes(n)
         ws2 = torch.empty(nb2, dtype=torch.uint8, device=self.device)
         with torch.cuda.device(self.device):
             check(lib().gpmpc_predict(n, self.x_dim, ptr(X_old), lp, sigma_f, None, None, 0.0, 1, ptr(xn), ptr(k), None, None,
-                                      ctypes.c_void_p(ws.data_ptr()), nb, stream_ptr()), "gpmpc_predict")
+                                      ctypes.c_void_p(ws.data_ptr()), nb, stream_ptr(self.device)), "gpmpc_predict")
             check(lib().gpmpc_kinv_append(n, ptr(kinv_old), ptr(k), sigma_f ** 2 + noise, ptr(out),
-                                          ctypes.c_void_p(ws2.data_ptr()), nb2, stream_ptr()), "gpmpc_kinv_append")
+                                          ctypes.c_void_p(ws2.data_ptr()), nb2, stream_ptr(self.device)), "gpmpc_kinv_append")
         kff = torch.full((1, 1), sigma_f ** 2, dtype=torch.float64, device=self.device)
-        self.Kf = torch.cat((torch.cat((self.Kf, k.t()), dim=1), torch.cat((k, kff), dim=1)), dim=0)
-        self.Ky = torch.cat((torch.cat((self.Ky, k.t()), dim=1), torch.cat((k, kff + noise), dim=1)), dim=0)
-        self.Ky_inv = out
+        Kf2 = torch.cat((torch.cat((Kf, k.t()), dim=1), torch.cat((k, kff), dim=1)), dim=0)
+        Ky2 = torch.cat((torch.cat((Ky, k.t()), dim=1), torch.cat((k, kff + noise), dim=1)), dim=0)
+        return Kf2, Ky2, out
+
+    def _append_one_incremental(self, x_new):
+        """self.X_train / y_train already hold the new row (last) and num_train counts it; Kf, Ky, Ky_inv still have the
+        old size n."""
+        n = self.num_train - 1
+        self.Kf, self.Ky, self.Ky_inv = self._schur_append(self.X_train[:n], x_new, self.Kf, self.Ky, self.Ky_inv)
         self._beta = None
         self.version += 1
         self._appends_since_rebuild += 1
+        if self.async_rebuild:
+            self._service_async_rebuild()
+
+    def _service_async_rebuild(self):
+        """Side-stream rebuild: start one when `rebuild_every` appends have accumulated; once a started one has finished,
+        bring its result up to date with the observations appended since and swap it in."""
+        if self._pending is not None:
+            n_p, hyp, Kf, Ky, Kinv, ev, side = self._pending
+            if hyp != self._current_hypers():
+                self._pending = None
+            elif ev.query():
+                main = torch.cuda.current_stream(self.device.index)
+                for t in (Kf, Ky, Kinv):
+                    t.record_stream(main)                          # allocated on the side stream, consumed here
+                for m in range(n_p, self.num_train):               # the observations that arrived while it ran
+                    Kf, Ky, Kinv = self._schur_append(self.X_train[:m], self.X_train[m:m + 1], Kf, Ky, Kinv)
+                self.Kf, self.Ky, self.Ky_inv = Kf, Ky, Kinv
+                self._beta = None
+                self.version += 1
+                self._appends_since_rebuild = self.num_train - n_p
+                self._pending = None
+            return
+        if self._appends_since_rebuild < self.rebuild_every:
+            return
+        n = self.num_train
+        X = self.X_train.contiguous()                              # immutable: later appends make new tensors
+        side = getattr(self, "_side_stream", None)
+        if side is None:
+            side = self._side_stream = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream(self.device.index)
+        side.wait_stream(main)                                     # X (and the hyper-parameter copies) are ready
+        _, lp = host_doubles(self.get_lambdas())
+        with torch.cuda.stream(side), torch.cuda.device(self.device):
+            Kf = torch.empty((n, n), dtype=torch.float64, device=self.device)
+            Ky = torch.empty((n, n), dtype=torch.float64, device=self.device)
+            check(lib().gpmpc_build_ky(n, self.x_dim, ptr(X), lp, self.get_sigma_f(), self._noise_var(), ptr(Kf), ptr(Ky),
+                                       ctypes.c_void_p(side.cuda_stream)), "gpmpc_build_ky")
+            Kinv = self._invert(Ky)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        X.record_stream(side)
+        self._pending = (n, self._current_hypers(), Kf, Ky, Kinv, ev, side)
+
+    def finish_async_rebuild(self):
+        """Wait for a side-stream rebuild in flight and swap it in (tests; not needed in the loop)."""
+        if self._pending is not None:
+            self._pending[5].synchronize()
+            self._service_async_rebuild()
 
     def build_Ky_inv_mat(self):
         """Kf, Ky, Ky_inv from scratch (src/gpr.py:159-171)."""

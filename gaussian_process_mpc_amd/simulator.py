@@ -11,7 +11,8 @@ import numpy as np
 class Simulator(object):
     """env: anything with ``reset() -> (obs, info)`` and ``step(action) -> (obs, reward, terminated, truncated, info)``."""
 
-    def __init__(self, mpc, env, num_iters=500, record=False, video_folder=None, name_prefix=None, incremental=False):
+    def __init__(self, mpc, env, num_iters=500, record=False, video_folder=None, name_prefix=None, incremental=False,
+                 async_rebuild=False):
         if record:
             raise NotImplementedError("video recording needs gym's RecordVideo wrapper: wrap the env before passing it in")
         self.mpc = mpc
@@ -19,6 +20,7 @@ class Simulator(object):
         self.num_iters = num_iters
         self.history = []
         self.incremental = incremental      # O(N^2) Ky_inv append per step instead of the reference's O(N^3) rebuild
+        self.async_rebuild = async_rebuild  # ... and its periodic full rebuild on a side stream (off the step's critical path)
 
     def run(self):
         obs, _ = self.env.reset()
@@ -28,7 +30,8 @@ class Simulator(object):
             self.history.append((np.array(obs), np.array(action), float(reward)))
             if terminated or truncated:
                 break
-            self.mpc.dynamics.append_train_data(obs, action, next_obs, incremental=self.incremental)   # :55
+            self.mpc.dynamics.append_train_data(obs, action, next_obs, incremental=self.incremental,
+                                                async_rebuild=self.async_rebuild if self.incremental else None)   # :55
             obs = next_obs
         if hasattr(self.env, "close"):
             self.env.close()

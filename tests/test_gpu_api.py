@@ -612,3 +612,40 @@ def test_pack_is_refilled_in_place_while_the_padded_size_fits(G, golden):
                              np.array([g.get_sigma_f() for g in mpc.dynamics.gpr_err]))
             r = G.rollout(fresh, z["x0"][0], z["U"][0], mpc._cost_params())
             assert c == r["cost"][0].item(), n
+
+
+def test_side_stream_rebuild_catches_up_and_swaps(G):
+    """async_rebuild: the periodic full rebuild of the incremental path runs on a side stream; when it has finished, the
+    observations appended meanwhile are re-applied to its result and the matrices are swapped.  The swapped inverse must be
+    what a rebuild followed by those appends gives (i.e. close to a fresh rebuild: the drift since the snapshot only), the
+    counter must restart from the number of caught-up observations, and predictions must agree with a from-scratch GP."""
+    rng = np.random.default_rng(11)
+    D, n0, extra = 3, 120, 150
+    X = rng.uniform(-2, 2, (n0 + extra, D))
+    y = np.sin(X).sum(axis=1)
+    inc, ref = G.GaussianProcessRegression(D), G.GaussianProcessRegression(D)
+    for g in (inc, ref):
+        g.set_lambdas(np.array([1.5, 2.0, 1.0])); g.set_sigma_n(1e-2); g.set_sigma_f(1.2)
+    inc.rebuild_every, inc.async_rebuild = 16, True
+    inc.append_train_data(X[:n0], y[:n0])
+    swaps, full_on_step = 0, 0
+    for k in range(n0, n0 + extra):
+        before = inc._appends_since_rebuild
+        inc.append_train_data(X[k], float(y[k]), incremental=True)
+        if inc._appends_since_rebuild == 0:
+            full_on_step += 1                               # a synchronous rebuild on the step: must not happen
+        elif inc._appends_since_rebuild <= before:
+            swaps += 1
+            assert 1 <= inc._appends_since_rebuild <= 16    # restarted from the caught-up observations
+    assert full_on_step == 0 and swaps >= extra // 40, (full_on_step, swaps)
+    inc.finish_async_rebuild()
+    ref.append_train_data(X, y)                             # one rebuild from scratch
+    assert inc.num_train == ref.num_train == n0 + extra
+    scale = float(ref.Ky_inv.abs().max())
+    np.testing.assert_allclose(inc.Ky_inv.cpu().numpy(), ref.Ky_inv.cpu().numpy(), rtol=0, atol=1e-7 * scale)
+    np.testing.assert_allclose(inc.Ky.cpu().numpy(), ref.Ky.cpu().numpy(), rtol=1e-12, atol=1e-14)
+    Xp = rng.uniform(-2, 2, (5, D))
+    fi, ci = inc.predict_latent_vars(Xp, covar=True)
+    fr, cr = ref.predict_latent_vars(Xp, covar=True)
+    np.testing.assert_allclose(fi, fr, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(ci, cr, rtol=1e-5, atol=1e-9)
