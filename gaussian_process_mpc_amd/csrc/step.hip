@@ -1233,6 +1233,14 @@ static int enqueue_split(gpmpc_pack* p, gpmpc_graph_cache* g, int S, const RollP
     }
     for (int k = 1; k < S && ef == hipSuccess; ++k) ef = hipStreamWaitEvent(origin, g->ev_join[k - 1], 0);
     if (ef != hipSuccess && rc == GPMPC_OK) { gpmpc_set_error("split launch (fork / join)", ef); rc = GPMPC_E_LAUNCH; }
+    if (rc != GPMPC_OK) {
+        // a sub-batch failed to enqueue: what the others already enqueued on the auxiliary streams still reads the caller's
+        // buffers and is not joined into the caller's stream -- drain it before the error is returned (a stream that is
+        // being captured cannot be synchronised: ending the capture discards its work)
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(origin, &st) == hipSuccess && st == hipStreamCaptureStatusNone)
+            for (int k = 0; k < S - 1; ++k) (void)hipStreamSynchronize(g->aux[k]);
+    }
     return rc;
 }
 

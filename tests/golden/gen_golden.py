@@ -29,6 +29,8 @@ Fixtures:
   g11_fullsize_pin.npz reference-produced mean / variance of every GP at N = 2048 (C3 training set re-derived from the
                        seed) for two single-step queries
 
+  g12_fullsize_rollout.npz reference-produced objective / gradient / trajectory of two plans at N = 2048, H = 2
+
 g9 imports src/environments/*, which need ``gym`` (absent here).  A minimal stand-in module (``gym.Env`` as a bare base
 class, ``spaces.Box`` recording its arguments, ``seeding.np_random``, ``error.DependencyNotInstalled``) is registered
 for that import only; none of the arithmetic captured below goes through it.
@@ -483,10 +485,37 @@ def g11():
     np.savez(os.path.join(OUT, "g11_fullsize_pin.npz"), **out)
 
 
+def g12():
+    """The WHOLE path at full size, produced by the reference: objective + gradient (rollout, cost, autograd backward) of two
+    candidate plans at N = 2048, ds = 4, da = 1 (the C3 training set of gaussian_process_mpc_amd/synth.py, seed 1003), H = 2
+    (a full-horizon reference run needs ~46 GiB), gamma = -1.  Inputs are re-derived from the seed by the tests."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from gaussian_process_mpc_amd.synth import synth_problem
+    N, ds, da, H = 2048, 4, 1, 2
+    pb = synth_problem(3, N, ds, da, 20, 8)
+    mpc = RiskSensitiveMPC(-1.0, H, ds, da, pb["Q"], pb["R"], None)
+    for a in range(ds):
+        g = mpc.dynamics.gpr_err[a]
+        g.set_lambdas(pb["lambdas"][a]); g.set_sigma_n(float(pb["sigma_n"][a])); g.set_sigma_f(1.0)
+    mpc.dynamics.append_train_data(pb["X"][:, :ds], pb["X"][:, ds:], pb["Y"])
+    out = {"dims": np.array([N, ds, da, H]), "seed": np.array([3]), "traj": np.array([0, 5]), "gamma": np.array([-1.0]),
+           "means": np.zeros((2, H + 1, ds)), "vars": np.zeros((2, H + 1, ds)), "cost": np.zeros(2), "grad": np.zeros((2, H, da))}
+    for k, b in enumerate(out["traj"]):
+        mpc.curr_state = torch.tensor(pb["x0"][b]).type(torch.float64)
+        mpc.curr_cost = None
+        x = pb["U"][b, :H].reshape(-1).copy()
+        out["cost"][k] = mpc.objective(x)
+        out["grad"][k] = np.asarray(mpc.gradient(x)).reshape(H, da)
+        sm, sc = mpc.dynamics.forward_propagate_torch(H, mpc.curr_state, torch.tensor(pb["U"][b, :H]).type(torch.float64))
+        out["means"][k] = torch.stack(sm).detach().numpy()
+        out["vars"][k] = torch.stack([torch.diag(c) for c in sc]).detach().numpy()
+    np.savez(os.path.join(OUT, "g12_fullsize_rollout.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12):
         if only and fn.__name__ not in only:
             continue
         fn()

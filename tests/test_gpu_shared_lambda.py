@@ -124,3 +124,16 @@ def test_c3_sizes_shared_lambda_vs_cport(G):
     m, v = RolloutFunction.apply(torch.tensor(pb["x0"][:8], device=pack.device), U, pack)
     np.testing.assert_allclose(m.detach().cpu().numpy(), r8["means"].cpu().numpy(), rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(v.detach().cpu().numpy(), r8["vars"].cpu().numpy(), rtol=1e-7)
+
+
+def test_c4_sizes_shared_lambda_vs_cport(G):
+    """N = 4096, ds = 6, da = 1 with one lambda for all GPs: groups of three GPs per workgroup (the NG = 3 instances at D = 7),
+    B = 24 on the 256x256 shared list, two trajectories over H = 6 steps against the C port."""
+    torch.set_num_threads(16)
+    pb, kinv = _problem(4, 4096, 6, 1, 6, 24)
+    pack = G.GPPack(pb["X"], pb["Y"], kinv, pb["lambdas"], pb["sigma_f"])
+    assert pack.shared_lambda
+    cost = G.CostParams(-1.0, pb["Q"], pb["R"])
+    r = G.rollout(pack, pb["x0"], pb["U"], cost)
+    assert all(torch.isfinite(v).all() for v in r.values())
+    _check_vs_cport(r, pb, kinv, [0, 23], "C4 sizes shared")

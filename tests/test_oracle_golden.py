@@ -373,3 +373,20 @@ def test_g11_reference_scalars_at_full_size(golden):
                                 mode="faithful" if (q, a) == (1, 2) else "o2")
             np.testing.assert_allclose(m.item(), z["mean"][q, a], rtol=1e-7)
             np.testing.assert_allclose(v.item(), z["var"][q, a], rtol=1e-5)
+
+
+def test_g12_reference_rollout_at_full_size(golden):
+    """Oracle (O(N^2) mode) against the reference's own objective / gradient / trajectory at N = 2048, H = 2 (g12)."""
+    from gaussian_process_mpc_amd.synth import synth_problem
+    z = golden("g12_fullsize_rollout.npz")
+    N, ds, da, H = (int(v) for v in z["dims"])
+    pb = synth_problem(int(z["seed"][0]), N, ds, da, 20, 8)
+    torch.set_num_threads(8)
+    gp = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"])
+    b = int(z["traj"][0])
+    r = O.objective_and_gradient(gp, H, pb["x0"][b], pb["U"][b, :H], pb["x_ref"], pb["u_ref"], pb["Q"], pb["R"], float(z["gamma"][0]),
+                                 mode="o2")
+    np.testing.assert_allclose(r["means"], z["means"][0], rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(r["vars"], z["vars"][0], rtol=1e-5)
+    np.testing.assert_allclose(r["cost"], z["cost"][0], rtol=1e-7)
+    np.testing.assert_allclose(r["grad"], z["grad"][0], rtol=1e-4, atol=1e-8)
