@@ -115,6 +115,21 @@ class Dynamics(object):
             return rollout_fullcov(self.pack(), curr_state, actions, cost, want_grad=want_grad)
         return rollout(self.pack(), curr_state, actions, cost, want_grad=want_grad, want_traj=True)
 
+    def forward_propagate(self, horizon, curr_state, actions):
+        """The reference's numpy rollout (src/dynamics.py:62-124; its slow double-loop oracle, sigma_f = 1 only) with the same
+        signature and return types -- numpy (H+1, ds) means and (H+1, ds, ds) diagonal covariances -- evaluated by the HIP
+        path.  One documented difference: the numpy version adds an action-noise variance of exactly 1e-3, the torch version
+        (and this library) float32(1e-3) (src/dynamics.py:162); the reference's own test holds the two to 1e-7
+        (src/test/test_dynamics.py:134-196) and so do these values."""
+        r = self.rollout(np.asarray(curr_state, dtype=np.float64).reshape(self.state_dim),
+                         np.asarray(actions, dtype=np.float64).reshape(horizon, self.action_dim))
+        means = r["means"][0].cpu().numpy()
+        covars = np.zeros((horizon + 1, self.state_dim, self.state_dim))
+        v = r["vars"][0].cpu().numpy()
+        for t in range(horizon + 1):
+            covars[t] = np.diag(v[t])
+        return means, covars
+
     def forward_propagate_torch(self, horizon, curr_state, actions):
         """Means and (diagonal) covariances of the H-step shooting rollout (src/dynamics.py:126-191).
         Returns (list of H+1 (ds,) tensors, list of H+1 (ds,ds) tensors) on the device.  Like the reference's, the

@@ -649,3 +649,16 @@ def test_side_stream_rebuild_catches_up_and_swaps(G):
     fr, cr = ref.predict_latent_vars(Xp, covar=True)
     np.testing.assert_allclose(fi, fr, rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(ci, cr, rtol=1e-5, atol=1e-9)
+
+
+def test_numpy_forward_propagate_signature(G, golden):
+    """Dynamics.forward_propagate (the reference's numpy rollout, src/dynamics.py:62-124): numpy in, numpy (H+1, ds) /
+    (H+1, ds, ds) out, values of the torch rollout (the reference's own rung-4 test holds the two to 1e-7)."""
+    z = golden("g3_rollout_c1.npz")
+    N, ds, da, H = (int(v) for v in z["dims"])
+    mpc = _mpc_from(G, z, -1.0)
+    means, covs = mpc.dynamics.forward_propagate(H, z["x0"][0], z["U"][0])
+    assert isinstance(means, np.ndarray) and means.shape == (H + 1, ds) and covs.shape == (H + 1, ds, ds)
+    np.testing.assert_allclose(means, z["means"][0], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(np.diagonal(covs, axis1=1, axis2=2), z["vars"][0], rtol=1e-5)
+    assert np.all(covs[3] - np.diag(np.diag(covs[3])) == 0)
