@@ -315,9 +315,16 @@ static int pack_build_impl(gpmpc_pack* p, const double* X_dev, const double* Y_d
     }
     // every GP with bit-identical length-scales (the reference's experiments): the rollout may share exponent and exp
     // across the GPs of a pair (pair_kernel_sbs.h)
+    const int shared_before = p->shared_lambda;
     p->shared_lambda = p->sh_ng > 0 ? 1 : 0;
     for (int a = 1; a < p->ds && p->shared_lambda; ++a)
         if (memcmp(p->lam_host[a], p->lam_host[0], sizeof(double) * p->D) != 0) p->shared_lambda = 0;
+    // a captured launch sequence carries the kernel choice of the build it was captured under: the shared-lambda kernel
+    // replayed on a pack whose lambdas have since become distinct would be WRONG (not just slow)
+    if (p->shared_lambda != shared_before) {
+        gpmpc_graph_cache_invalidate(p->graph_cache);
+        gpmpc_cb_cache_invalidate(p->cb_cache);
+    }
     // hyper-parameters are tiny; pageable-host copies are staged synchronously by the runtime
     GPMPC_HIP(hipMemcpyAsync(p->lam, lambdas_host, sizeof(double) * p->ds * p->D, hipMemcpyHostToDevice, s));
     GPMPC_HIP(hipMemcpyAsync(p->sf, sigma_f_host, sizeof(double) * p->ds, hipMemcpyHostToDevice, s));

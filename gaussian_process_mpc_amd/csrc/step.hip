@@ -1394,6 +1394,14 @@ extern "C" int gpmpc_objective_gradient(gpmpc_pack* p, int H, const double* x0_h
         (void)hipStreamSynchronize(g->stream);
         if (g->exec) { (void)hipGraphExecDestroy(g->exec); g->exec = nullptr; }
         g->valid = 0;
+        // the pack may have been refilled under a plan that needs more scratch (e.g. lambdas no longer shared: G rows per GP)
+        const size_t need = gpmpc_rollout_workspace_bytes(p, 1, H, GPMPC_WANT_GRAD);
+        if (need > g->ws_bytes) {
+            if (g->ws) (void)hipFree(g->ws);
+            g->ws = nullptr; g->ws_bytes = 0;
+            if (hipError_t ea = hipMalloc(&g->ws, need); ea != hipSuccess) { gpmpc_set_error("gpmpc_objective_gradient: workspace", ea); g->cap_H = 0; return GPMPC_E_ALLOC; }
+            g->ws_bytes = need;
+        }
         hipGraph_t graph = nullptr;
         GPMPC_HIP(hipStreamBeginCapture(g->stream, hipStreamCaptureModeThreadLocal));
         hipError_t e1 = hipMemcpyAsync(g->d_in, g->h_in, sizeof(double) * nin, hipMemcpyHostToDevice, g->stream);

@@ -100,7 +100,6 @@ class GPPack:
         with torch.cuda.device(self.device):
             if n != self.N:
                 check(lib().gpmpc_pack_resize(self._h, n), "gpmpc_pack_resize")
-            self._graph_bufs = {}
         self._fill(X, Y, Ky_inv, lambdas, sigma_f, False)      # (cross-covariance weights, if enabled, follow every build)
         return True
 
@@ -239,6 +238,8 @@ def rollout(pack, x0, U, cost, want_grad=True, want_traj=True, graph=False, prec
             if len(pack._graph_bufs) >= 4:                   # the library keeps 4 captured shapes per pack
                 pack._graph_bufs.pop(next(iter(pack._graph_bufs)))
             pack._graph_bufs[key] = buf
+        if buf["ws"].numel() < nbytes:                          # the pack was refilled under a plan that needs more scratch
+            buf["ws"] = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)     # (new pointer: the library captures anew)
         buf["x0"].copy_(x0)
         if U_host is not None:
             # the previous copy out of the pinned buffer has completed: every graph call is followed by a synchronising

@@ -137,3 +137,23 @@ def test_c4_sizes_shared_lambda_vs_cport(G):
     r = G.rollout(pack, pb["x0"], pb["U"], cost)
     assert all(torch.isfinite(v).all() for v in r.values())
     _check_vs_cport(r, pb, kinv, [0, 23], "C4 sizes shared")
+
+
+def test_captured_graphs_follow_a_change_of_the_lambda_sharing(G):
+    """A pack refilled in place (GPPack.rebuild) keeps its captured launch sequences -- unless the refill changes whether the
+    lambdas are shared: a graph captured with the shared-lambda kernel must not be replayed on distinct lambdas (and the other
+    way round the replay would merely be slow).  Graph-replayed values after each refill == eager values of a fresh pack."""
+    pb, kinv = _problem(9, 700, 3, 1, 4, 40, shared=True)
+    pbd, kinvd = _problem(9, 700, 3, 1, 4, 40, shared=False)
+    cost = G.CostParams(-1.0, pb["Q"], pb["R"])
+    pack = G.GPPack(pb["X"], pb["Y"], kinv, pb["lambdas"], pb["sigma_f"])
+    X, Y = torch.as_tensor(pb["X"], device=pack.device), torch.as_tensor(pb["Y"], device=pack.device)
+    for step, (lam, kv, want_shared) in enumerate([(pb["lambdas"], kinv, True), (pbd["lambdas"], kinvd, False), (pb["lambdas"], kinv, True)]):
+        if step > 0:
+            assert pack.rebuild(X, Y, torch.as_tensor(kv, device=pack.device), lam, pb["sigma_f"])
+        assert pack.shared_lambda == want_shared
+        g1 = G.rollout(pack, pb["x0"], pb["U"], cost, graph=True)
+        g2 = G.rollout(pack, pb["x0"], pb["U"], cost, graph=True)           # the replay
+        fresh = G.rollout(G.GPPack(pb["X"], pb["Y"], kv, lam, pb["sigma_f"]), pb["x0"], pb["U"], cost)
+        for k in ("cost", "grad", "means", "vars"):
+            assert torch.equal(g2[k], fresh[k]) and torch.equal(g1[k], fresh[k]), (step, k)
