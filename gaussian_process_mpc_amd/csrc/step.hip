@@ -953,10 +953,16 @@ static int split_count(const gpmpc_pack* p, const RollPlan& r, int B, bool lowpr
     // measured (tools/env_ab.py --var GPMPC_SPLIT, profiles/r03/split_ab.txt): N = 1024, B = 16: 11.3 -> 13.8 (2 branches) -> 14.3 k
     // rollouts/s (4); N = 2048, B = 4 / 16: +15 % / +13 %; a branch must keep at least two trajectories, and branches whose
     // pair launch alone fills the chip twice over gain nothing unless they are wide (N = 4096, B = 2 as 1 + 1: -20 %)
+    // A caller who needs each result before the next call (a solver loop) sees the latency of ONE call: there every extra
+    // branch also costs launch work up front, and a branch must keep ~900 workgroups per pair launch to pay for itself
+    // (N = 1024, B = 16, synchronising after every call: 2 branches x1.12, 4 branches x0.93-1.02; B = 32: 4 branches x1.09-1.13;
+    // with calls queued back to back 4 branches give x1.27 / x1.24 -- profiles/r03/split_latency_vs_throughput.txt).
     int S = 1;
     if (mid && B >= 4) {
         S = B / 2 < GPMPC_MAX_SPLIT ? B / 2 : GPMPC_MAX_SPLIT;
         while (S > 1 && (long)(B / S) * r.nwork >= 4096 && B / S < 8) --S;
+        while (S > 1 && (long)(B / S) * r.nwork < 900) --S;
+        if (S == 3) S = 2;
     }
     // 256x256 tiling with two trajectories per wave, up to ~8 generations of workgroups: two sub-batches fill each other's partly
     // filled last generation (N = 2048: B = 48 / 64 / 128 +11 / +9 / +4 %, B = 256 +-0; N = 1024, B = 128 / 256 +6 / +5 %;

@@ -44,7 +44,7 @@ for shape in args.shapes.split(","):
         U = torch.as_tensor(pb["U"][:B], device=dev)
         graph = B < 32 and not args.fullcov
         run = (lambda: rollout_fullcov(pack, x0, U, cost)) if args.fullcov else (lambda: rollout(pack, x0, U, cost, want_grad=True, want_traj=False, graph=graph))
-        reps = max(3, min(200, int((2e9 if args.quick else 8e9) / (B * H * (ds * ds if args.fullcov else ds) * N * N / 2 * 30))))
+        reps = max(10, min(200, int((2e9 if args.quick else 8e9) / (B * H * (ds * ds if args.fullcov else ds) * N * N / 2 * 30))))
         for _ in range(3):
             run()
         torch.cuda.synchronize()

@@ -16,6 +16,7 @@ ap.add_argument("--values", required=True, help="comma separated; 'unset' remove
 ap.add_argument("--bitwise", action="store_true")
 ap.add_argument("--eager", action="store_true", help="plain launches instead of graph replay")
 ap.add_argument("--shared-lambda", action="store_true")
+ap.add_argument("--sync-each", action="store_true", help="synchronise after every call (the latency a caller sees who needs each result)")
 ap.add_argument("shapes", nargs="*")
 args = ap.parse_args()
 shapes = args.shapes or ["1024:4:1:20:8", "1024:4:1:20:12", "1024:4:1:20:16", "1024:4:1:20:24", "1024:4:1:20:32", "1024:4:1:20:64",
@@ -58,7 +59,10 @@ for shape in shapes:
         for _ in range(3): run()
         torch.cuda.synchronize(); t0 = time.perf_counter()
         reps = 20
-        for _ in range(reps): run()
+        for _ in range(reps):
+            run()
+            if args.sync_each:
+                torch.cuda.synchronize()
         torch.cuda.synchronize(); t[v] = min(t.get(v, 1e9), (time.perf_counter() - t0) / reps)
     os.environ.pop(args.var, None)
     base = t[values[0]]
