@@ -828,7 +828,7 @@ int gpmpc_timed_pair_sbf(int D, bool grad, int ns2, int waves, const PairSbfArgs
     return timed_launch(GPMPC_TIME_FULL, s, [&] { return gpmpc_launch_pair_sbf(D, grad, ns2, waves, a, s); });
 }
 
-struct RollPlan { int tiling, tb, waves, nwork, nm, pps, sps, sb, gw, rgroup, fused, fq, hchunks, hrows, shared, sh_list, persist /* columns per iteration of the sb kernel */; size_t off_mpart; size_t off_G; size_t off_pp, off_sp, off_part, off_partz, off_jac, off_means, off_vars, total; };
+struct RollPlan { int tiling, tb, waves, nwork, nm, pps, sps, sb, gw, rgroup, fused, fq, hchunks, hrows, shared, sh_list, colunroll /* columns per iteration of the sb kernel */; size_t off_mpart; size_t off_G; size_t off_pp, off_sp, off_part, off_partz, off_jac, off_means, off_vars, total; };
 
 // shape (optional): take every SHAPE decision (tiling, kernel, trajectories per wave, row chunks ...) from this plan of a larger
 // batch and only size the buffers for B: the sub-batches of a split call then run exactly the launches the whole batch would,
@@ -906,12 +906,12 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     // Columns per iteration of the scalar-broadcast kernel: 4 on the 256x64 tiling (mid-size batches: latency tolerance of
     // the partly filled generations, pair_kernel_sb.h), 1 on full launches.
     // (tools/env_ab.py --var GPMPC_SB_UNROLL: +8...14 % up to ~2 generations of workgroups, -4 % from ~4 on)
-    r->persist = (r->sb && !r->shared && !lowprec && r->tiling == 2 && r->tb == 1 && tn.colunroll != 1 &&
+    r->colunroll = (r->sb && !r->shared && !lowprec && r->tiling == 2 && r->tb == 1 && tn.colunroll != 1 &&
                   ((long)B * r->nwork <= 4096 || tn.colunroll == 4)) ? 4 : 1;
     if (shape) {
         r->tiling = shape->tiling; r->tb = shape->tb; r->waves = shape->waves; r->nwork = shape->nwork; r->sb = shape->sb;
         r->rgroup = shape->rgroup; r->fused = shape->fused; r->fq = shape->fq; r->shared = shape->shared; r->sh_list = shape->sh_list;
-        r->persist = shape->persist;
+        r->colunroll = shape->colunroll;
     }
     r->nm = gpmpc_num_moments(D, diag, grad);
     r->pps = D + D * D;
@@ -1104,7 +1104,7 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
             Q.M = p->M; Q.XT = p->XT; Q.pp = A.pp; Q.G = A.G; Q.part = A.part; Q.work = P.work;
             Q.Np = p->Np; Q.B = B; Q.ds = p->ds; Q.nwork = r.nwork; Q.pps = r.pps; Q.nm = r.nm; Q.rgroup = r.rgroup;
             Q.first_step = (t == 1 && !p->tune.no_first && !full_first) ? 1 : 0;
-            Q.colunroll = r.persist;
+            Q.colunroll = r.colunroll;
             rc = gpmpc_timed_pair_sb(p->D, grad, r.tb, p->ds, r.waves, Q, s);
         } else {
             rc = gpmpc_timed_pair(p->D, true, grad, r.tb, P.colsplit ? 4 : r.waves, P, s);
