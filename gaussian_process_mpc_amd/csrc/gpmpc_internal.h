@@ -25,6 +25,7 @@ struct gpmpc_worklist {
     int nunits, nwork;
     int contiguous;     // items of a unit are contiguous (ustart valid); 0: XCD-sorted order, look the unit up per item
     int* work_dev;      // [nwork][4]
+    int* perm_dev;      // [nwork] item indices grouped by unit (XCD-sorted lists only, else null): unit u owns perm[ustart[u] .. ustart[u+1])
     int* ustart_dev;    // [nunits + 1]
     int ustart_host[GPMPC_MAX_DS + GPMPC_MAX_PAIRS + 1];
 };

@@ -172,6 +172,16 @@ static int build_worklist(int Np, int it, int jt, int ds, int npairs, bool xcd_s
     w->it = it; w->waves = it / 64 > 0 ? it / 64 : 1; w->jt = jt; w->nunits = ds + npairs; w->nwork = n;
     hipError_t e = hipMalloc(&w->work_dev, sizeof(int) * 4 * (size_t)n);
     if (e == hipSuccess) e = hipMemcpy(w->work_dev, h, sizeof(int) * 4 * (size_t)n, hipMemcpyHostToDevice);
+    w->perm_dev = nullptr;
+    if (e == hipSuccess && !w->contiguous) {                      // per-unit index of the re-ordered list (finish_step, step.hip)
+        int* perm = (int*)malloc(sizeof(int) * (size_t)n);
+        int fill[GPMPC_MAX_DS + GPMPC_MAX_PAIRS + 1];
+        for (int u = 0; u <= ds + npairs; ++u) fill[u] = w->ustart_host[u];
+        for (int k = 0; k < n; ++k) perm[fill[h[4 * k]]++] = k;
+        e = hipMalloc(&w->perm_dev, sizeof(int) * (size_t)n);
+        if (e == hipSuccess) e = hipMemcpy(w->perm_dev, perm, sizeof(int) * (size_t)n, hipMemcpyHostToDevice);
+        free(perm);
+    }
     if (e == hipSuccess) e = hipMalloc(&w->ustart_dev, sizeof(int) * (ds + npairs + 1));
     if (e == hipSuccess) e = hipMemcpy(w->ustart_dev, w->ustart_host, sizeof(int) * (ds + npairs + 1), hipMemcpyHostToDevice);
     free(h);
@@ -283,10 +293,12 @@ extern "C" int gpmpc_pack_destroy(gpmpc_pack* p) {
     for (int mode = 0; mode < 2; ++mode)
         for (int k = 0; k < 4; ++k) {
             if (p->wl[mode][k].work_dev) (void)hipFree(p->wl[mode][k].work_dev);
+            if (p->wl[mode][k].perm_dev) (void)hipFree(p->wl[mode][k].perm_dev);
             if (p->wl[mode][k].ustart_dev) (void)hipFree(p->wl[mode][k].ustart_dev);
         }
     for (int k = 0; k < 2; ++k) {
         if (p->wl_sh[k].work_dev) (void)hipFree(p->wl_sh[k].work_dev);
+        if (p->wl_sh[k].perm_dev) (void)hipFree(p->wl_sh[k].perm_dev);
         if (p->wl_sh[k].ustart_dev) (void)hipFree(p->wl_sh[k].ustart_dev);
     }
     free(p);

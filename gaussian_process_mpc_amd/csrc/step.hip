@@ -20,6 +20,17 @@
 #include "fast_exp.h"
 #include <cstdlib>
 
+// Diagnostic build (-DGPMPC_SB_STAMPS): phase stamps of the head kernel, workgroup (0, 0, 0) of horizon step 5 (tools/sb_stamps.py)
+#ifdef GPMPC_SB_STAMPS
+static __device__ unsigned long long g_head_stamps[16];
+#define GPMPC_HST(slot) do { if (t == 5 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_head_stamps[slot] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int gpmpc_debug_head_stamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_head_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -3;
+}
+#else
+#define GPMPC_HST(slot) do { } while (0)
+#endif
+
 struct RollArgs {
     // pack
     const double* XT; const double* beta; const double* lam; const double* sf;
@@ -36,6 +47,7 @@ struct RollArgs {
     int ust_inline;    // ust[] below replaces ustart (the fused path splits tiles into column pieces: its own item ranges)
     int ust[GPMPC_MAX_DS + 1];
     const int* work;   // [nwork][4] when the items of a unit are NOT contiguous (XCD-sorted list), else null
+    const int* perm;   // ... and then the item indices grouped by unit (ascending within a unit): unit a owns perm[ustart[a] .. ustart[a+1])
     double* jac;   // [B][H][2ds][2ds+da] or null
     double* G;     // [B][ds][Np][gw] column rows of the scalar-broadcast pair kernel, or null
     int gw;
@@ -65,6 +77,13 @@ __device__ static void finish_step(const RollArgs& A, int b, int t, int own, dou
                                    double* s_ms /* [MAX_DS*(1+2 MAX_D) + 4 MAX_DS] */) {
     const int ds = A.ds, D = A.D, nm = A.nm;
     const bool chunked = A.hchunks > 1;
+    // the per-GP scalars of step t, fetched in ONE coalesced round trip that overlaps the reduction below (they were read one by
+    // one, each its own round trip, by the ds threads that finish the step)
+    __shared__ double s_spv[GPMPC_MAX_DS * (3 + 4 * GPMPC_MAX_D)];
+    {
+        const double* spb = A.sp + ((size_t)(t & 1) * A.B + b) * ds * A.sps;
+        for (int e = threadIdx.x; e < ds * A.sps; e += blockDim.x) s_spv[e] = spb[e];
+    }
     if (chunked) {      // mean sums of step t: the row chunks' partial sums, combined in chunk order
         const int nv = 1 + 2 * D;
         for (int o = threadIdx.x; o < ds * nv; o += blockDim.x) {
@@ -165,19 +184,24 @@ __device__ static void finish_step(const RollArgs& A, int b, int t, int own, dou
     } else {
         // Few items per GP: GPMPC_RED_CH threads share one output (each a strided subset of the work items, so the
         // global loads of a pass are independent), then a fixed-order combine.
+        // Four loads in flight per thread (this reduction is a chain of L2 round trips, not of arithmetic: it was 44 % of the
+        // head kernel at N = 1024, B = 16 with one load at a time); the XCD-sorted list is walked through its per-unit index
+        // (perm) instead of filtering all items.
         const int nout = ds * nm, ch = threadIdx.x % GPMPC_RED_CH, per_pass = blockDim.x / GPMPC_RED_CH;
         for (int o0 = 0; o0 < nout; o0 += per_pass) {
             const int o = o0 + threadIdx.x / GPMPC_RED_CH;
             if (o < nout) {
                 const int a = o / nm, m = o - a * nm;
                 const double* p = A.part + (size_t)b * A.nwork * nm + m;
+                const int w0 = A.ust_inline ? A.ust[a] : A.ustart[a], w1 = A.ust_inline ? A.ust[a + 1] : A.ustart[a + 1];
+                const int* __restrict__ pm = (!A.ust_inline && A.work) ? A.perm : nullptr;
                 double s = 0.0;
-                if (A.ust_inline) {
-                    for (int wi = A.ust[a] + ch; wi < A.ust[a + 1]; wi += GPMPC_RED_CH) s += p[(size_t)wi * nm];
-                } else if (A.work) {
-                    for (int wi = ch; wi < A.nwork; wi += GPMPC_RED_CH) if (A.work[4 * wi] == a) s += p[(size_t)wi * nm];
-                } else {
-                    for (int wi = A.ustart[a] + ch; wi < A.ustart[a + 1]; wi += GPMPC_RED_CH) s += p[(size_t)wi * nm];
+                for (int k = w0 + ch; k < w1; k += 4 * GPMPC_RED_CH) {
+                    const int k1 = k + GPMPC_RED_CH, k2 = k + 2 * GPMPC_RED_CH, k3 = k + 3 * GPMPC_RED_CH;
+                    const int c1 = k1 < w1 ? k1 : k, c2 = k2 < w1 ? k2 : k, c3 = k3 < w1 ? k3 : k;      // clamped: no divergent loads
+                    const int i0 = pm ? pm[k] : k, i1 = pm ? pm[c1] : c1, i2 = pm ? pm[c2] : c2, i3 = pm ? pm[c3] : c3;
+                    const double v0 = p[(size_t)i0 * nm], v1 = p[(size_t)i1 * nm], v2 = p[(size_t)i2 * nm], v3 = p[(size_t)i3 * nm];
+                    s += (v0 + (k1 < w1 ? v1 : 0.0)) + ((k2 < w1 ? v2 : 0.0) + (k3 < w1 ? v3 : 0.0));
                 }
                 s_red[o * GPMPC_RED_CH + ch] = s;
             }
@@ -192,7 +216,7 @@ __device__ static void finish_step(const RollArgs& A, int b, int t, int own, dou
     __syncthreads();
     if (threadIdx.x < ds) {
         const int a = threadIdx.x;
-        const double* sp = A.sp + (((size_t)(t & 1) * A.B + b) * ds + a) * A.sps;
+        const double* sp = s_spv + a * A.sps;
         const double* z = s_z + a * nm;
         const double* ms = s_ms + a * (1 + 2 * D);
         const double cm = sp[1];                                   // chunked layout only
@@ -261,6 +285,7 @@ __device__ static void prep_step(const RollArgs& A, int b, int t, int a, int chu
         s_r2[k] = 2.0 * sk / lam + 1.0;
     }
     __syncthreads();
+    GPMPC_HST(2);
     double u[D], Bk[D], sck[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) {
@@ -275,13 +300,28 @@ __device__ static void prep_step(const RollArgs& A, int b, int t, int a, int chu
     for (int m = 0; m < 1 + 2 * D; ++m) v[m] = 0.0;
     const bool chunked = A.hchunks > 1;
     const int r0 = chunked ? chunk * A.hrows : 0, r1 = chunked ? (r0 + A.hrows < A.Np ? r0 + A.hrows : A.Np) : A.Np;
-    for (int i0 = r0; i0 < r1; i0 += blockDim.x) {           // uniform trip count: the G rows go through LDS
+    // The points of up to PF row blocks are fetched first (clamped addresses, one round trip for all of them), then the blocks
+    // are evaluated in order: same per-thread summation order as a plain loop, a quarter of the exposed load latency.
+    constexpr int PF = 4;
+    for (int ib = r0; ib < r1; ib += PF * (int)blockDim.x) {
+        double xpf[PF][D], bpf[PF];
+#pragma unroll
+        for (int r = 0; r < PF; ++r) {
+            const int i = ib + r * (int)blockDim.x + (int)threadIdx.x, ic = i < r1 ? i : r1 - 1;
+#pragma unroll
+            for (int k = 0; k < D; ++k) xpf[r][k] = A.XT[(size_t)k * A.Np + ic];
+            bpf[r] = A.beta[(size_t)a * A.Np + ic];
+        }
+#pragma unroll
+        for (int r = 0; r < PF; ++r) {
+        const int i0 = ib + r * (int)blockDim.x;               // uniform trip count: the G rows go through LDS
+        if (i0 >= r1) break;
         const int i = i0 + threadIdx.x;
         if (i < r1) {
             double d[D], xk[D], q = 0.0;
 #pragma unroll
-            for (int k = 0; k < D; ++k) { xk[k] = A.XT[(size_t)k * A.Np + i]; d[k] = u[k] - xk[k]; q = fma(Bk[k] * d[k], d[k], q); }
-            const double p = A.beta[(size_t)a * A.Np + i] * exp(-0.5 * q);
+            for (int k = 0; k < D; ++k) { xk[k] = xpf[r][k]; d[k] = u[k] - xk[k]; q = fma(Bk[k] * d[k], d[k], q); }
+            const double p = bpf[r] * exp(-0.5 * q);
             v[0] += p;
 #pragma unroll
             for (int k = 0; k < D; ++k) { v[1 + k] = fma(p, d[k], v[1 + k]); v[1 + D + k] = fma(p * d[k], d[k], v[1 + D + k]); }
@@ -306,8 +346,11 @@ __device__ static void prep_step(const RollArgs& A, int b, int t, int a, int chu
             for (int e = threadIdx.x; e < rows * A.gw; e += blockDim.x) dst[e] = s_g[e];
             __syncthreads();
         }
+        }
     }
+    GPMPC_HST(3);
     block_sum<1 + 2 * D>(v, s_scr, s_out);
+    GPMPC_HST(4);
     if (chunked) {
         // partial sums of this row chunk; the constants of the step by chunk 0 (the next launch's finish phase forms mu)
         if (threadIdx.x < 1 + 2 * D)
@@ -360,6 +403,7 @@ __global__ __launch_bounds__(256) void k_roll_head(RollArgs A, int t) {
     __shared__ double s_g[256 * (2 * D + 2)];             // staging of 256 G rows (gw <= 2D + 2)
     __shared__ double s_ms[GPMPC_MAX_DS * (1 + 2 * GPMPC_MAX_D) + 4 * GPMPC_MAX_DS];      // mean sums | Z0 wave sums
     const int b = blockIdx.x, a = blockIdx.y, chunk = blockIdx.z;
+    GPMPC_HST(0);
     if (t == 1) {
         if (threadIdx.x < A.ds) {
             const double x = A.x0[(size_t)b * A.ds + threadIdx.x];
@@ -374,7 +418,9 @@ __global__ __launch_bounds__(256) void k_roll_head(RollArgs A, int t) {
     } else {
         finish_step(A, b, t - 1, chunk == 0 ? a : A.ds, s_z, s_zred, s_mu, s_var, s_ms);     // rows of GP a are written by chunk 0 only
     }
+    GPMPC_HST(1);
     prep_step<D>(A, b, t, a, chunk, s_mu, s_var, s_u, s_s, s_scr, s_out, s_g);
+    GPMPC_HST(5);
 }
 
 // ---------------------------------------------------------------------------
@@ -1045,9 +1091,10 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
     A.pps = r.pps; A.sps = r.sps; A.nwork = r.nwork; A.nm = r.nm; A.grad = grad ? 1 : 0;
     A.ustart = p->wl[0][r.tiling].ustart_dev;
     A.work = p->wl[0][r.tiling].contiguous ? nullptr : p->wl[0][r.tiling].work_dev;
+    A.perm = p->wl[0][r.tiling].contiguous ? nullptr : p->wl[0][r.tiling].perm_dev;
     A.out_cost = out_cost; A.out_grad = out_grad; A.cost = *cost;
     if (r.shared) {                                          // partial sums laid out [GP][tile]
-        A.shared = 1; A.ust_inline = 1; A.work = nullptr;
+        A.shared = 1; A.ust_inline = 1; A.work = nullptr; A.perm = nullptr;
         for (int a = 0; a <= p->ds; ++a) A.ust[a] = a * p->sh_tiles[r.sh_list];
     }
 

@@ -48,3 +48,14 @@ hist, edges = np.histogram(start_us, bins=12)
 print("start-time histogram [us]:", " ".join(f"{edges[i]:.0f}-{edges[i+1]:.0f}:{hist[i]}" for i in range(len(hist))))
 active = [(np.sum((start_us <= t) & (end_us > t))) for t in np.linspace(0, end_us.max(), 13)]
 print("resident workgroups over the launch:", " ".join(str(a) for a in active))
+
+try:
+    hb = (ctypes.c_ulonglong * 16)()
+    fh = g.lib().gpmpc_debug_head_stamps
+    fh.argtypes = [ctypes.c_void_p]
+    if fh(hb) == 0:
+        h = np.array(list(hb), dtype=np.int64)
+        names = ["finish_step (reduce the partials of step t-1, Jacobian rows)", "per-dimension scalars", "row loop (mean sums, G rows)", "block sum", "publish scalars"]
+        print("head kernel, workgroup (0, 0, 0) of step 5 [cycles]: " + " | ".join(f"{n} {h[k + 1] - h[k]}" for k, n in enumerate(names)) + f" | total {h[5] - h[0]}")
+except AttributeError:
+    pass
