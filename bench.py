@@ -432,6 +432,10 @@ def run_rank(args):
         if fused_path:
             full_ms, full_n = tcls[2]
         launch_s = (full_ms / full_n) * 1e-3 if full_n else float("nan")
+        # mid-size batches run as concurrent sub-batches (step.hip split_count): one timed launch then covers B / S trajectories
+        per_rollout = H if fused_path else max(H - 1, 1)
+        n_sub = max(1, int(round(full_n / float(args.steps * per_rollout)))) if full_n else 1
+        pairs_per_launch /= n_sub
         achieved = pairs_per_launch * fl / launch_s / 1e12
         m_bytes = 8 * (ds * N * (N + 1) / 2 + (ds * (ds - 1) / 2 * N * N if fullcov else 0))     # M read once per launch
         sm = "sbf" if fullcov else ("sbs" if shared else "sb")
@@ -481,7 +485,7 @@ def run_rank(args):
                               "7-slot table exp, so `frac` is an ALGORITHMIC rate, not a utilisation -- the two bounded figures are "
                               "issue_util and executed_flops_frac)",
                 "algorithmic_flops_per_pair": fl, "algorithmic_slots_per_pair_survey_8d": slots, "pairs_per_launch": pairs_per_launch,
-                "avg_launch_ms": launch_s * 1e3, "launches": full_n,
+                "avg_launch_ms": launch_s * 1e3, "launches": full_n, "sub_batches_per_call": n_sub,
                 "first_step_variant": {"avg_launch_ms": (tcls[1][0] / tcls[1][1]) if tcls[1][1] else None, "launches": tcls[1][1]},
                 "issue_util": None if fused_path else issue_util,
                 "issue_util_note": f"static VALU instructions of the column loop per pair ({i_f64:g} fp64-rate + {i_int:g} integer) x 4 "

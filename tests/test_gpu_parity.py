@@ -386,6 +386,22 @@ def test_abi_error_codes_on_device(G, golden):
     assert lib.gpmpc_rollout(*args[:10], None, ctypes.c_void_p(ws.data_ptr()), ws.numel(), None) == -1   # grad wanted, no buffer
     assert lib.gpmpc_rollout_fullcov(pack.handle, 1, 10, _lib.ptr(x0), _lib.ptr(U), ctypes.byref(c.c), 0, _lib.ptr(out),
                                      _lib.ptr(out), _lib.ptr(out), None, ctypes.c_void_p(ws.data_ptr()), ws.numel(), None) == -5
+    # round-3 entry points: differentiable propagation, cost derivatives, pack re-use
+    jac = torch.zeros(10 * 4 * 6, dtype=torch.float64, device="cuda")
+    need_j = lib.gpmpc_rollout_jac_workspace_bytes(pack.handle, 1, 10)
+    assert need_j > need
+    jargs = (pack.handle, 1, 10, _lib.ptr(x0), _lib.ptr(U), _lib.ptr(out), _lib.ptr(out), _lib.ptr(jac))
+    assert lib.gpmpc_rollout_jac(*jargs, ctypes.c_void_p(ws.data_ptr()), need_j - 8, None) == -4     # workspace too small
+    assert lib.gpmpc_rollout_jac(*jargs[:7], None, ctypes.c_void_p(ws.data_ptr()), ws.numel(), None) == -1   # no Jacobian buffer
+    assert lib.gpmpc_rollout_jac(*jargs, ctypes.c_void_p(ws.data_ptr()), ws.numel(), None) == 0
+    assert lib.gpmpc_rollout_vjp(1, 10, 2, 2, _lib.ptr(jac), None, None, _lib.ptr(out), None, None) == 0       # zero seeds are allowed
+    assert lib.gpmpc_rollout_vjp(1, 10, 2, 2, None, None, None, _lib.ptr(out), None, None) == -1
+    assert lib.gpmpc_cost_grad(1, 10, 2, 2, ctypes.byref(c.c), _lib.ptr(out), _lib.ptr(out), _lib.ptr(out), _lib.ptr(out), _lib.ptr(out),
+                               None, None, None) == -1                                                     # one of three derivative outputs
+    assert lib.gpmpc_pack_resize(pack.handle, 129) == -1          # padded size would change (100 -> 128, 129 -> 192)
+    assert lib.gpmpc_pack_resize(pack.handle, 101) == 0
+    assert lib.gpmpc_pack_shared_lambda(pack.handle) == -5        # resized, not rebuilt yet
+    assert lib.gpmpc_rollout(*args, ctypes.c_void_p(ws.data_ptr()), ws.numel(), None) == -5
     torch.cuda.synchronize()
 
 
