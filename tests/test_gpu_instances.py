@@ -19,7 +19,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-DIMS = [(1, 1), (1, 2), (2, 1), (2, 2), (3, 1), (3, 2), (4, 1), (4, 2), (5, 1), (5, 2), (6, 1)]
+DIMS = [(1, 1), (1, 2), (2, 1), (2, 2), (3, 1), (3, 2), (4, 1), (4, 2), (5, 1), (5, 2), (6, 1), (6, 2), (7, 1)]      # up to D = 8 = GPMPC_MAX_D
 
 
 @pytest.fixture(scope="module")

@@ -50,7 +50,7 @@ def test_detection_is_bit_exact(G):
     assert G.GPPack(pb["X"], pb["Y"], kinv, pb["lambdas"], sf).shared_lambda
 
 
-@pytest.mark.parametrize("ds,da", [(2, 1), (2, 2), (3, 1), (3, 2), (4, 1), (4, 2), (5, 1), (5, 2), (6, 1)])
+@pytest.mark.parametrize("ds,da", [(2, 1), (2, 2), (3, 1), (3, 2), (4, 1), (4, 2), (5, 1), (5, 2), (6, 1), (6, 2), (7, 1)])
 def test_every_shape_vs_cport_and_vs_distinct_kernels(G, ds, da, monkeypatch):
     """256x64 and 256x256 shared work lists, GRAD / objective-only / horizon-step-1 instances of every (ds, da), incl. the
     partial last GP group (ds = 5: groups of 3 + 2)."""
