@@ -232,6 +232,25 @@ class GaussianProcessRegression(object):
             self._pending[5].synchronize()
             self._service_async_rebuild()
 
+    def update_Ky_inv_mat(self, k_new):
+        """Ky_inv of the n current points -> Ky_inv of the n + 1 points whose last one has the covariance column ``k_new``
+        (n, 1) with the others (src/gpr.py:137-157: block inverse with the scalar Schur complement
+        ``sigma_n^2 + sigma_f^2 - k^T Ky_inv k``; the reference marks it "don't use" and never calls it).  Like the
+        reference's it only replaces ``Ky_inv``; here the update runs on the device (C ABI ``gpmpc_kinv_append``)."""
+        n = self.Ky_inv.shape[0]
+        k = torch.as_tensor(k_new).detach().to(self.device, torch.float64).reshape(1, n).contiguous()
+        kinv_old = self.Ky_inv.detach().contiguous()
+        out = torch.empty((n + 1, n + 1), dtype=torch.float64, device=self.device)
+        nb = lib().gpmpc_kinv_append_workspace_bytes(n)
+        ws = torch.empty(nb, dtype=torch.uint8, device=self.device)
+        kappa = self.get_sigma_n() ** 2 + self.get_sigma_f() ** 2
+        with torch.cuda.device(self.device):
+            check(lib().gpmpc_kinv_append(n, ptr(kinv_old), ptr(k), kappa, ptr(out), ctypes.c_void_p(ws.data_ptr()), nb,
+                                          stream_ptr(self.device)), "gpmpc_kinv_append")
+        self.Ky_inv = out
+        self._beta = None
+        self.version += 1
+
     def build_Ky_inv_mat(self):
         """Kf, Ky, Ky_inv from scratch (src/gpr.py:159-171)."""
         self._build_kf_ky()

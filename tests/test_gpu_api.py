@@ -662,3 +662,23 @@ def test_numpy_forward_propagate_signature(G, golden):
     np.testing.assert_allclose(means, z["means"][0], rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(np.diagonal(covs, axis1=1, axis2=2), z["vars"][0], rtol=1e-5)
     assert np.all(covs[3] - np.diag(np.diag(covs[3])) == 0)
+
+
+def test_update_Ky_inv_mat_block_inverse(G):
+    """GaussianProcessRegression.update_Ky_inv_mat(k_new) (src/gpr.py:137-157; the reference's block-inverse check is
+    src/test/test_gpr.py:563-609): appending the covariance column of a new point to Ky_inv gives the inverse of the bordered
+    matrix [[Ky, k], [k^T, sigma_n^2 + sigma_f^2]]."""
+    rng = np.random.default_rng(4)
+    D, n = 2, 60
+    gp = G.GaussianProcessRegression(D)
+    gp.set_lambdas(np.array([1.0, 2.0])); gp.set_sigma_n(0.3); gp.set_sigma_f(1.1)
+    X = rng.uniform(-2, 2, (n, D))
+    gp.append_train_data(X, np.sin(X).sum(axis=1))
+    xn = rng.uniform(-2, 2, D)
+    k = gp.compute_pred_train_covariance(xn).reshape(n, 1)               # K(x_new, X)
+    Ky = gp.Ky.cpu().numpy()
+    kn = k.cpu().numpy()
+    full = np.block([[Ky, kn], [kn.T, np.array([[gp.get_sigma_n() ** 2 + gp.get_sigma_f() ** 2]])]])
+    gp.update_Ky_inv_mat(k)
+    assert gp.Ky_inv.shape == (n + 1, n + 1)
+    np.testing.assert_allclose(gp.Ky_inv.cpu().numpy() @ full, np.eye(n + 1), rtol=0, atol=1e-9)
