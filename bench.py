@@ -512,6 +512,17 @@ def run_rank(args):
                     gr.cpu()
             torch.cuda.synchronize()
             out["pcie_inclusive_rollouts_per_s"] = max(2, min(args.steps, 5)) * B / (time.perf_counter() - tp)
+        if world == 1 and not args.graph and not args.no_extras:
+            # sustained rate: the same step repeated for ~5 s, outside the timed region (the timed K steps are a sub-second
+            # burst; the kernel runs the chip on its power cap, so this is the number a long job sees)
+            torch.cuda.synchronize()
+            ts, ns = time.perf_counter(), 0
+            while time.perf_counter() - ts < 5.0:
+                for _ in range(4):
+                    step()
+                ns += 4
+                torch.cuda.synchronize()
+            out["sustained"] = {"seconds": time.perf_counter() - ts, "steps": ns, "rollouts_per_s": ns * B / (time.perf_counter() - ts)}
         if world == 1 and want_grad and not fullcov and not args.no_extras:
             # objective-only rate beside the headline, outside the timed region
             for _ in range(2):
