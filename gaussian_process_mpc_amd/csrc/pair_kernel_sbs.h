@@ -95,26 +95,36 @@ void gpmpc_pair_kernel_sbs(PairSbsArgs A) {
             Mrs[g] = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(A.M + ((size_t)a * Np + jstart) * Np + iw0), 0, 0x7fffffff, 0x00020000);
         }
         const int lane8 = lane * 8;
-        for (int jc = jstart; jc < j1; ++jc) {
-            double mij[NG];
+#ifndef GPMPC_SBS_CU
+#define GPMPC_SBS_CU 1       /* columns per loop iteration (A/B knob; 1 measured best, see profiles/r03/ab_shared_columns.txt) */
+#endif
+        constexpr int CU = GPMPC_SBS_CU;
+        for (int jc = jstart; jc < j1; jc += CU) {
+            double mij[CU][NG];
 #pragma unroll
-            for (int g = 0; g < NG; ++g)
-                mij[g] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs[g], lane8, (jc - jstart) * Np * 8, 0));
+            for (int c = 0; c < CU; ++c)
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+                    mij[c][g] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs[g], lane8, (jc - jstart + c) * Np * 8, 0));
             __builtin_amdgcn_sched_barrier(0);            // loads stay at the top of the iteration (pair_kernel_sb.h)
-            const double* __restrict__ g = Gt + (size_t)jc * GW;          // wave-uniform address -> SGPRs
-            double s = qi + g[D];
 #pragma unroll
-            for (int k = 0; k < D; ++k) s = fma(hi2[k], g[k], s);
-            const double e = gpmpc_exp_neg_scaled(s, s_tab);
+            for (int c = 0; c < CU; ++c) {
+                typedef const double __attribute__((address_space(4))) gpmpc_cdouble;      // constant for the launch: scalar loads
+                const gpmpc_cdouble* __restrict__ g = (const gpmpc_cdouble*)(Gt + (size_t)(jc + c) * GW);
+                double s = qi + g[D];
 #pragma unroll
-            for (int q = 0; q < NG; ++q) {
-                const double P = mij[q] * e;
-                acc[q][0] += P;
-                if (GRAD) {
+                for (int k = 0; k < D; ++k) s = fma(hi2[k], g[k], s);
+                const double e = gpmpc_exp_neg_scaled(s, s_tab);
 #pragma unroll
-                    for (int k = 0; k < D; ++k) if (!FIRST || k >= NS2) acc[q][1 + k] = fma(P, g[k], acc[q][1 + k]);
+                for (int q = 0; q < NG; ++q) {
+                    const double P = mij[c][q] * e;
+                    acc[q][0] += P;
+                    if (GRAD) {
 #pragma unroll
-                    for (int k = 0; k < NS2; ++k) if (!FIRST) acc[q][1 + D + k] = fma(P, g[D + 1 + k], acc[q][1 + D + k]);
+                        for (int k = 0; k < D; ++k) if (!FIRST || k >= NS2) acc[q][1 + k] = fma(P, g[k], acc[q][1 + k]);
+#pragma unroll
+                        for (int k = 0; k < NS2; ++k) if (!FIRST) acc[q][1 + D + k] = fma(P, g[D + 1 + k], acc[q][1 + D + k]);
+                    }
                 }
             }
         }
