@@ -907,25 +907,30 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     // N = 1024, B = 8 / 10: 0.92 vs 0.99 / 1.00 vs 1.18 ms; smaller training sets stay at 1700: N = 600, B = 16 0.89 vs 0.86 ms,
     // N = 400, B = 64 0.43 vs 0.38 ms -- profiles/r03/ab_fused_vs_sb_threshold.txt)
     const bool mid = !big && sb_ok && (long)B * p->wl[0][2].nwork >= (p->Np >= 1024 ? 1250 : 1700);
+    // 256x128 tiles with two trajectories per wave where they already give the workgroups the 256x256 tiles do not yet
+    // (profiles/r03/ab_tiling_256x128.txt: N = 2048, B = 24 / 32 4.02 / 5.07 vs 4.78 / 6.12 ms on 256x64; N = 1024, B = 96 / 128
+    // 4.51 / 5.71 vs 4.98 / 6.49 ms; from there on 256x256 is 3-4 % ahead)
+    const bool big128 = !big && sb_ok && tb2 && p->Np > 512 && (long)((B + 1) / 2) * p->wl[0][4].nwork >= thr2;
     r->sb = (sb_ok && (big || mid)) ? 1 : 0;
     const bool many = (long)p->wl[0][1].nwork > 256L * p->ds;        // > 256 one-wave tiles per GP (N >= 1472)
-    r->tiling = big ? 0 : (mid ? 2 : (many ? 3 : 1));
+    r->tiling = big ? 0 : (big128 ? 4 : (mid ? 2 : (many ? 3 : 1)));
     const gpmpc_tuning& tn = p->tune;                        // GPMPC_* overrides, read once at pack creation
     if (tn.pair_sb >= 0) {                                   // 0 = staged kernel, 1 = scalar broadcast
         r->sb = (tn.pair_sb != 0 && sb_ok) ? 1 : 0;
-        r->tiling = r->sb ? (big ? 0 : 2) : (big ? 0 : (many ? 3 : 1));
+        r->tiling = r->sb ? (big ? 0 : (big128 ? 4 : 2)) : (big ? 0 : (many ? 3 : 1));
     }
-    if (tn.tiling >= 0) { const int v = tn.tiling; if (v == 0 || ((v == 1 || v == 3) && !r->sb) || (v == 2 && r->sb)) r->tiling = v; }
+    if (tn.tiling >= 0) { const int v = tn.tiling; if (v == 0 || ((v == 1 || v == 3) && !r->sb) || ((v == 2 || v == 4) && r->sb)) r->tiling = v; }
+    const bool wide = r->tiling == 0 || r->tiling == 4;          // 256-row tiles of the XCD-sorted lists
     // scalar-broadcast kernel: two trajectories per wave on the big tiling up to D = 5 (two independent dependency chains per
     // lane, one M_ij load for both: C3 +2.6 %, objective-only +14 %; 82 VGPRs); D = 7 (C4) is 2.5 % faster with one
-    r->tb = r->sb ? ((big && D <= 5 && B >= 2) ? 2 : 1) : (B >= 2 ? 2 : 1);
+    r->tb = r->sb ? ((wide && D <= 5 && B >= 2) ? 2 : 1) : (B >= 2 ? 2 : 1);
     if (tn.tb) { const int v = tn.tb; if (v == 1 || v == 2 || (v == 4 && !r->sb)) r->tb = v; }
     if (!diag && grad && r->tb > 2) r->tb = 2;
     // Dispatch interleave of the scalar-broadcast kernel (pair_kernel_sb.h): 4 row tiles per trajectory share each fetch
     // of the G rows (C3 fabric reads per launch 757 -> 418 MB by FETCH_SIZE at the same speed; C4 +0.5 %).
     r->rgroup = 4;
     if (tn.rgroup >= 1 && tn.rgroup <= 16) r->rgroup = tn.rgroup;
-    if (r->tiling != 0) r->rgroup = 1;
+    if (!wide) r->rgroup = 1;
     if (lowprec) { r->sb = 0; r->tiling = 0; r->tb = 1; }      // tolerance-sweep kernels: 256x256 work list, one trajectory per workgroup
     // Small batches on the 64-row work lists: ONE launch per horizon step (step_fused.h) instead of head + staged pair
     // kernel -- the B = 1 callbacks of a solver loop are pure dependent latency (GPMPC_FUSED=0 keeps the two-kernel form).
@@ -1013,7 +1018,7 @@ static int split_count(const gpmpc_pack* p, const RollPlan& r, int B, bool lowpr
     // 256x256 tiling with two trajectories per wave, up to ~8 generations of workgroups: two sub-batches fill each other's partly
     // filled last generation (N = 2048: B = 48 / 64 / 128 +11 / +9 / +4 %, B = 256 +-0; N = 1024, B = 128 / 256 +6 / +5 %;
     // one trajectory per wave (D >= 6, N = 4096): -3...-7 %, not split) -- profiles/r03/split_big_ab.txt
-    if (!mid && !r.shared && r.tiling == 0 && r.tb == 2 && B >= 16 && (long)((B + 1) / 2) * r.nwork <= 10000) S = 2;
+    if (!mid && !r.shared && (r.tiling == 0 || r.tiling == 4) && r.tb == 2 && B >= 16 && (long)((B + 1) / 2) * r.nwork <= 10000) S = 2;
     if (p->tune.split >= 1) S = p->tune.split;
     if (S > GPMPC_MAX_SPLIT) S = GPMPC_MAX_SPLIT;
     if (S > B) S = B;

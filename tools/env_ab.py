@@ -16,6 +16,7 @@ ap.add_argument("--values", required=True, help="comma separated; 'unset' remove
 ap.add_argument("--bitwise", action="store_true")
 ap.add_argument("--eager", action="store_true", help="plain launches instead of graph replay")
 ap.add_argument("--shared-lambda", action="store_true")
+ap.add_argument("--create-env", default="", help="NAME=VALUE[,NAME=VALUE] set while the packs are CREATED (variables read at gpmpc_pack_create)")
 ap.add_argument("--sync-each", action="store_true", help="synchronise after every call (the latency a caller sees who needs each result)")
 ap.add_argument("shapes", nargs="*")
 args = ap.parse_args()
@@ -23,6 +24,8 @@ shapes = args.shapes or ["1024:4:1:20:8", "1024:4:1:20:12", "1024:4:1:20:16", "1
                          "2048:4:1:20:4", "2048:4:1:20:8", "2048:4:1:20:16", "2048:4:1:20:32", "512:3:1:20:64", "600:4:1:20:32",
                          "400:2:1:10:128", "4096:6:1:30:1", "4096:6:1:30:2"]
 values = args.values.split(",")
+for kv in filter(None, args.create_env.split(",")):
+    os.environ[kv.split("=")[0]] = kv.split("=")[1]
 dev = g.require_gpu()
 packs = {}
 for shape in shapes:
