@@ -76,8 +76,8 @@ struct gpmpc_pack {
     // shared-lambda path (pair_kernel_sbs.h): every GP has bit-identical length-scales (detected at gpmpc_pack_build)
     int shared_lambda;
     int sh_ng;                 // GPs per workgroup
-    gpmpc_worklist wl_sh[2];   // items {group, i0, j0, tile}: [0: 256x256 tiles, XCD-sorted | 1: 256x64]; .nunits = groups
-    int sh_tiles[2];           // tiles per GP
+    gpmpc_worklist wl_sh[3];   // items {group, i0, j0, tile}: [0: 256x256 tiles, XCD-sorted | 1: 256x64 | 2: 256x128, XCD-sorted]; .nunits = groups
+    int sh_tiles[3];           // tiles per GP
 };
 
 // Number of pair-kernel output moments per (trajectory, GP, tile).

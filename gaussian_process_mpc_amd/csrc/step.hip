@@ -944,15 +944,19 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     r->waves = p->wl[0][r->tiling].waves;
     r->nwork = p->wl[0][r->tiling].nwork;
     // Shared length-scales: one exponent / exp per pair for a group of GPs (pair_kernel_sbs.h) wherever the scalar-broadcast
-    // kernel would run.  256x256 tiles once they give ~1500 workgroups (one trajectory per workgroup), else 256x64.
+    // kernel would run.  256x256 tiles once they give ~1700 workgroups (one trajectory per workgroup), else 256x64.
     r->shared = 0; r->sh_list = 0;
     if (r->sb && !lowprec && p->shared_lambda && tn.shared != 0 && p->sh_ng >= 2) {
         r->shared = 1;
-        r->sh_list = ((long)B * p->wl_sh[0].nwork >= 1500) ? 0 : 1;
-        if (tn.tiling == 0 || tn.tiling == 2) r->sh_list = tn.tiling == 0 ? 0 : 1;
+        // (round 3: a 256x128 list, wl_sh[2], is built for the A/B only -- GPMPC_TILING=4 --: with one trajectory per workgroup it has
+        // nothing to share that the 256x64 tiles under the concurrent sub-batches do not have; N = 2048, B = 16...40 -3...-20 %,
+        // N = 1024, B = 128 / 160 +2 / +3 % -- profiles/r03/ab_shared_tiling.txt.  256x256 from 1700 workgroups: N = 2048, B = 40
+        // 4.90 (256x64) vs 5.32 ms, B = 48 5.71 vs 5.77; N = 1024, B = 160 5.10 vs 5.19)
+        r->sh_list = ((long)B * p->wl_sh[0].nwork >= 1700) ? 0 : 1;
+        if (tn.tiling == 0 || tn.tiling == 2 || tn.tiling == 4) r->sh_list = tn.tiling == 0 ? 0 : (tn.tiling == 2 ? 1 : 2);
         r->tb = 1; r->waves = 4;
         r->nwork = p->ds * p->sh_tiles[r->sh_list];           // partial sums per trajectory: [GP][tile]
-        r->rgroup = r->sh_list == 0 ? ((tn.rgroup >= 1 && tn.rgroup <= 16) ? tn.rgroup : 4) : 1;
+        r->rgroup = r->sh_list != 1 ? ((tn.rgroup >= 1 && tn.rgroup <= 16) ? tn.rgroup : 4) : 1;
     }
     // Columns per iteration of the scalar-broadcast kernel: 4 on the 256x64 tiling (mid-size batches: latency tolerance of
     // the partly filled generations, pair_kernel_sb.h), 1 on full launches.

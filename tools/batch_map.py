@@ -44,15 +44,17 @@ for shape in args.shapes.split(","):
         U = torch.as_tensor(pb["U"][:B], device=dev)
         graph = B < 32 and not args.fullcov
         run = (lambda: rollout_fullcov(pack, x0, U, cost)) if args.fullcov else (lambda: rollout(pack, x0, U, cost, want_grad=True, want_traj=False, graph=graph))
-        reps = max(10, min(200, int((2e9 if args.quick else 8e9) / (B * H * (ds * ds if args.fullcov else ds) * N * N / 2 * 30))))
+        reps = max(10, min(200, int((1e9 if args.quick else 4e9) / (B * H * (ds * ds if args.fullcov else ds) * N * N / 2 * 30))))
         for _ in range(3):
             run()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            run()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / reps
+        dt = float("inf")
+        for _ in range(3):                                   # best of three blocks: the eager path is host-launch sensitive
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                run()
+            torch.cuda.synchronize()
+            dt = min(dt, (time.perf_counter() - t0) / reps)
         rows.append((B, dt, B / dt))
     pairs = H * (ds * N * (N + 1) / 2 + (ds * (ds - 1) / 2 * N * N if args.fullcov else 0))
     best = max(r[2] for r in rows)

@@ -26,7 +26,9 @@ SHAPES = {"auto": {}, "sb256": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "0"}, "sb6
           # round 3: four columns in flight / one, concurrent sub-batches forced on and off, shared-lambda group sizes
           "sb64_u4": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "2", "GPMPC_SB_UNROLL": "4"}, "sb64_u1_split4": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "2", "GPMPC_SB_UNROLL": "1", "GPMPC_SPLIT": "4"},
           "sb256_split2": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "0", "GPMPC_SPLIT": "2"}, "nosplit": {"GPMPC_SPLIT": "1"},
-          "sh_ng2": {"GPMPC_PAIR_SB": "1", "GPMPC_SHARED_NG": "2"}, "sh_off": {"GPMPC_SHARED": "0"}, "sh_sb64": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "2", "GPMPC_SPLIT": "3"}}
+          "sh_ng2": {"GPMPC_PAIR_SB": "1", "GPMPC_SHARED_NG": "2"}, "sh_off": {"GPMPC_SHARED": "0"}, "sh_sb64": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "2", "GPMPC_SPLIT": "3"},
+          # 256x128 tiles, two trajectories per wave (work list 4), alone and as two concurrent sub-batches
+          "sb128": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "4"}, "sb128_split2": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "4", "GPMPC_SPLIT": "2"}}
 worst = {"means": 0.0, "vars": 0.0, "cost": 0.0, "grad": 0.0}
 bad = 0
 t_start = time.time()
