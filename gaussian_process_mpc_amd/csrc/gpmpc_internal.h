@@ -44,6 +44,7 @@ struct gpmpc_tuning {
     int hchunks;     // GPMPC_HEAD_CHUNKS row chunks of the head kernel: 0 / 1 none | 2..16 | -1 unset (chosen per call)
     int sbf_min;     // GPMPC_SBF_MIN     workgroups from which the full-S path uses 256x256 tiles + pair_kernel_sbf.h | 0 unset
     int colunroll;   // GPMPC_SB_UNROLL   1 | 4 columns per iteration of the scalar-broadcast kernel on the 256x64 tiling | -1 unset (4)
+    int fused_sb;    // GPMPC_FUSED_SB    one launch per horizon step for mid-size batches (step_fused.h, Q = 0): 0 off | 1 on | -1 unset
     int split;       // GPMPC_SPLIT       sub-batches (parallel graph branches) of a graph-replayed rollout: 1 none | 2..4 | -1 unset (2 for mid-size batches)
     int shared;      // GPMPC_SHARED      0: never use the shared-lambda kernel (pair_kernel_sbs.h) | -1 unset (used when lambdas are shared)
 };
@@ -168,6 +169,7 @@ struct FusedArgs {
     double* means; double* vars; double* jac;
     double* sp; double* part; double* partz;
     int sps, nm;
+    double* gscr;                          // mid-size form (q = 0): [B][nwork][64][gw] column rows, one slot per tile workgroup
 };
 template <int D> int gpmpc_launch_step_fused_D(bool grad, int ns2, int q, const FusedArgs& a, int t, hipStream_t s);
 

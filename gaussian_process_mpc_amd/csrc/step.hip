@@ -906,7 +906,15 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     // (round 3, with four columns in flight and concurrent sub-batches on the 256x64 path: from 1250 work items for N >= 1024 --
     // N = 1024, B = 8 / 10: 0.92 vs 0.99 / 1.00 vs 1.18 ms; smaller training sets stay at 1700: N = 600, B = 16 0.89 vs 0.86 ms,
     // N = 400, B = 64 0.43 vs 0.38 ms -- profiles/r03/ab_fused_vs_sb_threshold.txt)
-    const bool mid = !big && sb_ok && (long)B * p->wl[0][2].nwork >= (p->Np >= 1024 ? 1250 : 1700);
+    // ... and, where the one-launch-per-step form on these tiles can run (step_fused.h, Q = 0: see r->fused below), from ~400 tile
+    // workgroups: against the 64-row fused form N = 2048, B = 1 / 2 x1.19 / 1.43; N = 1024, B = 2 / 3 / 4 / 6 x1.06 / 1.24 / 1.19 / 1.34;
+    // N = 512, ds = 3, B = 8 / 12 / 16 / 32 x1.01 / 1.16 / 1.19 / 1.38; N = 300, ds = 2, B = 32 / 64 x1.02 / 1.15; below ~300 workgroups
+    // it loses (N = 1024, B = 1 x0.92; N = 512, B = 4 x0.77), and so do training sets of less than one row tile (N = 128, B = 128 x0.89)
+    const long wg2 = (long)B * p->wl[0][2].nwork;
+    const bool shared_on = p->shared_lambda && p->tune.shared != 0 && p->sh_ng >= 2;
+    const bool fsb_can = sb_ok && !lowprec && p->da >= 1 && p->tune.fused_sb != 0 && !shared_on && (p->Np >= 256 || p->tune.fused_sb == 1) &&
+                         p->wl[0][2].nwork <= (p->tune.fused_sb == 1 ? 600 : 320) * p->ds;
+    const bool mid = !big && sb_ok && (wg2 >= (p->Np >= 1024 ? 1250 : 1700) || (fsb_can && wg2 >= 400));
     // 256x128 tiles with two trajectories per wave where they already give the workgroups the 256x256 tiles do not yet
     // (profiles/r03/ab_tiling_256x128.txt: N = 2048, B = 24 / 32 4.02 / 5.07 vs 4.78 / 6.12 ms on 256x64; N = 1024, B = 96 / 128
     // 4.51 / 5.71 vs 4.98 / 6.49 ms; from there on 256x256 is 3-4 % ahead)
@@ -938,9 +946,19 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     // a few thousand -- N = 2048 has 2112 --, 16x off at the 6336 items of N = 4096, which keeps the two-kernel form)
     r->fused = (!r->sb && !lowprec && diag && (r->tiling == 1 || r->tiling == 3) && p->da <= 2 && tn.fused != 0 &&
                 p->wl[0][r->tiling].nwork <= 4096) ? 1 : 0;
+    // Mid-size batches on the 256x64 tiling: the same single launch per step with the scalar-broadcast column loop in the tile
+    // workgroups (step_fused.h, Q = 0).  Every tile workgroup re-reduces the Z0 partial sums of its trajectory: up to 320 tiles
+    // per GP (N <= 2048; 256 of them are prefetched in one round trip).
+    // Measured against head + pair kernel with concurrent sub-batches (tools/env_ab.py --var GPMPC_FUSED_SB, synchronising after
+    // each call; profiles/r03/ab_fused_sb.txt): N = 1024, B = 8 / 12 / 16 / 24 / 32 / 48 x1.29 / 1.42 / 1.26 / 1.08 / 1.04 / 0.98;
+    // N = 2048, B = 4 / 6 / 8 / 12 x1.17 / 1.10 / 1.06 / 0.97; N = 768, B = 24 / 48 x1.36 / 1.13: up to ~4700 tile workgroups per
+    // launch (beyond, the longer prologue of every tile workgroup costs more than the head kernel it replaces).
+    // (N > ~2100 -- more than 320 tiles per GP -- stays on head + pair kernel: N = 4096, B = 1 4.35 vs 3.73 ms)
+    if (r->sb && r->tiling == 2 && r->tb == 1 && fsb_can && (tn.fused_sb == 1 || wg2 <= 4700))
+        r->fused = 2;
     if (r->fused) r->tb = 1;
     // a quarter of a tile's columns per workgroup while whole tiles would leave most SIMDs without a wave
-    r->fq = (r->fused && r->tiling == 1 && (long)B * p->wl[0][1].nwork < 256) ? 4 : 1;
+    r->fq = (r->fused == 1 && r->tiling == 1 && (long)B * p->wl[0][1].nwork < 256) ? 4 : 1;
     r->waves = p->wl[0][r->tiling].waves;
     r->nwork = p->wl[0][r->tiling].nwork;
     // Shared length-scales: one exponent / exp per pair for a group of GPs (pair_kernel_sbs.h) wherever the scalar-broadcast
@@ -991,7 +1009,9 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     r->off_mpart = take(r->hchunks > 1 ? (size_t)2 * B * p->ds * r->hchunks * (1 + 2 * D) : 0);
     r->off_jac = take(grad ? (size_t)B * H * 2 * p->ds * (2 * p->ds + p->da) : 0);
     r->gw = gpmpc_sb_gw(D, p->ds);
-    r->off_G = take(r->sb ? (size_t)B * (r->shared ? 1 : p->ds) * p->Np * r->gw : 0);
+    // column rows: [B][GP][Np][gw] written by the head kernel, or one [64][gw] slot per tile workgroup of the mid-size fused form
+    r->off_G = take(r->fused == 2 ? (size_t)B * r->nwork * 64 * r->gw
+                                  : (r->sb ? (size_t)B * (r->shared ? 1 : p->ds) * p->Np * r->gw : 0));
     r->off_means = take((size_t)B * (H + 1) * p->ds);
     r->off_vars = take((size_t)B * (H + 1) * p->ds);
     r->total = off;
@@ -1002,7 +1022,7 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
 // kernel runs B ds workgroups, the pair kernel ends in a partly filled generation: tools/sb_stamps.py); two independent chains
 // fill each other's gaps.
 #define GPMPC_MAX_SPLIT 4
-static int split_count(const gpmpc_pack* p, const RollPlan& r, int B, bool lowprec) {
+static int split_count(const gpmpc_pack* p, const RollPlan& r, int B, bool lowprec, bool eager = false) {
     if (lowprec || !r.sb) return 1;
     const bool mid = r.shared ? r.sh_list == 1 : r.tiling == 2;
     // measured (tools/env_ab.py --var GPMPC_SPLIT, profiles/r03/split_ab.txt): N = 1024, B = 16: 11.3 -> 13.8 (2 branches) -> 14.3 k
@@ -1013,7 +1033,11 @@ static int split_count(const gpmpc_pack* p, const RollPlan& r, int B, bool lowpr
     // (N = 1024, B = 16, synchronising after every call: 2 branches x1.12, 4 branches x0.93-1.02; B = 32: 4 branches x1.09-1.13;
     // with calls queued back to back 4 branches give x1.27 / x1.24 -- profiles/r03/split_latency_vs_throughput.txt).
     int S = 1;
-    if (mid && B >= 4) {
+    if (r.fused == 2) {
+        // one launch per step: two branches are ahead everywhere (tools/env_ab.py --var GPMPC_SPLIT, N = 1024, B = 8 / 16 / 24: one branch
+        // x1.03 / 0.86 / 0.94, two x1.11 / 1.01 / 1.06, four x1.02 / 0.95 / 1.01 of the two-kernel rule's choice)
+        S = B >= 4 ? 2 : 1;
+    } else if (mid && B >= 4) {
         S = B / 2 < GPMPC_MAX_SPLIT ? B / 2 : GPMPC_MAX_SPLIT;
         while (S > 1 && (long)(B / S) * r.nwork >= 4096 && B / S < 8) --S;
         while (S > 1 && (long)(B / S) * r.nwork < 900) --S;
@@ -1023,6 +1047,11 @@ static int split_count(const gpmpc_pack* p, const RollPlan& r, int B, bool lowpr
     // filled last generation (N = 2048: B = 48 / 64 / 128 +11 / +9 / +4 %, B = 256 +-0; N = 1024, B = 128 / 256 +6 / +5 %;
     // one trajectory per wave (D >= 6, N = 4096): -3...-7 %, not split) -- profiles/r03/split_big_ab.txt
     if (!mid && !r.shared && (r.tiling == 0 || r.tiling == 4) && r.tb == 2 && B >= 16 && (long)((B + 1) / 2) * r.nwork <= 10000) S = 2;
+    // Launched plainly (no graph) the branches are streams of the pack, which the runtime maps onto a handful of hardware queues
+    // shared with every other stream of the process: four branches then ran from x1.27 to x0.87 of the unsplit call depending on
+    // what else the process had created (N = 1024, B = 32 in a fresh process: 1 / 2 / 3 / 4 branches 2.15 / 1.95 / 1.92 / 2.47 ms
+    // -- profiles/r03/split_eager_branches.txt); two are ahead in every process measured.
+    if (eager && S > 2) S = 2;
     if (p->tune.split >= 1) S = p->tune.split;
     if (S > GPMPC_MAX_SPLIT) S = GPMPC_MAX_SPLIT;
     if (S > B) S = B;
@@ -1126,8 +1155,9 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
         F.means = A.means; F.vars = A.vars; F.jac = A.jac;
         F.sp = A.sp; F.part = A.part; F.partz = (double*)(ws + r.off_partz);
         F.sps = r.sps; F.nm = r.nm;
+        F.gscr = r.fused == 2 ? (double*)(ws + r.off_G) : nullptr;
         for (int t = 1; t <= H; ++t) {
-            const int rc = timed_launch(GPMPC_TIME_FUSED, s, [&] { return launch_step_fused(p->D, grad, p->ds, r.fq, F, t, s); });
+            const int rc = timed_launch(GPMPC_TIME_FUSED, s, [&] { return launch_step_fused(p->D, grad, p->ds, r.fused == 2 ? 0 : r.fq, F, t, s); });
             if (rc != GPMPC_OK) return rc;
         }
         A.part += (size_t)(H & 1) * B * nwg * r.nm;          // the tail finishes step H from the parity the last launch wrote
@@ -1508,7 +1538,7 @@ extern "C" int gpmpc_rollout(const gpmpc_pack* p, int B, int H, const double* x0
         const bool grad = (flags & GPMPC_WANT_GRAD) != 0;
         RollPlan whole;
         plan_rollout(p, B, H, grad, true, &whole, false);
-        const int S = split_count(p, whole, B, false);
+        const int S = split_count(p, whole, B, false, true);
         if (S > 1 && split_bytes(p, whole, B, H, grad, S) <= workspace_bytes) {
             gpmpc_graph_cache* g = nullptr;
             if (int rcg = ensure_graph_cache(const_cast<gpmpc_pack*>(p), &g)) return rcg;

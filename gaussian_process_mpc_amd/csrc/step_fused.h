@@ -69,16 +69,28 @@ static __device__ unsigned long long g_fused_stamps[64];
 #endif
 #define GPMPC_FUSED_PZ 4        // Z0 partials of one GP prefetched per thread: covers 256 * 4 workgroups per GP
 
+// Q = 0: the MID-SIZE form (round 3).  The tile workgroups take 256 x 64 tiles (work list 2) and run the SCALAR-BROADCAST column
+// loop of pair_kernel_sb.h (four columns in flight, table exp) instead of the staged one: a batch of B = 4...32 trajectories of
+// a large N then needs ONE launch per horizon step where the two-kernel form needs head + pair kernel, and the O(N) mean sums
+// and the finish work run beside the tiles instead of in front of them.  The column rows G[j] = [h_j | q_j N/ln2 | h_jk^2] the
+// loop reads through scalar loads are computed by the workgroup itself for ITS 64 columns (wave 0, one column per lane),
+// stored to a scratch slot of its own, and read back after s_waitcnt vmcnt(0) (the stores have reached L2), an s_dcache_inv
+// (the scalar cache may hold the slot's previous contents) and the workgroup barrier.
 // layout of sp (doubles), as step.hip: 0 c | 1 mu | 2 sf2 | 3 A[D] | 3+D scale[D] | 3+2D dmu_du[D] | 3+3D dmu_ds[D]
-template <int D, int NS2, bool GRAD, int Q>
-__global__ __launch_bounds__(256) void k_step_fused(FusedArgs A, int t) {
-    constexpr int DS = NS2, DA = D - NS2, NM = GRAD ? 1 + 2 * D : 1, DP = (D + 1) & ~1;
-    constexpr int NV = 1 + 2 * D, NT = 256, CW = 16 / Q, NCOL = 64 / Q;            // NCOL columns of a chunk per workgroup
-    constexpr int TABN = GPMPC_EXP_N / NT; (void)TABN;
-#if GPMPC_FUSED_TABLE
-    __shared__ double s_tab[GPMPC_EXP_N];
+#ifndef GPMPC_FUSED_SB_WAVES
+#define GPMPC_FUSED_SB_WAVES 5      /* waves per SIMD the mid-size form is compiled for (A/B knob) */
 #endif
-    __shared__ __attribute__((aligned(16))) double s_hj[NCOL * DP];
+template <int D, int NS2, bool GRAD, int Q>
+__global__ __launch_bounds__(256, Q == 0 ? GPMPC_FUSED_SB_WAVES : 1) void k_step_fused(FusedArgs A, int t) {
+    constexpr bool SB = Q == 0;
+    constexpr int QQ = SB ? 1 : Q;
+    constexpr int DS = NS2, DA = D - NS2, NM = GRAD ? 1 + 2 * D : 1, DP = (D + 1) & ~1;
+    constexpr int NV = 1 + 2 * D, NT = 256, CW = 16 / QQ, NCOL = 64 / QQ;          // NCOL columns of a chunk per workgroup
+    constexpr int TABN = GPMPC_EXP_N / NT; (void)TABN;
+    constexpr bool TABLE = SB || GPMPC_FUSED_TABLE;
+    constexpr int GW = (D + 1 + NS2 + 1) & ~1;                                     // doubles per G row, as PairSbTraits
+    __shared__ double s_tab[TABLE ? GPMPC_EXP_N : 1];
+    __shared__ __attribute__((aligned(16))) double s_hj[SB ? 2 : NCOL * DP];
     __shared__ double s_red[16 * NV];
     __shared__ double s_out[NV];
     __shared__ double s_zw[GPMPC_MAX_DS];
@@ -119,12 +131,10 @@ __global__ __launch_bounds__(256) void k_step_fused(FusedArgs A, int t) {
     //      followed by its own s_waitcnt, which serialises the round trips. ---------------------------------------------------
     int unit = 0, i0 = 0, j0 = 0, j1 = 0, jq = 0;
     double xrow[D], xcol[D], mpre[CW];
-#if GPMPC_FUSED_TABLE
-    double tabreg[TABN];
-#endif
+    double tabreg[(TABLE && !SB) ? TABN : 1];
     if (role == 0) {
-        const int item = (int)blockIdx.x / Q;
-        jq = ((int)blockIdx.x - item * Q) * NCOL;                                     // this workgroup's columns of every chunk
+        const int item = (int)blockIdx.x / QQ;
+        jq = ((int)blockIdx.x - item * QQ) * NCOL;                                    // this workgroup's columns of every chunk
         if (A.tri64) {
             const int T = Np >> 6, per = T * (T + 1) / 2;
             unit = item / per;
@@ -174,7 +184,18 @@ __global__ __launch_bounds__(256) void k_step_fused(FusedArgs A, int t) {
             }
         }
     }
-    if (role == 0) {
+    if (role == 0 && SB) {
+        // 256 x 64 tile: wave w owns rows i0 + 64 w ... (clamped: the last row tile of a padded size that is no multiple of 256
+        // has waves past the end, which skip the column loop), wave 0 also fetches the tile's 64 columns, one per lane
+        const int ir = i0 + 64 * w + lane;
+#pragma unroll
+        for (int k = 0; k < D; ++k) xrow[k] = A.XT[(size_t)k * Np + (ir < Np ? ir : Np - 1)];
+        if (w == 0) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) xcol[k] = A.XT[(size_t)k * Np + j0 + lane];
+        }
+    }
+    if (role == 0 && !SB) {
 #pragma unroll
         for (int k = 0; k < D; ++k) xrow[k] = A.XT[(size_t)k * Np + i0 + lane];      // the 4 waves share the tile's 64 rows
         const int jfirst = (j0 + 63 < i0) ? j0 + 64 : j0;                             // first column chunk that carries weight
@@ -187,14 +208,22 @@ __global__ __launch_bounds__(256) void k_step_fused(FusedArgs A, int t) {
 #pragma unroll
         for (int q = 0; q < CW; ++q) mpre[q] = Mc[(size_t)(w * CW + q) * Np];
     }
-#if GPMPC_FUSED_TABLE
-    if (role == 0) {
+    if (SB && role == 0) {
+        // exp table: global -> LDS directly (16 x 1 KiB wave-instructions per workgroup, no registers held while they fly);
+        // the compiler drains them (vmcnt) in front of the barrier that ends phase 1
+        typedef const void __attribute__((address_space(1))) gvoid;
+        typedef void __attribute__((address_space(3))) lvoid;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = ((w * 4 + r) * 64 + lane) * 2;
+            __builtin_amdgcn_global_load_lds((gvoid*)(gpmpc_exp2_table + e), (lvoid*)(s_tab + e), 16, 0, 0);
+        }
+    } else if (TABLE && role == 0) {
 #pragma unroll
         for (int r = 0; r < TABN; ++r) tabreg[r] = gpmpc_exp2_table[tid + r * NT];   // LDS write deferred: see below
     }
-#endif
     // mean sums: this thread's first points (the loop below loads the ones beyond)
-    constexpr int PF = 2;
+    constexpr int PF = SB ? 1 : 2;                                  // (mid-size form: registers; N >= 1024 loops anyway)
     double xpt[PF][D], bpt[PF], sf_a = 0.0;
     if (role == 1) {
 #pragma unroll
@@ -252,16 +281,128 @@ __global__ __launch_bounds__(256) void k_step_fused(FusedArgs A, int t) {
         s_sck[k] = sc;
         s_cv[k] = sc * uk;
     }
-#if GPMPC_FUSED_TABLE
-    if (role == 0) {
+    if (TABLE && !SB && role == 0) {
 #pragma unroll
         for (int r = 0; r < TABN; ++r) s_tab[tid + r * NT] = tabreg[r];
     }
-#endif
     __syncthreads();
     GPMPC_STAMP(3);
 
+    if constexpr (SB) {
     if (role == 0) {
+        // ---- 256 x 64 tile of the N^2 sum of step t, scalar-broadcast form (pair_kernel_sb.h: same expressions, same order) ----
+        double sck[D], cv[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) { sck[k] = s_sck[k]; cv[k] = s_cv[k]; }
+        double* __restrict__ Gs = A.gscr + ((size_t)b * A.nwork + blockIdx.x) * (size_t)(64 * GW);
+        if (w == 0) {                                                    // column rows of this tile, one column per lane
+            double g[GW], qh = 0.0;
+#pragma unroll
+            for (int k = 0; k < GW; ++k) g[k] = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const double h = fma(-sck[k], xcol[k], cv[k]);
+                g[k] = h;
+                qh = fma(h, h, qh);
+                if (k < NS2) g[D + 1 + k] = h * h;
+            }
+            g[D] = GPMPC_EXP_NEG_INV_C * qh;
+            double2* dst = reinterpret_cast<double2*>(Gs + (size_t)lane * GW);
+#pragma unroll
+            for (int k = 0; k < GW / 2; ++k) dst[k] = make_double2(g[2 * k], g[2 * k + 1]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the rows are in L2 (this CU's vector L1 writes through)
+            __builtin_amdgcn_s_dcache_inv();                             // drop what the scalar cache may hold of this slot
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        const int iw0 = i0 + w * 64;
+        double hi2[D], qi;
+        {
+            double q = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const double h = fma(-sck[k], xrow[k], cv[k]);
+                hi2[k] = (2.0 * GPMPC_EXP_NEG_INV_C) * h;
+                q = fma(h, h, q);
+            }
+            qi = GPMPC_EXP_NEG_INV_C * q;
+        }
+        constexpr int NA = GRAD ? 1 + D + NS2 : 1;
+        double acc[NA];
+#pragma unroll
+        for (int m = 0; m < NA; ++m) acc[m] = 0.0;
+        __syncthreads();                                                 // G rows and exp table ready
+        GPMPC_STAMP(4);
+        if (iw0 < Np && j0 >= iw0) {                                     // tiles left of the wave's diagonal block carry no weight
+            // the scratch slot was written by this workgroup a moment ago: take the address through an opaque asm so that the
+            // constant-address-space loads below (scalar loads) cannot be moved in front of the stores and the barrier
+            const double* Gl = Gs;
+            asm volatile("" : "+s"(Gl) :: "memory");
+            const __amdgpu_buffer_rsrc_t Mrs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<double*>(A.M + (size_t)unit * Np * Np + (size_t)j0 * Np + iw0), 0, 0x7fffffff, 0x00020000);
+            const int lane8 = lane * 8;
+            constexpr int CU = 4;
+            for (int jc = 0; jc < j1 - j0; jc += CU) {
+                double mij[CU];
+#pragma unroll
+                for (int q = 0; q < CU; ++q)
+                    mij[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, (jc + q) * Np * 8, 0));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < CU; ++q) {
+                    typedef const double __attribute__((address_space(4))) gpmpc_cdouble;
+                    const gpmpc_cdouble* __restrict__ g = (const gpmpc_cdouble*)(Gl + (size_t)(jc + q) * GW);
+                    double sx = qi + g[D];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) sx = fma(hi2[k], g[k], sx);
+                    const double P = mij[q] * gpmpc_exp_neg_scaled(sx, s_tab);
+                    acc[0] += P;
+                    if (GRAD) {
+#pragma unroll
+                        for (int k = 0; k < D; ++k) acc[GRAD ? 1 + k : 0] = fma(P, g[k], acc[GRAD ? 1 + k : 0]);
+#pragma unroll
+                        for (int k = 0; k < NS2; ++k) acc[GRAD ? 1 + D + k : 0] = fma(P, g[D + 1 + k], acc[GRAD ? 1 + D + k : 0]);
+                    }
+                }
+            }
+        }
+        GPMPC_STAMP(5);
+        {
+            double z[NM];
+#pragma unroll
+            for (int m = 0; m < NM; ++m) z[m] = 0.0;
+            const double rs = acc[0];
+            z[0] = rs;
+            if (GRAD) {
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    const double h = (0.5 / GPMPC_EXP_NEG_INV_C) * hi2[k], v = acc[GRAD ? 1 + k : 0];
+                    z[GRAD ? 1 + k : 0] = fma(h, rs, v);
+                    if (k < NS2) z[GRAD ? 1 + D + k : 0] = fma(h * h, rs, fma(2.0 * h, v, acc[GRAD ? 1 + D + (k < NS2 ? k : 0) : 0]));
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                const double sr = wave_row_sum(z[m]);
+                if ((lane & 15) == 0) s_red[(w * 4 + (lane >> 4)) * NM + m] = sr;
+            }
+        }
+        __syncthreads();
+        GPMPC_STAMP(6);
+        if (tid < NM) {
+            double sum = 0.0;                                            // fixed order: waves, each as (row 0 + row 1) + (row 2 + row 3)
+            for (int ww = 0; ww < 4; ++ww) {
+                const double* r4 = &s_red[ww * 4 * NM + tid];
+                sum += (r4[0] + r4[NM]) + (r4[2 * NM] + r4[3 * NM]);
+            }
+            A.part[(((size_t)pcur * A.B + b) * A.nwork + blockIdx.x) * A.nm + tid] = sum;
+            if (tid == 0) A.partz[((size_t)pcur * A.B + b) * A.nwork + blockIdx.x] = sum;
+        }
+        GPMPC_STAMP(7);
+        return;
+    }
+    }
+
+    if (role == 0 && !SB) {
         // ---- piece of a tile of the N^2 sum of step t (staged form of pair_kernel.h: diagonal S, one trajectory) ------------
         double hi[D], sck[D], cv[D];
 #pragma unroll
@@ -298,11 +439,7 @@ __global__ __launch_bounds__(256) void k_step_fused(FusedArgs A, int t) {
                 double s = sq[0];
 #pragma unroll
                 for (int k = 1; k < D; ++k) s += sq[k];
-#if GPMPC_FUSED_TABLE
-                const double P = mpre[q] * gpmpc_exp_neg(s, s_tab);
-#else
-                const double P = mpre[q] * exp(-s);
-#endif
+                const double P = mpre[q] * (GPMPC_FUSED_TABLE ? gpmpc_exp_neg(s, s_tab) : exp(-s));
                 acc[0] += P;
                 if (GRAD) {
 #pragma unroll
@@ -444,16 +581,18 @@ __global__ __launch_bounds__(256) void k_step_fused(FusedArgs A, int t) {
 
 template <int D, int NS2, bool GRAD, int Q>
 static int launch_step_fused_one(const FusedArgs& a, int t, hipStream_t s) {
+    if (Q == 0 && !a.gscr) return GPMPC_E_ARG;
     hipLaunchKernelGGL((k_step_fused<D, NS2, GRAD, Q>), dim3(a.nwork + 2 * NS2, a.B), dim3(256), 0, s, a, t);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { gpmpc_set_error("fused step kernel launch", e); return GPMPC_E_LAUNCH; }
     return GPMPC_OK;
 }
 
-// ns2 = state_dim: D - ns2 in {0, 1, 2} action dimensions; q = 1 (whole tiles) or 4 (a quarter of a tile's columns per workgroup)
+// ns2 = state_dim: D - ns2 in {0, 1, 2} action dimensions; q = 1 (whole tiles), 4 (a quarter of a tile's columns per workgroup)
+// or 0 (256 x 64 tiles, scalar-broadcast column loop: the mid-size form)
 template <int D>
 int gpmpc_launch_step_fused_D(bool grad, int ns2, int q, const FusedArgs& a, int t, hipStream_t s) {
-    if (a.nm != (grad ? 1 + 2 * D : 1) || (q != 1 && q != 4)) return GPMPC_E_ARG;
+    if (a.nm != (grad ? 1 + 2 * D : 1) || (q != 0 && q != 1 && q != 4)) return GPMPC_E_ARG;
 #define GPMPC_FUSED_CASE(GR, QV)                                                                                   \
     if (grad == GR && q == QV) {                                                                                   \
         if (ns2 == D) return launch_step_fused_one<D, D, GR, QV>(a, t, s);                                         \
@@ -465,6 +604,8 @@ int gpmpc_launch_step_fused_D(bool grad, int ns2, int q, const FusedArgs& a, int
     GPMPC_FUSED_CASE(true, 4)
     GPMPC_FUSED_CASE(false, 1)
     GPMPC_FUSED_CASE(false, 4)
+    GPMPC_FUSED_CASE(true, 0)
+    GPMPC_FUSED_CASE(false, 0)
 #undef GPMPC_FUSED_CASE
     return GPMPC_E_ARG;
 }

@@ -3,7 +3,9 @@
 The rollout picks its kernel by the amount of work (csrc/step.hip::plan_rollout, csrc/moment.hip::plan_mom):
 
     one launch per step, 64-row tiles (step_fused.h)      small batches (the staged pair_kernel.h with GPMPC_FUSED=0 / full S)
-    scalar broadcast, 256x64 tiles   (pair_kernel_sb.h)   B * tiles >= 1700, one trajectory per wave
+    one launch per step, 256x64 tiles (step_fused.h Q=0)  B * tiles from 1250 / 1700 up to ~4700 workgroups (scalar-broadcast column loop)
+    scalar broadcast, 256x64 tiles   (pair_kernel_sb.h)   beyond, one trajectory per wave
+    scalar broadcast, 256x128 tiles  (pair_kernel_sb.h)   >= 2800 workgroups of two trajectories per wave, N > 512
     scalar broadcast, 256x256 tiles  (pair_kernel_sb.h)   >= 2800 workgroups of two trajectories per wave (D <= 5), >= 1500 of one
     scalar broadcast, full S         (pair_kernel_sbf.h)  full-covariance rollout / moment matching on large batches
 
@@ -49,8 +51,20 @@ def test_diag_rollout_every_shape_vs_cport(G, ds, da):
     pb, kinv = _problem(40 + 8 * ds + da, N, ds, da, H, b_big)
     pack = G.GPPack(pb["X"], pb["Y"], kinv, pb["lambdas"], pb["sigma_f"])
     cost = G.CostParams(-1.0, pb["Q"], pb["R"])
-    for B in (3, b_mid, b_big):
-        r = G.rollout(pack, pb["x0"][:B], pb["U"][:B], cost)
+    import os
+    for B, env in ((3, None), (b_mid, None), (b_mid, {"GPMPC_FUSED_SB": "1"}), (b_big, None)):
+        # b_mid runs twice: as head kernel + pair_kernel_sb.h on the 256x64 tiles (the plan for a training set of less than one
+        # 256-row tile, and for more than ~4700 tile workgroups) and, forced, as one launch per step on the same tiles
+        # (step_fused.h, Q = 0: the plan from ~400 to ~4700 tile workgroups of a larger training set)
+        try:
+            os.environ.update(env or {})
+            pack.reload_tuning()
+            r = G.rollout(pack, pb["x0"][:B], pb["U"][:B], cost)
+            f = G.rollout(pack, pb["x0"][:B], pb["U"][:B], cost, want_grad=False)       # the GRAD = false instances
+        finally:
+            for k in env or {}:
+                os.environ.pop(k, None)
+            pack.reload_tuning()
         assert all(torch.isfinite(v).all() for v in r.values())
         pick = sorted({0, 1, B // 2, B - 1})
         c = cport.rollout(pb, kinv, -1.0, x0=pb["x0"][pick], U=pb["U"][pick], nthreads=8)
@@ -58,7 +72,6 @@ def test_diag_rollout_every_shape_vs_cport(G, ds, da):
         np.testing.assert_allclose(r["vars"][pick].cpu().numpy(), c["vars"], rtol=1e-4, atol=1e-12, err_msg=f"B={B}")
         np.testing.assert_allclose(r["cost"][pick].cpu().numpy(), c["cost"], rtol=1e-6, err_msg=f"B={B}")
         np.testing.assert_allclose(r["grad"][pick].cpu().numpy(), c["grad"], rtol=1e-4, atol=1e-7, err_msg=f"B={B}")
-        f = G.rollout(pack, pb["x0"][:B], pb["U"][:B], cost, want_grad=False)       # the GRAD = false instances
         np.testing.assert_allclose(f["cost"].cpu().numpy(), r["cost"].cpu().numpy(), rtol=1e-9)
         np.testing.assert_allclose(f["vars"].cpu().numpy(), r["vars"].cpu().numpy(), rtol=1e-7)
 
