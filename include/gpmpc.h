@@ -196,10 +196,11 @@ int gpmpc_cost_grad(int B, int H, int state_dim, int action_dim, const gpmpc_cos
  *   x0 dev [B][ds]; U dev [B][H][da]
  *   out_means dev [B][H+1][ds]; out_vars dev [B][H+1][ds]  (either may be NULL)
  *   out_cost dev [B]; out_grad dev [B][H][da] (required with GPMPC_WANT_GRAD)
- * Mid-size batches (a few to a few dozen trajectories) are run as 2-4 concurrent sub-batches on streams owned by the pack,
- * forked from and joined back into `stream` with events (parallel branches of the graph under GPMPC_USE_GRAPH): the caller
- * still sees ONE call ordered on ONE stream, results are bit-identical to the unsplit launch, and the workspace size
- * reported below covers the sub-batches' slices.
+ * Mid-size batches (a few to a few dozen trajectories) are run as 2-4 concurrent sub-batches (2 when launched plainly) on
+ * streams owned by the pack, forked from and joined back into `stream` with events (parallel branches of the graph under
+ * GPMPC_USE_GRAPH): the caller still sees ONE call ordered on ONE stream, results are bit-identical to the unsplit launch,
+ * and the workspace size reported below covers the sub-batches' slices.  Small and mid-size batches (up to ~4700 tile
+ * workgroups per horizon step) are one kernel launch per horizon step; larger ones two (head + pair kernel).
  * ------------------------------------------------------------------------- */
 size_t gpmpc_rollout_workspace_bytes(const gpmpc_pack* pack, int B, int H, unsigned flags);
 int gpmpc_rollout(const gpmpc_pack* pack, int B, int H, const double* x0_dev, const double* U_dev,
