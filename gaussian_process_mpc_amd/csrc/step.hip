@@ -912,7 +912,7 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     // it loses (N = 1024, B = 1 x0.92; N = 512, B = 4 x0.77), and so do training sets of less than one row tile (N = 128, B = 128 x0.89)
     const long wg2 = (long)B * p->wl[0][2].nwork;
     const bool shared_on = p->shared_lambda && p->tune.shared != 0 && p->sh_ng >= 2;
-    const bool fsb_can = sb_ok && !lowprec && p->da >= 1 && p->tune.fused_sb != 0 && !shared_on && (p->Np >= 256 || p->tune.fused_sb == 1) &&
+    const bool fsb_can = sb_ok && !lowprec && p->da >= 1 && p->tune.fused_sb != 0 && (p->Np >= 256 || p->tune.fused_sb == 1) &&
                          p->wl[0][2].nwork <= (p->tune.fused_sb == 1 ? 600 : 320) * p->ds;
     const bool mid = !big && sb_ok && (wg2 >= (p->Np >= 1024 ? 1250 : 1700) || (fsb_can && wg2 >= 400));
     // 256x128 tiles with two trajectories per wave where they already give the workgroups the 256x256 tiles do not yet
@@ -954,7 +954,11 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     // N = 2048, B = 4 / 6 / 8 / 12 x1.17 / 1.10 / 1.06 / 0.97; N = 768, B = 24 / 48 x1.36 / 1.13: up to ~4700 tile workgroups per
     // launch (beyond, the longer prologue of every tile workgroup costs more than the head kernel it replaces).
     // (N > ~2100 -- more than 320 tiles per GP -- stays on head + pair kernel: N = 4096, B = 1 4.35 vs 3.73 ms)
-    if (r->sb && r->tiling == 2 && r->tb == 1 && fsb_can && (tn.fused_sb == 1 || wg2 <= 4700))
+    // With ONE lambda for all GPs the shared-lambda pair kernel (two launches per step) is the alternative: the one-launch form,
+    // which evaluates the exponent per GP, is still ahead up to ~3000 tile workgroups (profiles/r03/ab_fused_sb_vs_shared.txt:
+    // N = 1024, B = 8 / 12 / 16 / 24 / 32 x1.52 / 1.45 / 1.20 / 0.99 / 0.75; N = 2048, B = 2 / 4 / 8 x1.37 / 1.29 / 0.85;
+    // N = 512, ds = 3, B = 32 / 64 x1.38 / 1.27; N = 768, B = 24 / 48 x1.33 / 0.88).
+    if (r->sb && r->tiling == 2 && r->tb == 1 && fsb_can && (tn.fused_sb == 1 || wg2 <= (shared_on ? 3000 : 4700)))
         r->fused = 2;
     if (r->fused) r->tb = 1;
     // a quarter of a tile's columns per workgroup while whole tiles would leave most SIMDs without a wave
@@ -964,7 +968,7 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     // Shared length-scales: one exponent / exp per pair for a group of GPs (pair_kernel_sbs.h) wherever the scalar-broadcast
     // kernel would run.  256x256 tiles once they give ~1700 workgroups (one trajectory per workgroup), else 256x64.
     r->shared = 0; r->sh_list = 0;
-    if (r->sb && !lowprec && p->shared_lambda && tn.shared != 0 && p->sh_ng >= 2) {
+    if (r->sb && r->fused != 2 && !lowprec && p->shared_lambda && tn.shared != 0 && p->sh_ng >= 2) {
         r->shared = 1;
         // (round 3: a 256x128 list, wl_sh[2], is built for the A/B only -- GPMPC_TILING=4 --: with one trajectory per workgroup it has
         // nothing to share that the 256x64 tiles under the concurrent sub-batches do not have; N = 2048, B = 16...40 -3...-20 %,
