@@ -1,15 +1,21 @@
 #!/usr/bin/env python3
 """Phase timeline of the fused small-batch step kernel (diagnostic build, see csrc/step_fused.h):
     make -C gaussian_process_mpc_amd/csrc clean && make -C gaussian_process_mpc_amd/csrc -j8 EXTRA=-DGPMPC_FUSED_STAMPS
-    python tools/fused_stamps.py        (C2 sizes: D = 4)"""
+    python tools/fused_stamps.py        (C2 sizes: D = 4)
+    python tools/fused_stamps.py 1024:3:1:20:16      (any shape with D = 4; mid-size ones run the 256x64 scalar-broadcast form)
+A diagnostic library built beside the product (make BUILD=build_fst LIB=libgpmpc_hip_fst.so EXTRA=-DGPMPC_FUSED_STAMPS) is loaded
+with GPMPC_LIB_PATH."""
 import ctypes, sys
 import numpy as np, torch
 sys.path.insert(0, ".")
 import gaussian_process_mpc_amd as g
 from gaussian_process_mpc_amd.synth import CONFIGS, synth_problem
 from oracle import gpmpc_oracle as O
-cfg = CONFIGS["C2"]
-pb = synth_problem(2, cfg["N"], cfg["ds"], cfg["da"], cfg["H"], 1)
+cfg = dict(CONFIGS["C2"])
+if len(sys.argv) > 1:
+    cfg["N"], cfg["ds"], cfg["da"], cfg["H"], cfg["B"] = (int(v) for v in sys.argv[1].split(":"))
+assert cfg["ds"] + cfg["da"] == 4, "the stamps are compiled into the D = 4 instances"
+pb = synth_problem(2, cfg["N"], cfg["ds"], cfg["da"], cfg["H"], cfg["B"])
 gp = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"])
 pack = g.GPPack(pb["X"], pb["Y"], gp.Ky_inv.numpy(), pb["lambdas"], pb["sigma_f"])
 cost = g.CostParams(-1.0, pb["Q"], pb["R"])
