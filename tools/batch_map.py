@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Rollouts/s over (N, state_dim, batch size): where each kernel shape of plan_rollout (step.hip) sits against the
 pair-evaluation rate of the large-batch kernel.  Objective + gradient, inputs resident, each rollout replayed as one
-hipGraph below B = 32.  `eff` = pairs/s relative to the pair rate measured at the largest batch of the same (N, ds).
+hipGraph up to B = 128.  `eff` = pairs/s relative to the pair rate measured at the largest batch of the same (N, ds).
 
     python tools/batch_map.py [--quick]            # optional GPMPC_TILING / GPMPC_PAIR_SB / GPMPC_FUSED overrides apply
 """
@@ -42,7 +42,7 @@ for shape in args.shapes.split(","):
             continue
         x0 = torch.as_tensor(pb["x0"][:B], device=dev)
         U = torch.as_tensor(pb["U"][:B], device=dev)
-        graph = B < 32 and not args.fullcov
+        graph = B <= 128 and not args.fullcov
         run = (lambda: rollout_fullcov(pack, x0, U, cost)) if args.fullcov else (lambda: rollout(pack, x0, U, cost, want_grad=True, want_traj=False, graph=graph))
         reps = max(10, min(200, int((1e9 if args.quick else 4e9) / (B * H * (ds * ds if args.fullcov else ds) * N * N / 2 * 30))))
         for _ in range(3):
