@@ -882,12 +882,18 @@ struct RollPlan { int tiling, tb, waves, nwork, nm, pps, sps, sb, gw, rgroup, fu
 static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag, RollPlan* r, bool lowprec = false,
                          const RollPlan* shape = nullptr) {
     const int D = p->D;
-    // Shapes, by how many workgroups they give (>= 1024 fills the 256 CUs four deep):
-    //   256x256 tiles, scalar-broadcast kernel   large batches (C3: 2.2 ms per launch; staged kernel TB 2: 2.82)
-    //   256x64 tiles, scalar-broadcast kernel    small batches of a large N (N = 2048: B = 2..8 run 17-39 % faster than
-    //                                            on one-wave tiles; 256x32 only helps B = 1, by 2 %)
-    //   64x64 / 64x128 tiles, staged kernel      everything smaller (too few waves to hide the scalar loads); the rows
-    //                                            of a tile are shared by 4 waves that split its columns
+    // The selection as it stands (diagonal rollout, da <= 2; every threshold is a measured crossover -- its numbers are in the
+    // comment at its line, the method in DESIGN.md section 5, the maps in profiles/r02 and r03/batch_size_map.txt):
+    //   W64 = B x tiles(256x64) < ~400, or N < 256, or N > ~2100 below 1250     ONE launch per step, 64-row tiles, staged column loop
+    //                                                                           (step_fused.h, Q = 1 | 4; the B = 1 solver callbacks)
+    //   ~400 <= W64 <= ~4700 (3000 with one lambda for all GPs), 256 <= N <= ~2100   ONE launch per step, 256x64 tiles, scalar-broadcast
+    //                                                                           column loop (step_fused.h, Q = 0), two concurrent sub-batches
+    //   W64 beyond, until a wide tiling fills the chip                          head kernel + pair_kernel_sb.h on 256x64 tiles, one trajectory per
+    //                                                                           wave (pair_kernel_sbs.h with one lambda), 2-4 concurrent sub-batches
+    //   ceil(B/2) x tiles(256x128) >= 2800, N > 512, D <= 5                     head + pair_kernel_sb.h on 256x128 tiles, two trajectories per wave
+    //   ceil(B/2) x tiles(256x256) >= 2800 (1100 for N <= 512); D >= 6:         head + pair_kernel_sb.h on 256x256 tiles (the big batches: C3, C4);
+    //   B x tiles(256x256) >= 1500; one lambda: B x tiles >= 1700               XCD-aware dispatch, rgroup 4
+    //   full covariance / da > 2 / the fp32 sweep modes                         staged pair_kernel.h (fullcov.hip has its own plan)
     const bool sb_ok = diag && p->da <= 2;
     // 256x256 tiles once they give enough workgroups (profiles/r02/batch_size_map.txt): with two trajectories per wave
     // (D <= 5) from ~2800 on -- N = 2048: B = 32 5.28 k rollouts/s vs 5.45 k on 256x64, B = 48 equal, B = 64 6.02 k vs 5.76 k;
