@@ -35,7 +35,7 @@ struct gpmpc_worklist {
 // -1 / 0 = not set: the measured defaults of plan_rollout / plan_mom apply.
 struct gpmpc_tuning {
     int pair_sb;     // GPMPC_PAIR_SB     0 staged kernel | 1 scalar broadcast | -1 unset
-    int tiling;      // GPMPC_TILING      0..4 | -1 unset
+    int tiling;      // GPMPC_TILING      0..6 | -1 unset
     int tb;          // GPMPC_PAIR_TB     1 | 2 | 4 | 0 unset
     int rgroup;      // GPMPC_RGROUP      1..16 | 0 unset
     int no_first;    // GPMPC_NO_FIRST    full moments at horizon step 1 too
@@ -72,8 +72,9 @@ struct gpmpc_pack {
     double sf_host[GPMPC_MAX_DS];
     void* graph_cache;         // captured rollout (GPMPC_USE_GRAPH), owned by step.hip
     void* cb_cache;            // buffers + captured graph of gpmpc_objective_gradient (solver callbacks), owned by step.hip
-    // [0: variance units only | 1: + cross units][0: 256x256 tiles | 1: 64x64 | 2: 256x64 | 3: 64x128 | 4: 256x128 (mode 0 only)]
-    gpmpc_worklist wl[2][5];
+    // [0: variance units only | 1: + cross units][0: 256x256 tiles | 1: 64x64 | 2: 256x64 | 3: 64x128 | 4: 256x128 | 5: 256x32 | 6: 256x16
+    //  (4...6: mode 0 only)]
+    gpmpc_worklist wl[2][7];
     // shared-lambda path (pair_kernel_sbs.h): every GP has bit-identical length-scales (detected at gpmpc_pack_build)
     int shared_lambda;
     int sh_ng;                 // GPs per workgroup

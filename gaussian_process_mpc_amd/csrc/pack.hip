@@ -249,10 +249,12 @@ extern "C" int gpmpc_pack_create(gpmpc_pack** out, int n_train, int state_dim, i
     // rollout; N <= 512 is 10 % slower on it and stays on 64x64).
     // 256x128: between the 256x64 and the 256x256 shapes, two trajectories per wave (round 3: N = 2048, B = 24 / 32 +19 / +21 %
     // against 256x64, N = 1024, B = 96 / 128 +10 / +14 %; -3...-4 % against 256x256 from ~5 generations of workgroups on).
-    int cfg[5][2] = {{256, 256}, {64, 64}, {256, 64}, {64, 128}, {256, 128}};
+    // 256x32 / 256x16: the one-launch-per-step form (step_fused.h) on launches that would leave most of the chip without a workgroup
+    // (B = 1...4 of a large N): narrower tiles, more and shorter-lived tile workgroups.
+    int cfg[7][2] = {{256, 256}, {64, 64}, {256, 64}, {64, 128}, {256, 128}, {256, 32}, {256, 16}};
     if (const char* ev = getenv("GPMPC_JT0")) { const int v = atoi(ev); if (v >= 64 && v % 64 == 0) cfg[0][1] = v; }   // A/B: column extent of the large tiles
     for (int mode = 0; mode < 2 && ok; ++mode)
-        for (int k = 0; k < 5 && ok; ++k) {
+        for (int k = 0; k < 7 && ok; ++k) {
             if (mode == 1 && k >= 2) continue;
             ok = build_worklist(p->Np, cfg[k][0], cfg[k][1], state_dim, mode ? p->npairs : 0,
                                 mode == 0 && (k == 0 || k == 4) && !p->tune.no_xcd_sort, &p->wl[mode][k]) == 0;
@@ -296,7 +298,7 @@ extern "C" int gpmpc_pack_destroy(gpmpc_pack* p) {
     gpmpc_cb_cache_free(p->cb_cache);
     if (p->pair_ab_dev) (void)hipFree(p->pair_ab_dev);
     for (int mode = 0; mode < 2; ++mode)
-        for (int k = 0; k < 5; ++k) {
+        for (int k = 0; k < 7; ++k) {
             if (p->wl[mode][k].work_dev) (void)hipFree(p->wl[mode][k].work_dev);
             if (p->wl[mode][k].perm_dev) (void)hipFree(p->wl[mode][k].perm_dev);
             if (p->wl[mode][k].ustart_dev) (void)hipFree(p->wl[mode][k].ustart_dev);

@@ -920,7 +920,17 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     const bool shared_on = p->shared_lambda && p->tune.shared != 0 && p->sh_ng >= 2;
     const bool fsb_can = sb_ok && !lowprec && p->da >= 1 && p->tune.fused_sb != 0 && (p->Np >= 256 || p->tune.fused_sb == 1) &&
                          p->wl[0][2].nwork <= (p->tune.fused_sb == 1 ? 600 : 320) * p->ds;
-    const bool mid = !big && sb_ok && (wg2 >= (p->Np >= 1024 ? 1250 : 1700) || (fsb_can && wg2 >= 400));
+    // ... and with NARROWER tiles (256x32, 256x16: work lists 5, 6) further down for training sets of at least two row tiles: a launch
+    // of a few hundred 256x64 workgroups leaves most of the chip empty while each workgroup walks its 64 columns one L2 round trip
+    // at a time (N = 2048, B = 1: 24.5 us per launch on 576 workgroups, profiles/r03/kernel_stats_C3_B1.csv); half / quarter tiles
+    // give 2x / 4x the workgroups, each living half / a quarter as long (profiles/r03/ab_fused_sb_narrow_tiles.txt, ms per rollout
+    // on 64 / 32 / 16 columns: N = 1024, B = 1 0.359 / 0.300 / 0.270 (64-row form 0.330), B = 2 0.409 / 0.359 / 0.359, B = 4
+    // 0.561 / 0.484 / 0.514, B = 8 0.673 / 0.661 / 0.825; N = 1536, ds = 3, B = 1 0.391 / 0.330 / 0.308, B = 2 0.503 / 0.417 / 0.502;
+    // N = 512, ds = 3, B = 8 0.434 / 0.357 / 0.325, B = 16 0.481 / 0.396 / 0.407; N = 2048, B = 1 0.554 / 0.539 / 0.679 -- every tile
+    // workgroup re-reduces its trajectory's partial sums, 2304 of them there on 16 columns; N <= 448: the 64-row form stays ahead
+    // until ~400 workgroups, N = 400, ds = 2, B = 16 0.179 vs 0.200 / 0.190)
+    const bool narrow_ok = fsb_can && p->Np >= 512;
+    const bool mid = !big && sb_ok && (wg2 >= (p->Np >= 1024 ? 1250 : 1700) || (fsb_can && wg2 >= (narrow_ok ? 150 : 400)));
     // 256x128 tiles with two trajectories per wave where they already give the workgroups the 256x256 tiles do not yet
     // (profiles/r03/ab_tiling_256x128.txt: N = 2048, B = 24 / 32 4.02 / 5.07 vs 4.78 / 6.12 ms on 256x64; N = 1024, B = 96 / 128
     // 4.51 / 5.71 vs 4.98 / 6.49 ms; from there on 256x256 is 3-4 % ahead)
@@ -928,12 +938,14 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     r->sb = (sb_ok && (big || mid)) ? 1 : 0;
     const bool many = (long)p->wl[0][1].nwork > 256L * p->ds;        // > 256 one-wave tiles per GP (N >= 1472)
     r->tiling = big ? 0 : (big128 ? 4 : (mid ? 2 : (many ? 3 : 1)));
+    if (r->tiling == 2 && narrow_ok && wg2 < 1000)           // 32 columns from ~300 workgroups of 64, 16 below (while the partial sums
+        r->tiling = (wg2 >= 300 || p->wl[0][6].nwork > 1300) ? 5 : 6;      // of a trajectory stay within ~1300)
     const gpmpc_tuning& tn = p->tune;                        // GPMPC_* overrides, read once at pack creation
     if (tn.pair_sb >= 0) {                                   // 0 = staged kernel, 1 = scalar broadcast
         r->sb = (tn.pair_sb != 0 && sb_ok) ? 1 : 0;
         r->tiling = r->sb ? (big ? 0 : (big128 ? 4 : 2)) : (big ? 0 : (many ? 3 : 1));
     }
-    if (tn.tiling >= 0) { const int v = tn.tiling; if (v == 0 || ((v == 1 || v == 3) && !r->sb) || ((v == 2 || v == 4) && r->sb)) r->tiling = v; }
+    if (tn.tiling >= 0) { const int v = tn.tiling; if (v == 0 || ((v == 1 || v == 3) && !r->sb) || ((v == 2 || v == 4) && r->sb) || ((v == 5 || v == 6) && r->sb && fsb_can)) r->tiling = v; }
     const bool wide = r->tiling == 0 || r->tiling == 4;          // 256-row tiles of the XCD-sorted lists
     // scalar-broadcast kernel: two trajectories per wave on the big tiling up to D = 5 (two independent dependency chains per
     // lane, one M_ij load for both: C3 +2.6 %, objective-only +14 %; 82 VGPRs); D = 7 (C4) is 2.5 % faster with one
@@ -966,6 +978,7 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     // N = 512, ds = 3, B = 32 / 64 x1.38 / 1.27; N = 768, B = 24 / 48 x1.33 / 0.88).
     if (r->sb && r->tiling == 2 && r->tb == 1 && fsb_can && (tn.fused_sb == 1 || wg2 <= (shared_on ? 3000 : 4700)))
         r->fused = 2;
+    if (r->sb && (r->tiling == 5 || r->tiling == 6) && r->tb == 1 && fsb_can) r->fused = 2;   // narrower tiles: this form only
     if (r->fused) r->tb = 1;
     // a quarter of a tile's columns per workgroup while whole tiles would leave most SIMDs without a wave
     r->fq = (r->fused == 1 && r->tiling == 1 && (long)B * p->wl[0][1].nwork < 256) ? 4 : 1;
@@ -1020,7 +1033,7 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     r->off_jac = take(grad ? (size_t)B * H * 2 * p->ds * (2 * p->ds + p->da) : 0);
     r->gw = gpmpc_sb_gw(D, p->ds);
     // column rows: [B][GP][Np][gw] written by the head kernel, or one [64][gw] slot per tile workgroup of the mid-size fused form
-    r->off_G = take(r->fused == 2 ? (size_t)B * r->nwork * 64 * r->gw
+    r->off_G = take(r->fused == 2 ? (size_t)B * r->nwork * p->wl[0][r->tiling].jt * r->gw
                                   : (r->sb ? (size_t)B * (r->shared ? 1 : p->ds) * p->Np * r->gw : 0));
     r->off_means = take((size_t)B * (H + 1) * p->ds);
     r->off_vars = take((size_t)B * (H + 1) * p->ds);
@@ -1167,7 +1180,7 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
         F.sps = r.sps; F.nm = r.nm;
         F.gscr = r.fused == 2 ? (double*)(ws + r.off_G) : nullptr;
         for (int t = 1; t <= H; ++t) {
-            const int rc = timed_launch(GPMPC_TIME_FUSED, s, [&] { return launch_step_fused(p->D, grad, p->ds, r.fused == 2 ? 0 : r.fq, F, t, s); });
+            const int rc = timed_launch(GPMPC_TIME_FUSED, s, [&] { return launch_step_fused(p->D, grad, p->ds, r.fused == 2 ? (r.tiling == 2 ? 0 : wl.jt) : r.fq, F, t, s); });
             if (rc != GPMPC_OK) return rc;
         }
         A.part += (size_t)(H & 1) * B * nwg * r.nm;          // the tail finishes step H from the parity the last launch wrote

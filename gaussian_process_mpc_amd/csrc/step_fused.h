@@ -81,8 +81,9 @@ static __device__ unsigned long long g_fused_stamps[64];
 #define GPMPC_FUSED_SB_WAVES 5      /* waves per SIMD the mid-size form is compiled for (A/B knob) */
 #endif
 template <int D, int NS2, bool GRAD, int Q>
-__global__ __launch_bounds__(256, Q == 0 ? GPMPC_FUSED_SB_WAVES : 1) void k_step_fused(FusedArgs A, int t) {
-    constexpr bool SB = Q == 0;
+__global__ __launch_bounds__(256, (Q == 0 || Q == 32 || Q == 16) ? GPMPC_FUSED_SB_WAVES : 1) void k_step_fused(FusedArgs A, int t) {
+    constexpr bool SB = Q == 0 || Q == 32 || Q == 16;
+    constexpr int NC = Q == 0 ? 64 : Q;                                            // columns of a tile of the mid-size form
     constexpr int QQ = SB ? 1 : Q;
     constexpr int DS = NS2, DA = D - NS2, NM = GRAD ? 1 + 2 * D : 1, DP = (D + 1) & ~1;
     constexpr int NV = 1 + 2 * D, NT = 256, CW = 16 / QQ, NCOL = 64 / QQ;          // NCOL columns of a chunk per workgroup
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256, Q == 0 ? GPMPC_FUSED_SB_WAVES : 1) void k_step
         for (int k = 0; k < D; ++k) xrow[k] = A.XT[(size_t)k * Np + (ir < Np ? ir : Np - 1)];
         if (w == 0) {
 #pragma unroll
-            for (int k = 0; k < D; ++k) xcol[k] = A.XT[(size_t)k * Np + j0 + lane];
+            for (int k = 0; k < D; ++k) xcol[k] = A.XT[(size_t)k * Np + j0 + (lane & (NC - 1))];
         }
     }
     if (role == 0 && !SB) {
@@ -294,8 +295,8 @@ __global__ __launch_bounds__(256, Q == 0 ? GPMPC_FUSED_SB_WAVES : 1) void k_step
         double sck[D], cv[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) { sck[k] = s_sck[k]; cv[k] = s_cv[k]; }
-        double* __restrict__ Gs = A.gscr + ((size_t)b * A.nwork + blockIdx.x) * (size_t)(64 * GW);
-        if (w == 0) {                                                    // column rows of this tile, one column per lane
+        double* __restrict__ Gs = A.gscr + ((size_t)b * A.nwork + blockIdx.x) * (size_t)(NC * GW);
+        if (w == 0) {                                                    // column rows of this tile, one column per lane (< NC)
             double g[GW], qh = 0.0;
 #pragma unroll
             for (int k = 0; k < GW; ++k) g[k] = 0.0;
@@ -307,9 +308,11 @@ __global__ __launch_bounds__(256, Q == 0 ? GPMPC_FUSED_SB_WAVES : 1) void k_step
                 if (k < NS2) g[D + 1 + k] = h * h;
             }
             g[D] = GPMPC_EXP_NEG_INV_C * qh;
-            double2* dst = reinterpret_cast<double2*>(Gs + (size_t)lane * GW);
+            double2* dst = reinterpret_cast<double2*>(Gs + (size_t)(lane & (NC - 1)) * GW);
+            if (NC == 64 || lane < NC) {
 #pragma unroll
-            for (int k = 0; k < GW / 2; ++k) dst[k] = make_double2(g[2 * k], g[2 * k + 1]);
+                for (int k = 0; k < GW / 2; ++k) dst[k] = make_double2(g[2 * k], g[2 * k + 1]);
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the rows are in L2 (this CU's vector L1 writes through)
             __builtin_amdgcn_s_dcache_inv();                             // drop what the scalar cache may hold of this slot
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(256, Q == 0 ? GPMPC_FUSED_SB_WAVES : 1) void k_step
                 const_cast<double*>(A.M + (size_t)unit * Np * Np + (size_t)j0 * Np + iw0), 0, 0x7fffffff, 0x00020000);
             const int lane8 = lane * 8;
             constexpr int CU = 4;
-            for (int jc = 0; jc < j1 - j0; jc += CU) {
+            for (int jc = 0; jc < NC; jc += CU) {
                 double mij[CU];
 #pragma unroll
                 for (int q = 0; q < CU; ++q)
@@ -581,7 +584,7 @@ __global__ __launch_bounds__(256, Q == 0 ? GPMPC_FUSED_SB_WAVES : 1) void k_step
 
 template <int D, int NS2, bool GRAD, int Q>
 static int launch_step_fused_one(const FusedArgs& a, int t, hipStream_t s) {
-    if (Q == 0 && !a.gscr) return GPMPC_E_ARG;
+    if ((Q == 0 || Q == 32 || Q == 16) && !a.gscr) return GPMPC_E_ARG;
     hipLaunchKernelGGL((k_step_fused<D, NS2, GRAD, Q>), dim3(a.nwork + 2 * NS2, a.B), dim3(256), 0, s, a, t);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { gpmpc_set_error("fused step kernel launch", e); return GPMPC_E_LAUNCH; }
@@ -589,10 +592,10 @@ static int launch_step_fused_one(const FusedArgs& a, int t, hipStream_t s) {
 }
 
 // ns2 = state_dim: D - ns2 in {0, 1, 2} action dimensions; q = 1 (whole tiles), 4 (a quarter of a tile's columns per workgroup)
-// or 0 (256 x 64 tiles, scalar-broadcast column loop: the mid-size form)
+// or 0 / 32 / 16 (256 x 64 / 32 / 16 tiles, scalar-broadcast column loop: the mid-size form)
 template <int D>
 int gpmpc_launch_step_fused_D(bool grad, int ns2, int q, const FusedArgs& a, int t, hipStream_t s) {
-    if (a.nm != (grad ? 1 + 2 * D : 1) || (q != 0 && q != 1 && q != 4)) return GPMPC_E_ARG;
+    if (a.nm != (grad ? 1 + 2 * D : 1) || (q != 0 && q != 1 && q != 4 && q != 16 && q != 32)) return GPMPC_E_ARG;
 #define GPMPC_FUSED_CASE(GR, QV)                                                                                   \
     if (grad == GR && q == QV) {                                                                                   \
         if (ns2 == D) return launch_step_fused_one<D, D, GR, QV>(a, t, s);                                         \
@@ -606,6 +609,10 @@ int gpmpc_launch_step_fused_D(bool grad, int ns2, int q, const FusedArgs& a, int
     GPMPC_FUSED_CASE(false, 4)
     GPMPC_FUSED_CASE(true, 0)
     GPMPC_FUSED_CASE(false, 0)
+    GPMPC_FUSED_CASE(true, 32)
+    GPMPC_FUSED_CASE(false, 32)
+    GPMPC_FUSED_CASE(true, 16)
+    GPMPC_FUSED_CASE(false, 16)
 #undef GPMPC_FUSED_CASE
     return GPMPC_E_ARG;
 }

@@ -52,10 +52,13 @@ def test_diag_rollout_every_shape_vs_cport(G, ds, da):
     pack = G.GPPack(pb["X"], pb["Y"], kinv, pb["lambdas"], pb["sigma_f"])
     cost = G.CostParams(-1.0, pb["Q"], pb["R"])
     import os
-    for B, env in ((3, None), (b_mid, None), (b_mid, {"GPMPC_FUSED_SB": "1"}), (b_big, None)):
+    narrow = {"GPMPC_FUSED_SB": "1", "GPMPC_PAIR_SB": "1"}
+    for B, env in ((3, None), (b_mid, None), (b_mid, {"GPMPC_FUSED_SB": "1"}), (5, dict(narrow, GPMPC_TILING="5")),
+                   (4, dict(narrow, GPMPC_TILING="6")), (b_big, None)):
         # b_mid runs twice: as head kernel + pair_kernel_sb.h on the 256x64 tiles (the plan for a training set of less than one
         # 256-row tile, and for more than ~4700 tile workgroups) and, forced, as one launch per step on the same tiles
-        # (step_fused.h, Q = 0: the plan from ~400 to ~4700 tile workgroups of a larger training set)
+        # (step_fused.h, Q = 0: the plan from ~400 to ~4700 tile workgroups of a larger training set); the same form on 256x32 and
+        # 256x16 tiles (Q = 32 / 16: the plan for a handful of trajectories of a large training set) is forced on small batches
         try:
             os.environ.update(env or {})
             pack.reload_tuning()
