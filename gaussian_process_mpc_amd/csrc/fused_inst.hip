@@ -8,6 +8,9 @@ template int gpmpc_launch_step_fused_D<GPMPC_PAIR_D>(bool, int, int, const Fused
 
 #if defined(GPMPC_FUSED_STAMPS) && GPMPC_PAIR_D == 4
 // diagnostic build: the stamps of the D = 4 instances of this translation unit
+extern "C" int gpmpc_debug_wg_times(unsigned long long* host_out) {      // [2][8192]
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_fused_wg), sizeof(unsigned long long) * 2 * 8192) == hipSuccess ? 0 : -3;
+}
 extern "C" int gpmpc_debug_stamps(unsigned long long* host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_fused_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -3;
 }

@@ -49,10 +49,15 @@ __device__ __forceinline__ void gpmpc_tri_decode(int q, int T, int* r_out, int* 
 // executes no stamp.
 #ifdef GPMPC_FUSED_STAMPS
 static __device__ unsigned long long g_fused_stamps[64];
-#define GPMPC_STAMP(slot) do { if (t == 5 && blockIdx.y == 0 && tid == 0 && (blockIdx.x == 0 || (int)blockIdx.x == A.nwork)) \
-    g_fused_stamps[(blockIdx.x == 0 ? 0 : 16) + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+static __device__ unsigned long long g_fused_wg[2 * 8192];         // [start | end] of every workgroup of trajectory 0 at step 5 (100 MHz counter)
+#define GPMPC_STAMP_WG(which) do { if (t == 5 && blockIdx.y == 0 && tid == 0 && blockIdx.x < 8192) g_fused_wg[(which) * 8192 + blockIdx.x] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define GPMPC_STAMP(slot) do { if (t == 5 && blockIdx.y == 0 && tid == 0 && (blockIdx.x == 0 || (int)blockIdx.x == A.nwork || (int)blockIdx.x == A.nwork + NS2)) \
+    g_fused_stamps[(blockIdx.x == 0 ? 0 : ((int)blockIdx.x == A.nwork ? 16 : 32)) + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define GPMPC_STAMP_REAL(slot) do { if (t == 5 && blockIdx.y == 0 && tid == 0 && blockIdx.x == 0) g_fused_stamps[slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define GPMPC_STAMP(slot) do { } while (0)
+#define GPMPC_STAMP_REAL(slot) do { } while (0)
+#define GPMPC_STAMP_WG(which) do { } while (0)
 #endif
 
 // The tile pieces of this kernel evaluate 4..16 columns per wave: copying the 16 KB exp table into LDS per workgroup (7 MB
@@ -114,6 +119,8 @@ __global__ __launch_bounds__(256, (Q == 0 || Q == 32 || Q == 16) ? GPMPC_FUSED_S
 #pragma unroll
     for (int a = 0; a <= DS; ++a) { ust[a] = A.ustart[a]; asm volatile("" ::"s"(ust[a])); }
     GPMPC_STAMP(0);
+    GPMPC_STAMP_WG(0);
+    GPMPC_STAMP_REAL(12);       // constant 100 MHz counter beside the shader-clock one: the clock the launch ran at
 #ifdef GPMPC_FUSED_STAMPS
     {   // diagnostic: latency of ONE read-only load (length-scales), ONE load of data the previous launch wrote (partz), alone
         const double probe1 = __builtin_nontemporal_load(A.lam);
@@ -401,6 +408,8 @@ __global__ __launch_bounds__(256, (Q == 0 || Q == 32 || Q == 16) ? GPMPC_FUSED_S
             if (tid == 0) A.partz[((size_t)pcur * A.B + b) * A.nwork + blockIdx.x] = sum;
         }
         GPMPC_STAMP(7);
+        GPMPC_STAMP_REAL(13);
+        GPMPC_STAMP_WG(1);
         return;
     }
     }
@@ -471,6 +480,8 @@ __global__ __launch_bounds__(256, (Q == 0 || Q == 32 || Q == 16) ? GPMPC_FUSED_S
             if (tid == 0) A.partz[((size_t)pcur * A.B + b) * A.nwork + blockIdx.x] = s;
         }
         GPMPC_STAMP(7);
+        GPMPC_STAMP_REAL(13);
+        GPMPC_STAMP_WG(1);
         return;
     }
 
@@ -497,6 +508,7 @@ __global__ __launch_bounds__(256, (Q == 0 || Q == 32 || Q == 16) ? GPMPC_FUSED_S
             for (int wi = A.ustart[a] + ch; wi < A.ustart[a + 1]; wi += 16) s += p[(size_t)wi * A.nm];
             s_red[m * 16 + ch] = s;
         }
+        GPMPC_STAMP(4);
         __syncthreads();
         if (tid < NM) {
             double s = 0.0;
@@ -504,6 +516,7 @@ __global__ __launch_bounds__(256, (Q == 0 || Q == 32 || Q == 16) ? GPMPC_FUSED_S
             s_out[tid] = s;
         }
         __syncthreads();
+        GPMPC_STAMP(5);
         if (tid < D) {
             const int k = tid, nc = 2 * DS + DA;
             const double c = s_c[a], mu = s_mu[a], T = c * s_z0[a];  // the Z0 sum every workgroup of this launch uses
@@ -522,6 +535,8 @@ __global__ __launch_bounds__(256, (Q == 0 || Q == 32 || Q == 16) ? GPMPC_FUSED_S
                 jv[2 * DS + (k - DS)] = dv_du;
             }
         }
+        GPMPC_STAMP(6);
+        GPMPC_STAMP_WG(1);
         return;
     }
 
@@ -580,6 +595,7 @@ __global__ __launch_bounds__(256, (Q == 0 || Q == 32 || Q == 16) ? GPMPC_FUSED_S
         sp[3 + 3 * D + k] = -0.5 * mu * Bq + 0.5 * Bq * Bq * cm * s_out[1 + D + k];
     }
     GPMPC_STAMP(7);
+    GPMPC_STAMP_WG(1);
 }
 
 template <int D, int NS2, bool GRAD, int Q>

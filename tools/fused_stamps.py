@@ -27,10 +27,29 @@ assert g.lib().gpmpc_debug_stamps(buf) == 0
 st = np.array(list(buf), dtype=np.int64)
 names_tile = ["start", "loads issued", "z0 reduced", "scalars published", "chunk staged", "columns done", "tile reduced", "written"]
 names_mean = ["start", "loads issued", "z0 reduced", "scalars published", "B/A published", "N loop done", "block sum done", "sp written"]
-for off, names, tag in ((0, names_tile, "tile workgroup 0"), (16, names_mean, "mean-sum workgroup of GP 0")):
+names_fin = ["start", "loads issued", "z0 reduced", "scalars published", "moments summed", "combined", "rows written", "-"]
+for off, names, tag in ((0, names_tile, "tile workgroup 0"), (16, names_mean, "mean-sum workgroup of GP 0"), (32, names_fin, "finish workgroup of GP 0")):
     t = st[off:off + 8]
     print(tag)
-    for k in range(1, 8):
+    for k in range(1, 7 if off == 32 else 8):
         print(f"  {names[k]:22s} +{t[k] - t[k-1]:6d} cycles   (t = {t[k] - t[0]:6d})")
+if st[13] > st[12]:
+    ns = (st[13] - st[12]) * 10.0
+    print("tile workgroup 0: %.2f us by the 100 MHz counter, %d shader-clock ticks -> %.2f GHz" % (ns / 1e3, st[7] - st[0], (st[7] - st[0]) / ns))
 print("probes (tile wg): lam load %d cycles, partz load %d cycles, M load %d cycles" % (st[8] - st[0], st[9] - st[8], st[10] - st[9]))
 print("probes (mean wg): lam load %d cycles, partz load %d cycles, M load %d cycles" % (st[24] - st[16], st[25] - st[24], st[26] - st[25]))
+
+# start / end of EVERY workgroup of trajectory 0 in the stamped launch (100 MHz counter): where the launch's time goes
+wg = (ctypes.c_ulonglong * (2 * 8192))()
+if hasattr(g.lib(), "gpmpc_debug_wg_times") and g.lib().gpmpc_debug_wg_times(wg) == 0:
+    a = np.array(list(wg), dtype=np.int64).reshape(2, 8192)
+    used = np.nonzero(a[1] > 0)[0]
+    if len(used):
+        t0 = a[0][used].min()
+        start, end = (a[0][used] - t0) / 100.0, (a[1][used] - t0) / 100.0
+        ds = cfg["ds"]
+        ntile = len(used) - 2 * ds
+        print(f"{len(used)} workgroups of trajectory 0 ({ntile} tiles + {ds} mean-sum + {ds} finish); launch span {end.max():.1f} us")
+        for name, sel in (("tiles", slice(0, ntile)), ("mean sums", slice(ntile, ntile + ds)), ("finish", slice(ntile + ds, ntile + 2 * ds))):
+            st_, en_ = start[sel], end[sel]
+            print(f"  {name:10s} start {st_.min():6.1f} .. {st_.max():6.1f} us   end p50 {np.median(en_):6.1f}  p90 {np.percentile(en_, 90):6.1f}  max {en_.max():6.1f} us   lifetime p50 {np.median(en_ - st_):6.1f} max {(en_ - st_).max():6.1f} us")
