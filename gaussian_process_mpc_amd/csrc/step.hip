@@ -976,7 +976,11 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     // which evaluates the exponent per GP, is still ahead up to ~3000 tile workgroups (profiles/r03/ab_fused_sb_vs_shared.txt:
     // N = 1024, B = 8 / 12 / 16 / 24 / 32 x1.52 / 1.45 / 1.20 / 0.99 / 0.75; N = 2048, B = 2 / 4 / 8 x1.37 / 1.29 / 0.85;
     // N = 512, ds = 3, B = 32 / 64 x1.38 / 1.27; N = 768, B = 24 / 48 x1.33 / 0.88).
-    if (r->sb && r->tiling == 2 && r->tb == 1 && fsb_can && (tn.fused_sb == 1 || wg2 <= (shared_on ? 3000 : 4700)))
+    // (training sets of up to ~200 tiles per trajectory, N <= 1024 at ds = 4, whose tile workgroups have less to re-reduce: ahead or
+    // level up to ~7000 -- N = 1024, B = 32 / 48 1.88 / 2.72 vs 2.17 / 2.91 ms on one box, 1.95 / 2.83 vs 2.02 / 2.77 on another;
+    // N = 768, B = 64 2.14 vs 2.44 ms)
+    const long fsb_max = shared_on ? 3000 : (p->wl[0][2].nwork <= 200 ? 7000 : 4700);
+    if (r->sb && r->tiling == 2 && r->tb == 1 && fsb_can && (tn.fused_sb == 1 || wg2 <= fsb_max))
         r->fused = 2;
     if (r->sb && (r->tiling == 5 || r->tiling == 6) && r->tb == 1 && fsb_can) r->fused = 2;   // narrower tiles: this form only
     if (r->fused) r->tb = 1;
