@@ -934,7 +934,14 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     // 256x128 tiles with two trajectories per wave where they already give the workgroups the 256x256 tiles do not yet
     // (profiles/r03/ab_tiling_256x128.txt: N = 2048, B = 24 / 32 4.02 / 5.07 vs 4.78 / 6.12 ms on 256x64; N = 1024, B = 96 / 128
     // 4.51 / 5.71 vs 4.98 / 6.49 ms; from there on 256x256 is 3-4 % ahead)
-    const bool big128 = !big && sb_ok && tb2 && p->Np > 512 && (long)((B + 1) / 2) * p->wl[0][4].nwork >= thr2;
+    // (re-measured against the plan as it stood at the end of round 3, whose mid-size forms had moved: ahead from ~1600 of its own
+    // workgroups -- N = 2048, B = 12 / 14 / 16 / 18 x1.00 / 1.05 / 1.10 / 1.05; N = 1024, B = 44 / 48 / 56 / 64 x1.01 / 1.05 / 1.07 / 1.11;
+    // N = 1536, ds = 3, B = 24 / 32 x1.07 / 1.14; N = 2048, B = 10 x0.96)
+    // ... but only beyond the reach of the one-launch form, which is ahead of it wherever both apply (N = 1024, B = 40 2.27 vs 2.57 ms;
+    // N = 768, B = 72 2.35 vs 2.58; N = 600, B = 96 2.36 vs 2.64)
+    const long fsb_max = shared_on ? 3000 : (p->wl[0][2].nwork <= 200 ? 7000 : 4700);
+    const bool fsb_take = fsb_can && p->tune.fused_sb != 0 && wg2 <= fsb_max;
+    const bool big128 = !big && !fsb_take && sb_ok && tb2 && p->Np > 512 && (long)((B + 1) / 2) * p->wl[0][4].nwork >= 1600;
     r->sb = (sb_ok && (big || mid)) ? 1 : 0;
     const bool many = (long)p->wl[0][1].nwork > 256L * p->ds;        // > 256 one-wave tiles per GP (N >= 1472)
     r->tiling = big ? 0 : (big128 ? 4 : (mid ? 2 : (many ? 3 : 1)));
@@ -979,7 +986,6 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     // (training sets of up to ~200 tiles per trajectory, N <= 1024 at ds = 4, whose tile workgroups have less to re-reduce: ahead or
     // level up to ~7000 -- N = 1024, B = 32 / 48 1.88 / 2.72 vs 2.17 / 2.91 ms on one box, 1.95 / 2.83 vs 2.02 / 2.77 on another;
     // N = 768, B = 64 2.14 vs 2.44 ms)
-    const long fsb_max = shared_on ? 3000 : (p->wl[0][2].nwork <= 200 ? 7000 : 4700);
     if (r->sb && r->tiling == 2 && r->tb == 1 && fsb_can && (tn.fused_sb == 1 || wg2 <= fsb_max))
         r->fused = 2;
     if (r->sb && (r->tiling == 5 || r->tiling == 6) && r->tb == 1 && fsb_can) r->fused = 2;   // narrower tiles: this form only
