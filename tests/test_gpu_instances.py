@@ -3,9 +3,10 @@
 The rollout picks its kernel by the amount of work (csrc/step.hip::plan_rollout, csrc/moment.hip::plan_mom):
 
     one launch per step, 64-row tiles (step_fused.h)      small batches (the staged pair_kernel.h with GPMPC_FUSED=0 / full S)
-    one launch per step, 256x64 tiles (step_fused.h Q=0)  B * tiles from 1250 / 1700 up to ~4700 workgroups (scalar-broadcast column loop)
+    one launch per step, 256x64 / 32 / 16 tiles           from ~150 (N >= 512; else ~400) to ~4700 (7000: <= 200 tiles per trajectory)
+      (step_fused.h Q = 0 / 32 / 16)                      tile workgroups: scalar-broadcast column loop inside the fused step kernel
     scalar broadcast, 256x64 tiles   (pair_kernel_sb.h)   beyond, one trajectory per wave
-    scalar broadcast, 256x128 tiles  (pair_kernel_sb.h)   >= 2800 workgroups of two trajectories per wave, N > 512
+    scalar broadcast, 256x128 tiles  (pair_kernel_sb.h)   >= 1600 workgroups of two trajectories per wave, N > 512
     scalar broadcast, 256x256 tiles  (pair_kernel_sb.h)   >= 2800 workgroups of two trajectories per wave (D <= 5), >= 1500 of one
     scalar broadcast, full S         (pair_kernel_sbf.h)  full-covariance rollout / moment matching on large batches
 
