@@ -4,7 +4,7 @@
 #ifndef GPMPC_PAIR_D
 #error "compile with -DGPMPC_PAIR_D=<D>"
 #endif
-template int gpmpc_launch_step_fused_D<GPMPC_PAIR_D>(bool, int, int, const FusedArgs&, int, hipStream_t);
+template int gpmpc_launch_step_fused_D<GPMPC_PAIR_D>(bool, int, int, int, const FusedArgs&, int, hipStream_t);
 
 #if defined(GPMPC_FUSED_STAMPS) && GPMPC_PAIR_D == 4
 // diagnostic build: the stamps of the D = 4 instances of this translation unit

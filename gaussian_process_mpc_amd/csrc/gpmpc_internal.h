@@ -170,9 +170,11 @@ struct FusedArgs {
     double* means; double* vars; double* jac;
     double* sp; double* part; double* partz;
     int sps, nm;
-    double* gscr;                          // mid-size form (q = 0): [B][nwork][64][gw] column rows, one slot per tile workgroup
+    double* gscr;                          // mid-size form (q = 0 / 32 / 16): [B][ntile][columns][gw] column rows, one slot per tile workgroup
+    int ntile;                             // tile workgroups per trajectory (= nwork, except with one lambda for all GPs: groups x tiles)
+    int tiles;                             // one lambda for all GPs: tiles per GP (partial sums are laid out [GP][tile], nwork = ds * tiles)
 };
-template <int D> int gpmpc_launch_step_fused_D(bool grad, int ns2, int q, const FusedArgs& a, int t, hipStream_t s);
+template <int D> int gpmpc_launch_step_fused_D(bool grad, int ns2, int q, int ng, const FusedArgs& a, int t, hipStream_t s);
 
 
 // Implemented in pair_d*.hip (one translation unit per D so the build parallelises).

@@ -939,7 +939,7 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     // N = 1536, ds = 3, B = 24 / 32 x1.07 / 1.14; N = 2048, B = 10 x0.96)
     // ... but only beyond the reach of the one-launch form, which is ahead of it wherever both apply (N = 1024, B = 40 2.27 vs 2.57 ms;
     // N = 768, B = 72 2.35 vs 2.58; N = 600, B = 96 2.36 vs 2.64)
-    const long fsb_max = shared_on ? 3000 : (p->wl[0][2].nwork <= 200 ? 7000 : 4700);
+    const long fsb_max = shared_on ? 7000 : (p->wl[0][2].nwork <= 200 ? 7000 : 4700);
     const bool fsb_take = fsb_can && p->tune.fused_sb != 0 && wg2 <= fsb_max;
     const bool big128 = !big && !fsb_take && sb_ok && tb2 && p->Np > 512 && (long)((B + 1) / 2) * p->wl[0][4].nwork >= 1600;
     r->sb = (sb_ok && (big || mid)) ? 1 : 0;
@@ -979,10 +979,10 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     // N = 2048, B = 4 / 6 / 8 / 12 x1.17 / 1.10 / 1.06 / 0.97; N = 768, B = 24 / 48 x1.36 / 1.13: up to ~4700 tile workgroups per
     // launch (beyond, the longer prologue of every tile workgroup costs more than the head kernel it replaces).
     // (N > ~2100 -- more than 320 tiles per GP -- stays on head + pair kernel: N = 4096, B = 1 4.35 vs 3.73 ms)
-    // With ONE lambda for all GPs the shared-lambda pair kernel (two launches per step) is the alternative: the one-launch form,
-    // which evaluates the exponent per GP, is still ahead up to ~3000 tile workgroups (profiles/r03/ab_fused_sb_vs_shared.txt:
-    // N = 1024, B = 8 / 12 / 16 / 24 / 32 x1.52 / 1.45 / 1.20 / 0.99 / 0.75; N = 2048, B = 2 / 4 / 8 x1.37 / 1.29 / 0.85;
-    // N = 512, ds = 3, B = 32 / 64 x1.38 / 1.27; N = 768, B = 24 / 48 x1.33 / 0.88).
+    // With ONE lambda for all GPs the shared-lambda pair kernel (two launches per step) is the alternative: the one-launch form
+    // evaluating the exponent per GP is ahead of it up to ~3000 tile workgroups (profiles/r03/ab_fused_sb_vs_shared.txt:
+    // N = 1024, B = 8 / 12 / 16 / 24 / 32 x1.52 / 1.45 / 1.20 / 0.99 / 0.75; N = 2048, B = 2 / 4 / 8 x1.37 / 1.29 / 0.85), and with
+    // groups of GPs per tile workgroup (r->shared below) up to ~7000.
     // (training sets of up to ~200 tiles per trajectory, N <= 1024 at ds = 4, whose tile workgroups have less to re-reduce: ahead or
     // level up to ~7000 -- N = 1024, B = 32 / 48 1.88 / 2.72 vs 2.17 / 2.91 ms on one box, 1.95 / 2.83 vs 2.02 / 2.77 on another;
     // N = 768, B = 64 2.14 vs 2.44 ms)
@@ -997,6 +997,17 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     // Shared length-scales: one exponent / exp per pair for a group of GPs (pair_kernel_sbs.h) wherever the scalar-broadcast
     // kernel would run.  256x256 tiles once they give ~1700 workgroups (one trajectory per workgroup), else 256x64.
     r->shared = 0; r->sh_list = 0;
+    if (r->sb && r->fused == 2 && r->tiling == 2 && shared_on && (wg2 >= 2200 || tn.fused_sb == 1)) {
+        // one lambda for all GPs AND the one-launch form: its tile workgroups take groups of sh_ng GPs (step_fused.h, NG > 1) on the
+        // shared 256x64 list.  Three forms compete for such a pack (profiles/r03/ab_fused_shared.txt, ms per batch: groups of GPs in one
+        // launch | one GP per tile workgroup in one launch | shared-lambda pair kernel, two launches): N = 1024, B = 8 0.81 | 0.67 | -,
+        // B = 16 0.89 | 0.99 | -, B = 24 1.17 | 1.42 | 1.64, B = 32 1.45 | 1.84 | 1.67, B = 48 1.94 | - | 1.91; N = 2048, B = 2
+        // 0.82 | 0.67, B = 4 0.94 | 1.03, B = 8 1.37 | 1.88 | 1.69, B = 12 2.06 | - | 2.05; N = 512, ds = 3, B = 32 0.64 | 0.56, B = 128
+        // 1.10 | 1.48 | 1.41: per-GP workgroups (4x as many, narrower tiles) below ~2200 workgroups of 64 columns, groups up to ~7000
+        r->shared = 1; r->sh_list = 1;
+        r->tb = 1; r->waves = 4;
+        r->nwork = p->ds * p->sh_tiles[1];
+    } else
     if (r->sb && r->fused != 2 && !lowprec && p->shared_lambda && tn.shared != 0 && p->sh_ng >= 2) {
         r->shared = 1;
         // (round 3: a 256x128 list, wl_sh[2], is built for the A/B only -- GPMPC_TILING=4 --: with one trajectory per workgroup it has
@@ -1043,7 +1054,7 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     r->off_jac = take(grad ? (size_t)B * H * 2 * p->ds * (2 * p->ds + p->da) : 0);
     r->gw = gpmpc_sb_gw(D, p->ds);
     // column rows: [B][GP][Np][gw] written by the head kernel, or one [64][gw] slot per tile workgroup of the mid-size fused form
-    r->off_G = take(r->fused == 2 ? (size_t)B * r->nwork * p->wl[0][r->tiling].jt * r->gw
+    r->off_G = take(r->fused == 2 ? (size_t)B * (r->shared ? p->wl_sh[1].nwork : r->nwork) * p->wl[0][r->tiling].jt * r->gw
                                   : (r->sb ? (size_t)B * (r->shared ? 1 : p->ds) * p->Np * r->gw : 0));
     r->off_means = take((size_t)B * (H + 1) * p->ds);
     r->off_vars = take((size_t)B * (H + 1) * p->ds);
@@ -1112,16 +1123,16 @@ extern "C" size_t gpmpc_rollout_workspace_bytes(const gpmpc_pack* p, int B, int 
     return need;
 }
 
-static int launch_step_fused(int D, bool grad, int ns2, int q, const FusedArgs& a, int t, hipStream_t s) {
+static int launch_step_fused(int D, bool grad, int ns2, int q, int ng, const FusedArgs& a, int t, hipStream_t s) {
     switch (D) {
-        case 1: return gpmpc_launch_step_fused_D<1>(grad, ns2, q, a, t, s);
-        case 2: return gpmpc_launch_step_fused_D<2>(grad, ns2, q, a, t, s);
-        case 3: return gpmpc_launch_step_fused_D<3>(grad, ns2, q, a, t, s);
-        case 4: return gpmpc_launch_step_fused_D<4>(grad, ns2, q, a, t, s);
-        case 5: return gpmpc_launch_step_fused_D<5>(grad, ns2, q, a, t, s);
-        case 6: return gpmpc_launch_step_fused_D<6>(grad, ns2, q, a, t, s);
-        case 7: return gpmpc_launch_step_fused_D<7>(grad, ns2, q, a, t, s);
-        case 8: return gpmpc_launch_step_fused_D<8>(grad, ns2, q, a, t, s);
+        case 1: return gpmpc_launch_step_fused_D<1>(grad, ns2, q, ng, a, t, s);
+        case 2: return gpmpc_launch_step_fused_D<2>(grad, ns2, q, ng, a, t, s);
+        case 3: return gpmpc_launch_step_fused_D<3>(grad, ns2, q, ng, a, t, s);
+        case 4: return gpmpc_launch_step_fused_D<4>(grad, ns2, q, ng, a, t, s);
+        case 5: return gpmpc_launch_step_fused_D<5>(grad, ns2, q, ng, a, t, s);
+        case 6: return gpmpc_launch_step_fused_D<6>(grad, ns2, q, ng, a, t, s);
+        case 7: return gpmpc_launch_step_fused_D<7>(grad, ns2, q, ng, a, t, s);
+        case 8: return gpmpc_launch_step_fused_D<8>(grad, ns2, q, ng, a, t, s);
     }
     return GPMPC_E_ARG;
 }
@@ -1178,11 +1189,13 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
         FusedArgs F;
         memset(&F, 0, sizeof(F));
         const gpmpc_worklist& wl = p->wl[0][r.tiling];
-        F.XT = p->XT; F.beta = p->beta; F.lam = p->lam; F.sf = p->sf; F.M = p->M; F.work = wl.work_dev;
-        const int nwg = r.nwork * r.fq;                     // tile workgroups per trajectory
+        const bool fsh = r.fused == 2 && r.shared;          // groups of GPs with one lambda per tile workgroup
+        F.XT = p->XT; F.beta = p->beta; F.lam = p->lam; F.sf = p->sf; F.M = p->M; F.work = fsh ? p->wl_sh[1].work_dev : wl.work_dev;
+        const int nwg = r.nwork * r.fq;                     // partial sums per trajectory (= tile workgroups, except fsh: ds x tiles)
         F.N = p->N; F.Np = p->Np; F.nwork = nwg;
+        F.ntile = fsh ? p->wl_sh[1].nwork : nwg; F.tiles = fsh ? p->sh_tiles[1] : 0;
         F.tri64 = (r.tiling == 1) ? 1 : 0;                  // 64x64 list: items decoded arithmetically (no dependent load)
-        for (int a = 0; a <= p->ds; ++a) { F.ustart[a] = wl.ustart_host[a] * r.fq; A.ust[a] = F.ustart[a]; }
+        for (int a = 0; a <= p->ds; ++a) { F.ustart[a] = fsh ? a * p->sh_tiles[1] : wl.ustart_host[a] * r.fq; A.ust[a] = F.ustart[a]; }
         A.ust_inline = 1; A.nwork = nwg;
         F.x0 = x0; F.U = U; F.B = B; F.H = H;
         F.means = A.means; F.vars = A.vars; F.jac = A.jac;
@@ -1190,7 +1203,7 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
         F.sps = r.sps; F.nm = r.nm;
         F.gscr = r.fused == 2 ? (double*)(ws + r.off_G) : nullptr;
         for (int t = 1; t <= H; ++t) {
-            const int rc = timed_launch(GPMPC_TIME_FUSED, s, [&] { return launch_step_fused(p->D, grad, p->ds, r.fused == 2 ? (r.tiling == 2 ? 0 : wl.jt) : r.fq, F, t, s); });
+            const int rc = timed_launch(GPMPC_TIME_FUSED, s, [&] { return launch_step_fused(p->D, grad, p->ds, r.fused == 2 ? (r.tiling == 2 ? 0 : wl.jt) : r.fq, fsh ? p->sh_ng : 1, F, t, s); });
             if (rc != GPMPC_OK) return rc;
         }
         A.part += (size_t)(H & 1) * B * nwg * r.nm;          // the tail finishes step H from the parity the last launch wrote

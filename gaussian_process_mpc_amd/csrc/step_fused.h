@@ -85,9 +85,15 @@ static __device__ unsigned long long g_fused_wg[2 * 8192];         // [start | e
 #ifndef GPMPC_FUSED_SB_WAVES
 #define GPMPC_FUSED_SB_WAVES 5      /* waves per SIMD the mid-size form is compiled for (A/B knob) */
 #endif
-template <int D, int NS2, bool GRAD, int Q>
-__global__ __launch_bounds__(256, (Q == 0 || Q == 32 || Q == 16) ? GPMPC_FUSED_SB_WAVES : 1) void k_step_fused(FusedArgs A, int t) {
+// NG > 1 (Q = 0 only): every GP has the SAME length-scales (pair_kernel_sbs.h): a tile workgroup takes a group of NG GPs, evaluates the
+// exponent and the exp ONCE per pair and applies them to NG weight loads; work list wl_sh[1] (items {group, i0, j0, tile}),
+// partial sums laid out [GP][tile], one row of column data per trajectory instead of one per GP.
+template <int D, int NS2, bool GRAD, int Q, int NG = 1>
+__global__ __launch_bounds__(256, (Q == 0 || Q == 32 || Q == 16) ? (NG >= 3 ? 3 : (NG == 2 ? 4 : GPMPC_FUSED_SB_WAVES)) : 1)
+void k_step_fused(FusedArgs A, int t) {
     constexpr bool SB = Q == 0 || Q == 32 || Q == 16;
+    constexpr bool SH = NG > 1;
+    static_assert(!SH || Q == 0, "the shared-lambda tile role runs on 256x64 tiles");
     constexpr int NC = Q == 0 ? 64 : Q;                                            // columns of a tile of the mid-size form
     constexpr int QQ = SB ? 1 : Q;
     constexpr int DS = NS2, DA = D - NS2, NM = GRAD ? 1 + 2 * D : 1, DP = (D + 1) & ~1;
@@ -97,7 +103,7 @@ __global__ __launch_bounds__(256, (Q == 0 || Q == 32 || Q == 16) ? GPMPC_FUSED_S
     constexpr int GW = (D + 1 + NS2 + 1) & ~1;                                     // doubles per G row, as PairSbTraits
     __shared__ double s_tab[TABLE ? GPMPC_EXP_N : 1];
     __shared__ __attribute__((aligned(16))) double s_hj[SB ? 2 : NCOL * DP];
-    __shared__ double s_red[16 * NV];
+    __shared__ double s_red[16 * NV * NG];
     __shared__ double s_out[NV];
     __shared__ double s_zw[GPMPC_MAX_DS];
     __shared__ double s_mu[GPMPC_MAX_DS], s_var[GPMPC_MAX_DS], s_z0[GPMPC_MAX_DS], s_c[GPMPC_MAX_DS];
@@ -105,9 +111,9 @@ __global__ __launch_bounds__(256, (Q == 0 || Q == 32 || Q == 16) ? GPMPC_FUSED_S
     __shared__ double s_uin[D], s_sin[D], s_sck[D], s_cv[D];     // input moments of step t and the pair transform h = sc (u - x)
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int role = (int)blockIdx.x < A.nwork ? 0 : ((int)blockIdx.x < A.nwork + DS ? 1 : 2);     // tile | mean sums | finish
+    const int role = (int)blockIdx.x < A.ntile ? 0 : ((int)blockIdx.x < A.ntile + DS ? 1 : 2);     // tile | mean sums | finish
     const int Np = A.Np, pprev = (t - 1) & 1, pcur = t & 1;
-    const int am = role == 1 ? (int)blockIdx.x - A.nwork : (int)blockIdx.x - A.nwork - DS;         // GP of a non-tile workgroup
+    const int am = role == 1 ? (int)blockIdx.x - A.ntile : (int)blockIdx.x - A.ntile - DS;         // GP of a non-tile workgroup
 
     // All kernel arguments used below are read HERE, unconditionally (the empty asm is an unconditional use): left to
     // itself the compiler loads each field inside the branch that first needs it, one s_load + s_waitcnt after the other
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(256, (Q == 0 || Q == 32 || Q == 16) ? GPMPC_FUSED_S
             unit = wk[0]; i0 = wk[1]; j0 = wk[2]; j1 = wk[3];
         }
     }
-    const int a_own = role == 0 ? unit : am;                        // the GP whose length-scales this workgroup needs
+    const int a_own = role == 0 ? (SH ? (unit * NG < DS ? unit * NG : DS - 1) : unit) : am;      // the GP whose length-scales this workgroup needs
     // Load-instruction diet: a CU's vector memory path moves 64 B per clock, so every wave-wide load costs ~8 cycles of it
     // whatever it fetches; with 120 of them per workgroup (4 waves x 30) the opening burst took 3.7 k cycles (in-kernel
     // stamps), against ~500 for one load alone.  Per-dimension scalars are therefore loaded by wave 0 only, and the Z0
@@ -302,7 +308,7 @@ __global__ __launch_bounds__(256, (Q == 0 || Q == 32 || Q == 16) ? GPMPC_FUSED_S
         double sck[D], cv[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) { sck[k] = s_sck[k]; cv[k] = s_cv[k]; }
-        double* __restrict__ Gs = A.gscr + ((size_t)b * A.nwork + blockIdx.x) * (size_t)(NC * GW);
+        double* __restrict__ Gs = A.gscr + ((size_t)b * A.ntile + blockIdx.x) * (size_t)(NC * GW);
         if (w == 0) {                                                    // column rows of this tile, one column per lane (< NC)
             double g[GW], qh = 0.0;
 #pragma unroll
@@ -337,6 +343,94 @@ __global__ __launch_bounds__(256, (Q == 0 || Q == 32 || Q == 16) ? GPMPC_FUSED_S
             qi = GPMPC_EXP_NEG_INV_C * q;
         }
         constexpr int NA = GRAD ? 1 + D + NS2 : 1;
+        if constexpr (SH) {
+            // ---- group of NG GPs with one lambda: exponent and exp once per pair (pair_kernel_sbs.h: same expressions, same order) ----
+            const int tile = j1;                                         // 4th entry of a shared-list item: the tile's index within its GP
+            double accs[NG][NA];
+#pragma unroll
+            for (int q = 0; q < NG; ++q)
+#pragma unroll
+                for (int m = 0; m < NA; ++m) accs[q][m] = 0.0;
+            __syncthreads();                                             // G rows and exp table ready
+            if (iw0 < Np && j0 >= iw0) {
+                const double* Gl = Gs;
+                asm volatile("" : "+s"(Gl) :: "memory");
+                __amdgpu_buffer_rsrc_t Mrs[NG];
+#pragma unroll
+                for (int q = 0; q < NG; ++q) {
+                    const int a = unit * NG + q < DS ? unit * NG + q : DS - 1;       // a partial last group re-reads the last GP
+                    Mrs[q] = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(A.M + ((size_t)a * Np + j0) * Np + iw0), 0, 0x7fffffff, 0x00020000);
+                }
+                const int lane8 = lane * 8;
+                constexpr int CU = NG >= 3 ? 1 : 2;
+                for (int jc = 0; jc < NC; jc += CU) {
+                    double mij[CU][NG];
+#pragma unroll
+                    for (int c = 0; c < CU; ++c)
+#pragma unroll
+                        for (int q = 0; q < NG; ++q)
+                            mij[c][q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs[q], lane8, (jc + c) * Np * 8, 0));
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int c = 0; c < CU; ++c) {
+                        typedef const double __attribute__((address_space(4))) gpmpc_cdouble;
+                        const gpmpc_cdouble* __restrict__ g = (const gpmpc_cdouble*)(Gl + (size_t)(jc + c) * GW);
+                        double sx = qi + g[D];
+#pragma unroll
+                        for (int k = 0; k < D; ++k) sx = fma(hi2[k], g[k], sx);
+                        const double e = gpmpc_exp_neg_scaled(sx, s_tab);
+#pragma unroll
+                        for (int q = 0; q < NG; ++q) {
+                            const double P = mij[c][q] * e;
+                            accs[q][0] += P;
+                            if (GRAD) {
+#pragma unroll
+                                for (int k = 0; k < D; ++k) accs[q][GRAD ? 1 + k : 0] = fma(P, g[k], accs[q][GRAD ? 1 + k : 0]);
+#pragma unroll
+                                for (int k = 0; k < NS2; ++k) accs[q][GRAD ? 1 + D + k : 0] = fma(P, g[D + 1 + k], accs[q][GRAD ? 1 + D + k : 0]);
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NG; ++q) {
+                double z[NM];
+#pragma unroll
+                for (int m = 0; m < NM; ++m) z[m] = 0.0;
+                const double rs = accs[q][0];
+                z[0] = rs;
+                if (GRAD) {
+#pragma unroll
+                    for (int k = 0; k < D; ++k) {
+                        const double h = (0.5 / GPMPC_EXP_NEG_INV_C) * hi2[k], v = accs[q][GRAD ? 1 + k : 0];
+                        z[GRAD ? 1 + k : 0] = fma(h, rs, v);
+                        if (k < NS2) z[GRAD ? 1 + D + k : 0] = fma(h * h, rs, fma(2.0 * h, v, accs[q][GRAD ? 1 + D + (k < NS2 ? k : 0) : 0]));
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    const double sr = wave_row_sum(z[m]);
+                    if ((lane & 15) == 0) s_red[((w * 4 + (lane >> 4)) * NG + q) * NM + m] = sr;
+                }
+            }
+            __syncthreads();
+            for (int idx = tid; idx < NG * NM; idx += NT) {
+                const int q = idx / NM, m = idx - q * NM;
+                const int a = unit * NG + q;
+                if (a < DS) {
+                    double sum = 0.0;                                    // fixed order: waves, each as (row 0 + row 1) + (row 2 + row 3)
+                    for (int ww = 0; ww < 4; ++ww) {
+                        const double* r4 = &s_red[(ww * 4 * NG + q) * NM + m];
+                        sum += (r4[0] + r4[NG * NM]) + (r4[2 * NG * NM] + r4[3 * NG * NM]);
+                    }
+                    const size_t o = ((size_t)pcur * A.B + b) * A.nwork + (size_t)a * A.tiles + tile;
+                    A.part[o * A.nm + m] = sum;
+                    if (m == 0) A.partz[o] = sum;
+                }
+            }
+            return;
+        }
         double acc[NA];
 #pragma unroll
         for (int m = 0; m < NA; ++m) acc[m] = 0.0;
@@ -598,10 +692,11 @@ __global__ __launch_bounds__(256, (Q == 0 || Q == 32 || Q == 16) ? GPMPC_FUSED_S
     GPMPC_STAMP_WG(1);
 }
 
-template <int D, int NS2, bool GRAD, int Q>
+template <int D, int NS2, bool GRAD, int Q, int NG = 1>
 static int launch_step_fused_one(const FusedArgs& a, int t, hipStream_t s) {
     if ((Q == 0 || Q == 32 || Q == 16) && !a.gscr) return GPMPC_E_ARG;
-    hipLaunchKernelGGL((k_step_fused<D, NS2, GRAD, Q>), dim3(a.nwork + 2 * NS2, a.B), dim3(256), 0, s, a, t);
+    if (a.ntile < 1 || (NG > 1 && a.tiles < 1)) return GPMPC_E_ARG;
+    hipLaunchKernelGGL((k_step_fused<D, NS2, GRAD, Q, NG>), dim3(a.ntile + 2 * NS2, a.B), dim3(256), 0, s, a, t);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { gpmpc_set_error("fused step kernel launch", e); return GPMPC_E_LAUNCH; }
     return GPMPC_OK;
@@ -610,8 +705,23 @@ static int launch_step_fused_one(const FusedArgs& a, int t, hipStream_t s) {
 // ns2 = state_dim: D - ns2 in {0, 1, 2} action dimensions; q = 1 (whole tiles), 4 (a quarter of a tile's columns per workgroup)
 // or 0 / 32 / 16 (256 x 64 / 32 / 16 tiles, scalar-broadcast column loop: the mid-size form)
 template <int D>
-int gpmpc_launch_step_fused_D(bool grad, int ns2, int q, const FusedArgs& a, int t, hipStream_t s) {
+int gpmpc_launch_step_fused_D(bool grad, int ns2, int q, int ng, const FusedArgs& a, int t, hipStream_t s) {
     if (a.nm != (grad ? 1 + 2 * D : 1) || (q != 0 && q != 1 && q != 4 && q != 16 && q != 32)) return GPMPC_E_ARG;
+    if (ng > 1) {                                       // one lambda for all GPs: groups of ng GPs per tile workgroup (q = 0 only)
+        if (q != 0) return GPMPC_E_ARG;
+#define GPMPC_FUSED_SH(NGV, NSV)                                                                                   \
+        if constexpr (NGV <= NSV) if (ng == NGV && ns2 == NSV)                                                     \
+            return grad ? launch_step_fused_one<D, NSV, true, 0, NGV>(a, t, s) : launch_step_fused_one<D, NSV, false, 0, NGV>(a, t, s);
+#define GPMPC_FUSED_SH_NG(NGV)                                                                                     \
+        if constexpr (D >= 2) { GPMPC_FUSED_SH(NGV, (D >= 2 ? D - 1 : 1)) }                                        \
+        if constexpr (D >= 3) { GPMPC_FUSED_SH(NGV, (D >= 3 ? D - 2 : 1)) }
+        GPMPC_FUSED_SH_NG(2)
+        GPMPC_FUSED_SH_NG(3)
+        GPMPC_FUSED_SH_NG(4)
+#undef GPMPC_FUSED_SH_NG
+#undef GPMPC_FUSED_SH
+        return GPMPC_E_ARG;
+    }
 #define GPMPC_FUSED_CASE(GR, QV)                                                                                   \
     if (grad == GR && q == QV) {                                                                                   \
         if (ns2 == D) return launch_step_fused_one<D, D, GR, QV>(a, t, s);                                         \

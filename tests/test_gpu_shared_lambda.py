@@ -73,6 +73,19 @@ def test_every_shape_vs_cport_and_vs_distinct_kernels(G, ds, da, monkeypatch):
         for k in r:
             assert torch.equal(r[k], again[k]), k                                    # fixed-order reductions
         res[B] = r
+    # the one-launch-per-step form with a group of GPs per tile workgroup (step_fused.h, NG > 1: the plan from ~2200 to ~7000 tile
+    # workgroups of a training set of at least one 256-row tile), forced onto the mid-size batch: against the C port and against the
+    # two-launch shared-lambda kernel above (same tiles, same order inside a tile)
+    monkeypatch.setenv("GPMPC_FUSED_SB", "1")
+    pack.reload_tuning()
+    o = G.rollout(pack, pb["x0"][:b_mid], pb["U"][:b_mid], cost)
+    _check_vs_cport(o, pb, kinv, sorted({0, 1, b_mid // 2, b_mid - 1}), f"one-launch form ds={ds} da={da}")
+    np.testing.assert_allclose(res[b_mid]["vars"].cpu().numpy(), o["vars"].cpu().numpy(), rtol=1e-6, atol=1e-14)
+    np.testing.assert_allclose(res[b_mid]["grad"].cpu().numpy(), o["grad"].cpu().numpy(), rtol=1e-5, atol=1e-9)
+    of = G.rollout(pack, pb["x0"][:b_mid], pb["U"][:b_mid], cost, want_grad=False)
+    np.testing.assert_allclose(of["cost"].cpu().numpy(), o["cost"].cpu().numpy(), rtol=1e-9)
+    monkeypatch.delenv("GPMPC_FUSED_SB")
+    pack.reload_tuning()
     # the distinct-lambda kernels on the same pack: the same sums, the exponent rounded the same way -> agreement far inside
     # the tolerance (the tilings and the summation order of the partial sums are the same)
     monkeypatch.setenv("GPMPC_SHARED", "0")

@@ -30,7 +30,7 @@ SHAPES = {"auto": {}, "sb256": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "0"}, "sb6
           # 256x128 tiles, two trajectories per wave (work list 4), alone and as two concurrent sub-batches
           # one launch per step on 256x64 tiles (step_fused.h, Q = 0) forced on wherever the scalar-broadcast path can run, and off
           "fsb": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "2", "GPMPC_FUSED_SB": "1"}, "fsb_split2": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "2", "GPMPC_FUSED_SB": "1", "GPMPC_SPLIT": "2"},
-          "fsb_off": {"GPMPC_FUSED_SB": "0"},
+          "fsb_off": {"GPMPC_FUSED_SB": "0"}, "fsb_ng2": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "2", "GPMPC_FUSED_SB": "1", "GPMPC_SHARED_NG": "2"},
           "fsb32": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "5", "GPMPC_FUSED_SB": "1"}, "fsb16": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "6", "GPMPC_FUSED_SB": "1"},
           "sb128": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "4"}, "sb128_split2": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "4", "GPMPC_SPLIT": "2"}}
 worst = {"means": 0.0, "vars": 0.0, "cost": 0.0, "grad": 0.0}
