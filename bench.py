@@ -41,6 +41,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="C3")
     ap.add_argument("--batch", type=int, default=0, help="trajectories per GPU (default: the config's B)")
+    ap.add_argument("--n-train", type=int, default=0,
+                    help="training-set size instead of the config's N (side measurements, e.g. the mid-size case N = 1024, B = 16; "
+                         "the line then names the changed N and carries no PMC sidecar)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=5, help="timed repetitions of the CPU baseline legs (min is reported)")
     ap.add_argument("--forward-only", action="store_true")
@@ -345,6 +348,8 @@ def run_rank(args):
     from gaussian_process_mpc_amd.parallel import shard_range, gather_results
 
     cfg = dict(CONFIGS[args.config])
+    if args.n_train:
+        cfg["N"] = args.n_train
     B = args.batch or cfg["B"]
     if args.config == "C4" and not args.batch:
         B = cfg["B"] // 8                                  # 1024 trajectories over 8 GPUs
@@ -440,7 +445,7 @@ def run_rank(args):
         achieved = pairs_per_launch * fl / launch_s / 1e12
         m_bytes = 8 * (ds * N * (N + 1) / 2 + (ds * (ds - 1) / 2 * N * N if fullcov else 0))     # M read once per launch
         sm = "sbf" if fullcov else ("sbs" if shared else "sb")
-        traffic, traffic_src = measured_traffic(args.config, B, want_grad, sm)
+        traffic, traffic_src = (None, None) if args.n_train else measured_traffic(args.config, B, want_grad, sm)
         ng = 0
         if shared:                                             # GPs per workgroup: gpmpc_sbs_group (gpmpc_internal.h)
             cap = max(2, min(4, 48 // (1 + D + ds)))
@@ -457,7 +462,7 @@ def run_rank(args):
             "value": value, "unit": "rollouts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.config}: N={N}, d(state_dim)={ds}, action_dim={da}, H={H}, "
+            "config": {"workload": f"{args.config}{' with N changed' if args.n_train else ''}: N={N}, d(state_dim)={ds}, action_dim={da}, H={H}, "
                                    f"B={B} trajectories per GPU, gamma={cfg['gamma']}, "
                                    + ("full covariance, " if fullcov else "")
                                    + ("one lambda for all GPs (shared-lambda kernel), " if args.shared_lambda else "")

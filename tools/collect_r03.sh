@@ -24,6 +24,11 @@ for c in C1 C2; do
 done
 python bench.py --config C3 --steps 5 --warmup 2 --no-cpu-baseline --forward-only > $O/bench_C3_fwd.json 2>/dev/null
 for b in 1 4 16 32; do python bench.py --config C3 --batch $b --steps 20 --warmup 5 --no-cpu-baseline --graph > $O/bench_C3_B$b.json 2>/dev/null; done
+# the mid-size case the round-2 review set a target for (N = 1024, B = 16), and its neighbours, with and without one lambda for all GPs
+for b in 8 16 32; do
+  python bench.py --config C3 --n-train 1024 --batch $b --steps 50 --warmup 10 --no-cpu-baseline --no-extras --graph > $O/bench_N1024_B$b.json 2>/dev/null
+  python bench.py --config C3 --n-train 1024 --batch $b --steps 50 --warmup 10 --no-cpu-baseline --no-extras --graph --shared-lambda > $O/bench_N1024_B${b}_shared.json 2>/dev/null
+done
 python bench.py --gpus 2 --oversubscribe --backend gloo --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_2rank_gloo_one_card.json 2>/dev/null
 python bench.py --gpus 6 --config C4 --batch 2 --oversubscribe --backend gloo --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_C4_6rank_gloo_one_card.json 2>$O/bench_C4_6rank.err
 for v in "" "--cl-distinct" "--cl-rebuild"; do python bench.py --closed-loop $v > "$O/closed_loop$(echo $v | tr -d ' ').json" 2>/dev/null; done
