@@ -78,7 +78,8 @@ struct gpmpc_pack {
     // shared-lambda path (pair_kernel_sbs.h): every GP has bit-identical length-scales (detected at gpmpc_pack_build)
     int shared_lambda;
     int sh_ng;                 // GPs per workgroup
-    gpmpc_worklist wl_sh[3];   // items {group, i0, j0, tile}: [0: 256x256 tiles, XCD-sorted | 1: 256x64 | 2: 256x128, XCD-sorted]; .nunits = groups
+    gpmpc_worklist wl_sh[4];   // items {group, i0, j0, tile}: [0: 256x256 tiles, XCD-sorted | 1: 256x64 | 2: 256x128, XCD-sorted]; .nunits = groups
+                               // [3: 256x64 in groups of TWO GPs (the one-launch form of smaller mid-size batches; built when sh_ng > 2 and ds is even)]
     int sh_tiles[3];           // tiles per GP
 };
 

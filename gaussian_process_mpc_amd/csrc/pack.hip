@@ -267,6 +267,10 @@ extern "C" int gpmpc_pack_create(gpmpc_pack** out, int n_train, int state_dim, i
         ok = build_worklist(p->Np, 256, cfg[0][1], groups, 0, !p->tune.no_xcd_sort, &p->wl_sh[0], true, &p->sh_tiles[0]) == 0 &&
              build_worklist(p->Np, 256, 64, groups, 0, false, &p->wl_sh[1], true, &p->sh_tiles[1]) == 0 &&
              build_worklist(p->Np, 256, 128, groups, 0, !p->tune.no_xcd_sort, &p->wl_sh[2], true, &p->sh_tiles[2]) == 0;
+        if (ok && p->sh_ng > 2 && state_dim % 2 == 0) {
+            int tiles2 = 0;
+            ok = build_worklist(p->Np, 256, 64, state_dim / 2, 0, false, &p->wl_sh[3], true, &tiles2) == 0;
+        }
     }
     if (!ok) { gpmpc_set_error("gpmpc_pack_create", e); gpmpc_pack_destroy(p); return GPMPC_E_ALLOC; }
     *out = p;
@@ -303,7 +307,7 @@ extern "C" int gpmpc_pack_destroy(gpmpc_pack* p) {
             if (p->wl[mode][k].perm_dev) (void)hipFree(p->wl[mode][k].perm_dev);
             if (p->wl[mode][k].ustart_dev) (void)hipFree(p->wl[mode][k].ustart_dev);
         }
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < 4; ++k) {
         if (p->wl_sh[k].work_dev) (void)hipFree(p->wl_sh[k].work_dev);
         if (p->wl_sh[k].perm_dev) (void)hipFree(p->wl_sh[k].perm_dev);
         if (p->wl_sh[k].ustart_dev) (void)hipFree(p->wl_sh[k].ustart_dev);

@@ -874,7 +874,7 @@ int gpmpc_timed_pair_sbf(int D, bool grad, int ns2, int waves, const PairSbfArgs
     return timed_launch(GPMPC_TIME_FULL, s, [&] { return gpmpc_launch_pair_sbf(D, grad, ns2, waves, a, s); });
 }
 
-struct RollPlan { int tiling, tb, waves, nwork, nm, pps, sps, sb, gw, rgroup, fused, fq, hchunks, hrows, shared, sh_list, colunroll /* columns per iteration of the sb kernel */; size_t off_mpart; size_t off_G; size_t off_pp, off_sp, off_part, off_partz, off_jac, off_means, off_vars, total; };
+struct RollPlan { int tiling, tb, waves, nwork, nm, pps, sps, sb, gw, rgroup, fused, fq, hchunks, hrows, shared, sh_list, colunroll /* columns per iteration of the sb kernel */, fng /* GPs per tile workgroup of the one-launch form with one lambda */; size_t off_mpart; size_t off_G; size_t off_pp, off_sp, off_part, off_partz, off_jac, off_means, off_vars, total; };
 
 // shape (optional): take every SHAPE decision (tiling, kernel, trajectories per wave, row chunks ...) from this plan of a larger
 // batch and only size the buffers for B: the sub-batches of a split call then run exactly the launches the whole batch would,
@@ -997,7 +997,13 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     // Shared length-scales: one exponent / exp per pair for a group of GPs (pair_kernel_sbs.h) wherever the scalar-broadcast
     // kernel would run.  256x256 tiles once they give ~1700 workgroups (one trajectory per workgroup), else 256x64.
     r->shared = 0; r->sh_list = 0;
-    if (r->sb && r->fused == 2 && r->tiling == 2 && shared_on && (wg2 >= 2200 || tn.fused_sb == 1)) {
+    // groups of TWO GPs (twice the workgroups of the pack's group size, 17.5 instead of 14.25 instructions per pair and GP at D = 5) while
+    // the launch is small: ms per batch, groups of 2 | groups of 4 | one GP per workgroup -- N = 1024, B = 8 0.65 | 0.80 | 0.69, B = 12
+    // 0.70 | 0.87 | 0.81, B = 16 0.83 | 0.89 | 0.99, B = 24 1.07 | 1.16 | 1.44; N = 2048, B = 2 0.61 | 0.84 | 0.69, B = 4 0.86 | 0.95 | 1.03,
+    // B = 8 1.51 | 1.38 | 1.91; N = 768, B = 16 0.64 | 0.73 | 0.72 (profiles/r03/ab_fused_shared.txt)
+    r->fng = p->sh_ng;
+    if (p->sh_ng > 2 && p->ds % 2 == 0 && p->wl_sh[3].work_dev && wg2 < 4200) r->fng = 2;
+    if (r->sb && r->fused == 2 && r->tiling == 2 && shared_on && (wg2 >= (r->fng == 2 ? 1000 : 2200) || tn.fused_sb == 1)) {
         // one lambda for all GPs AND the one-launch form: its tile workgroups take groups of sh_ng GPs (step_fused.h, NG > 1) on the
         // shared 256x64 list.  Three forms compete for such a pack (profiles/r03/ab_fused_shared.txt, ms per batch: groups of GPs in one
         // launch | one GP per tile workgroup in one launch | shared-lambda pair kernel, two launches): N = 1024, B = 8 0.81 | 0.67 | -,
@@ -1027,7 +1033,7 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
                   ((long)B * r->nwork <= 4096 || tn.colunroll == 4)) ? 4 : 1;
     if (shape) {
         r->tiling = shape->tiling; r->tb = shape->tb; r->waves = shape->waves; r->nwork = shape->nwork; r->sb = shape->sb;
-        r->rgroup = shape->rgroup; r->fused = shape->fused; r->fq = shape->fq; r->shared = shape->shared; r->sh_list = shape->sh_list;
+        r->rgroup = shape->rgroup; r->fused = shape->fused; r->fq = shape->fq; r->shared = shape->shared; r->sh_list = shape->sh_list; r->fng = shape->fng;
         r->colunroll = shape->colunroll;
     }
     r->nm = gpmpc_num_moments(D, diag, grad);
@@ -1054,7 +1060,7 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     r->off_jac = take(grad ? (size_t)B * H * 2 * p->ds * (2 * p->ds + p->da) : 0);
     r->gw = gpmpc_sb_gw(D, p->ds);
     // column rows: [B][GP][Np][gw] written by the head kernel, or one [64][gw] slot per tile workgroup of the mid-size fused form
-    r->off_G = take(r->fused == 2 ? (size_t)B * (r->shared ? p->wl_sh[1].nwork : r->nwork) * p->wl[0][r->tiling].jt * r->gw
+    r->off_G = take(r->fused == 2 ? (size_t)B * (r->shared ? p->wl_sh[(r->fng == 2 && p->sh_ng != 2) ? 3 : 1].nwork : r->nwork) * p->wl[0][r->tiling].jt * r->gw
                                   : (r->sb ? (size_t)B * (r->shared ? 1 : p->ds) * p->Np * r->gw : 0));
     r->off_means = take((size_t)B * (H + 1) * p->ds);
     r->off_vars = take((size_t)B * (H + 1) * p->ds);
@@ -1190,10 +1196,11 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
         memset(&F, 0, sizeof(F));
         const gpmpc_worklist& wl = p->wl[0][r.tiling];
         const bool fsh = r.fused == 2 && r.shared;          // groups of GPs with one lambda per tile workgroup
-        F.XT = p->XT; F.beta = p->beta; F.lam = p->lam; F.sf = p->sf; F.M = p->M; F.work = fsh ? p->wl_sh[1].work_dev : wl.work_dev;
+        const gpmpc_worklist& wsh = p->wl_sh[(r.fng == 2 && p->sh_ng != 2) ? 3 : 1];      // groups of two GPs | of the pack's group size
+        F.XT = p->XT; F.beta = p->beta; F.lam = p->lam; F.sf = p->sf; F.M = p->M; F.work = fsh ? wsh.work_dev : wl.work_dev;
         const int nwg = r.nwork * r.fq;                     // partial sums per trajectory (= tile workgroups, except fsh: ds x tiles)
         F.N = p->N; F.Np = p->Np; F.nwork = nwg;
-        F.ntile = fsh ? p->wl_sh[1].nwork : nwg; F.tiles = fsh ? p->sh_tiles[1] : 0;
+        F.ntile = fsh ? wsh.nwork : nwg; F.tiles = fsh ? p->sh_tiles[1] : 0;
         F.tri64 = (r.tiling == 1) ? 1 : 0;                  // 64x64 list: items decoded arithmetically (no dependent load)
         for (int a = 0; a <= p->ds; ++a) { F.ustart[a] = fsh ? a * p->sh_tiles[1] : wl.ustart_host[a] * r.fq; A.ust[a] = F.ustart[a]; }
         A.ust_inline = 1; A.nwork = nwg;
@@ -1203,7 +1210,7 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
         F.sps = r.sps; F.nm = r.nm;
         F.gscr = r.fused == 2 ? (double*)(ws + r.off_G) : nullptr;
         for (int t = 1; t <= H; ++t) {
-            const int rc = timed_launch(GPMPC_TIME_FUSED, s, [&] { return launch_step_fused(p->D, grad, p->ds, r.fused == 2 ? (r.tiling == 2 ? 0 : wl.jt) : r.fq, fsh ? p->sh_ng : 1, F, t, s); });
+            const int rc = timed_launch(GPMPC_TIME_FUSED, s, [&] { return launch_step_fused(p->D, grad, p->ds, r.fused == 2 ? (r.tiling == 2 ? 0 : wl.jt) : r.fq, fsh ? r.fng : 1, F, t, s); });
             if (rc != GPMPC_OK) return rc;
         }
         A.part += (size_t)(H & 1) * B * nwg * r.nm;          // the tail finishes step H from the parity the last launch wrote
