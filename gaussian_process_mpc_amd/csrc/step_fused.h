@@ -83,13 +83,13 @@ static __device__ unsigned long long g_fused_wg[2 * 8192];         // [start | e
 // (the scalar cache may hold the slot's previous contents) and the workgroup barrier.
 // layout of sp (doubles), as step.hip: 0 c | 1 mu | 2 sf2 | 3 A[D] | 3+D scale[D] | 3+2D dmu_du[D] | 3+3D dmu_ds[D]
 #ifndef GPMPC_FUSED_SB_WAVES
-#define GPMPC_FUSED_SB_WAVES 5      /* waves per SIMD the mid-size form is compiled for (A/B knob) */
+#define GPMPC_FUSED_SB_WAVES 5      /* waves per SIMD the mid-size form is compiled for up to D = 5 (A/B knob; 4 from D = 6: 21 spilled registers at 96) */
 #endif
 // NG > 1 (Q = 0 only): every GP has the SAME length-scales (pair_kernel_sbs.h): a tile workgroup takes a group of NG GPs, evaluates the
 // exponent and the exp ONCE per pair and applies them to NG weight loads; work list wl_sh[1] (items {group, i0, j0, tile}),
 // partial sums laid out [GP][tile], one row of column data per trajectory instead of one per GP.
 template <int D, int NS2, bool GRAD, int Q, int NG = 1>
-__global__ __launch_bounds__(256, (Q == 0 || Q == 32 || Q == 16) ? (NG >= 3 ? 3 : (NG == 2 ? 4 : GPMPC_FUSED_SB_WAVES)) : 1)
+__global__ __launch_bounds__(256, (Q == 0 || Q == 32 || Q == 16) ? (NG >= 3 ? 3 : ((NG == 2 || D >= 6) ? 4 : GPMPC_FUSED_SB_WAVES)) : 1)
 void k_step_fused(FusedArgs A, int t) {
     constexpr bool SB = Q == 0 || Q == 32 || Q == 16;
     constexpr bool SH = NG > 1;
