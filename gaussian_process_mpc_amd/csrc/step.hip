@@ -884,10 +884,11 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     const int D = p->D;
     // The selection as it stands (diagonal rollout, da <= 2; every threshold is a measured crossover -- its numbers are in the
     // comment at its line, the method in DESIGN.md section 5, the maps in profiles/r02 and r03/batch_size_map.txt):
-    //   W64 = B x tiles(256x64) < ~400, or N < 256, or N > ~2100 below 1250     ONE launch per step, 64-row tiles, staged column loop
+    //   W64 = B x tiles(256x64) < ~150 (~400 for N < 512), or N < 256           ONE launch per step, 64-row tiles, staged column loop
     //                                                                           (step_fused.h, Q = 1 | 4; the B = 1 solver callbacks)
-    //   ~400 <= W64 <= ~4700 (3000 with one lambda for all GPs), 256 <= N <= ~2100   ONE launch per step, 256x64 tiles, scalar-broadcast
-    //                                                                           column loop (step_fused.h, Q = 0), two concurrent sub-batches
+    //   up to W64 ~4700 (~7000: <= 200 tiles per trajectory, or one lambda),    ONE launch per step, 256x16 / 32 / 64 tiles by the size of the launch,
+    //   256 <= N <= ~4300                                                       scalar-broadcast column loop (step_fused.h, Q = 16 / 32 / 0; groups of GPs
+    //                                                                           per tile workgroup with one lambda), two concurrent sub-batches
     //   W64 beyond, until a wide tiling fills the chip                          head kernel + pair_kernel_sb.h on 256x64 tiles, one trajectory per
     //                                                                           wave (pair_kernel_sbs.h with one lambda), 2-4 concurrent sub-batches
     //   ceil(B/2) x tiles(256x128) >= 2800, N > 512, D <= 5                     head + pair_kernel_sb.h on 256x128 tiles, two trajectories per wave
@@ -919,7 +920,7 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     const long wg2 = (long)B * p->wl[0][2].nwork;
     const bool shared_on = p->shared_lambda && p->tune.shared != 0 && p->sh_ng >= 2;
     const bool fsb_can = sb_ok && !lowprec && p->da >= 1 && p->tune.fused_sb != 0 && (p->Np >= 256 || p->tune.fused_sb == 1) &&
-                         p->wl[0][2].nwork <= (p->tune.fused_sb == 1 ? 600 : 320) * p->ds;
+                         p->wl[0][2].nwork <= 600 * p->ds;           // (N <= ~4300; measured up to N = 4096: B = 1 / 2 x1.22 / 1.18 at ds = 4, level at ds = 6)
     // ... and with NARROWER tiles (256x32, 256x16: work lists 5, 6) further down for training sets of at least two row tiles: a launch
     // of a few hundred 256x64 workgroups leaves most of the chip empty while each workgroup walks its 64 columns one L2 round trip
     // at a time (N = 2048, B = 1: 24.5 us per launch on 576 workgroups, profiles/r03/kernel_stats_C3_B1.csv); half / quarter tiles
@@ -978,7 +979,8 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     // each call; profiles/r03/ab_fused_sb.txt): N = 1024, B = 8 / 12 / 16 / 24 / 32 / 48 x1.29 / 1.42 / 1.26 / 1.08 / 1.04 / 0.98;
     // N = 2048, B = 4 / 6 / 8 / 12 x1.17 / 1.10 / 1.06 / 0.97; N = 768, B = 24 / 48 x1.36 / 1.13: up to ~4700 tile workgroups per
     // launch (beyond, the longer prologue of every tile workgroup costs more than the head kernel it replaces).
-    // (N > ~2100 -- more than 320 tiles per GP -- stays on head + pair kernel: N = 4096, B = 1 4.35 vs 3.73 ms)
+    // (up to 600 tiles per GP, N <= ~4300.  An earlier limit of 320 came from N = 4096, ds = 6, B = 1 at 4.35 vs 3.73 ms -- measured on D = 7
+    // instances that spilled 21 registers; compiled for 4 waves per SIMD they are level there, and ds = 4 gains x1.2 at N = 3584 / 4096)
     // With ONE lambda for all GPs the shared-lambda pair kernel (two launches per step) is the alternative: the one-launch form
     // evaluating the exponent per GP is ahead of it up to ~3000 tile workgroups (profiles/r03/ab_fused_sb_vs_shared.txt:
     // N = 1024, B = 8 / 12 / 16 / 24 / 32 x1.52 / 1.45 / 1.20 / 0.99 / 0.75; N = 2048, B = 2 / 4 / 8 x1.37 / 1.29 / 0.85), and with
