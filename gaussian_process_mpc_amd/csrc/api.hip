@@ -164,7 +164,7 @@ extern "C" int gpmpc_predict(int n, int D, const double* X, const double* lambda
     double* K = out_K ? out_K : (double*)workspace;
     double* W = (double*)((char*)workspace + slab);
     double* lam = (double*)((char*)workspace + 2 * slab);
-    GPMPC_HIP(hipMemcpyAsync(lam, lambdas_host, sizeof(double) * D, hipMemcpyHostToDevice, s));
+    if (int rcu = gpmpc_upload_small(lam, lambdas_host, sizeof(double) * D, s)) return rcu;
     const double sf2 = sigma_f * sigma_f;
     hipLaunchKernelGGL(k_cross_kernel, dim3((n + 255) / 256, np), dim3(256), 0, s, Xp, np, X, n, D, lam, sf2, K);
     if (out_mean) hipLaunchKernelGGL(k_rows_dot, dim3(np), dim3(256), 0, s, K, beta, n, out_mean);

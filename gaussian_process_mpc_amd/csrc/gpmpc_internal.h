@@ -183,6 +183,11 @@ int gpmpc_launch_pair(int D, bool diag, bool grad, int tb, int waves, const Pair
 template <int D> int gpmpc_launch_pair_D(bool diag, bool grad, int tb, int waves, const PairArgs& a, hipStream_t s);
 
 void gpmpc_set_error(const char* what, hipError_t e);
+// Small host array (<= 512 bytes: hyper-parameters, index pairs) -> device memory, ordered on `s`, with the host bytes CONSUMED BEFORE
+// THE CALL RETURNS: they travel as kernel arguments.  (hipMemcpyAsync from pageable memory may read the host buffer only when the
+// stream gets there -- behind a wait on another stream that can be after the caller has freed it; seen as a wrong K matrix from a
+// rebuild queued on a side stream.)  Returns a GPMPC_* code.
+int gpmpc_upload_small(void* dst_dev, const void* src_host, size_t bytes, hipStream_t s);
 // GPMPC_OK if the calling thread's current device is the pack's, else GPMPC_E_DEVICE (kernels launched on another
 // device would dereference this pack's memory without peer access: a GPU page fault, not an error code)
 static inline int gpmpc_check_device(const gpmpc_pack* p) {

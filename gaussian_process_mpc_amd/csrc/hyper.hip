@@ -95,7 +95,7 @@ extern "C" int gpmpc_ml_grad(int n, int D, const double* X_dev, const double* Ky
     const int nblocks = (n + GPMPC_ML_ROWS - 1) / GPMPC_ML_ROWS;
     double* part = (double*)workspace;
     double* lam = part + (size_t)nblocks * (D + 1);
-    GPMPC_HIP(hipMemcpyAsync(lam, lambdas_host, sizeof(double) * D, hipMemcpyHostToDevice, s));
+    if (int rcu = gpmpc_upload_small(lam, lambdas_host, sizeof(double) * D, s)) return rcu;
     const double sf2 = sigma_f * sigma_f;
     switch (D) {
         case 1: launch_ml_partial<1>(n, nblocks, X_dev, Ky_inv_dev, alpha_dev, lam, sf2, part, s); break;

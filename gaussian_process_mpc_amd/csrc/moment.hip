@@ -544,7 +544,7 @@ static int run_mom(const gpmpc_pack* p, MomArgs& A, const MomPlan& r, bool grad,
                 if (a == b || (!bug && b < a)) continue;   // the bug-compatible form is not symmetric in (a, b)
                 h[2 * n] = a; h[2 * n + 1] = b; ++n;
             }
-        GPMPC_HIP(hipMemcpyAsync(pairs_dev, h, sizeof(int) * 2 * n, hipMemcpyHostToDevice, s));
+        if (int rcu = gpmpc_upload_small(pairs_dev, h, sizeof(int) * 2 * n, s)) return rcu;      // (h is on this stack frame)
         hipLaunchKernelGGL(k_cross_cov<D>, dim3(A.nq * n), dim3(256), 0, s, A, pairs_dev, n);
     }
     GPMPC_HIP(hipGetLastError());

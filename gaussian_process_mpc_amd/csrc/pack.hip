@@ -80,6 +80,21 @@ __global__ __launch_bounds__(256) void k_pack_weights(const double* __restrict__
     }
 }
 
+struct gpmpc_small_payload { unsigned w[128]; };
+__global__ void k_upload_small(gpmpc_small_payload p, unsigned* __restrict__ dst, int nwords) {
+    const int i = threadIdx.x;
+    if (i < nwords) dst[i] = p.w[i];
+}
+int gpmpc_upload_small(void* dst_dev, const void* src_host, size_t bytes, hipStream_t s) {
+    if (!dst_dev || !src_host || bytes == 0 || bytes > sizeof(gpmpc_small_payload) || (bytes & 3)) return GPMPC_E_ARG;
+    gpmpc_small_payload p;
+    memset(&p, 0, sizeof(p));
+    memcpy(&p, src_host, bytes);
+    hipLaunchKernelGGL(k_upload_small, dim3(1), dim3(128), 0, s, p, (unsigned*)dst_dev, (int)(bytes / 4));
+    GPMPC_HIP(hipGetLastError());
+    return GPMPC_OK;
+}
+
 // Kf = sigma_f^2 exp(-1/2 d2), Ky = Kf + noise_var I   (src/gpr.py:163-170)
 __global__ void k_build_ky(const double* __restrict__ X, int n, int D, const double* __restrict__ lam,
                            double sf2, double noise_var, double* __restrict__ Kf, double* __restrict__ Ky) {
@@ -348,9 +363,9 @@ static int pack_build_impl(gpmpc_pack* p, const double* X_dev, const double* Y_d
         gpmpc_graph_cache_invalidate(p->graph_cache);
         gpmpc_cb_cache_invalidate(p->cb_cache);
     }
-    // hyper-parameters are tiny; pageable-host copies are staged synchronously by the runtime
-    GPMPC_HIP(hipMemcpyAsync(p->lam, lambdas_host, sizeof(double) * p->ds * p->D, hipMemcpyHostToDevice, s));
-    GPMPC_HIP(hipMemcpyAsync(p->sf, sigma_f_host, sizeof(double) * p->ds, hipMemcpyHostToDevice, s));
+    // hyper-parameters are tiny: as kernel arguments (consumed before this call returns, gpmpc_upload_small)
+    if (int rcu = gpmpc_upload_small(p->lam, lambdas_host, sizeof(double) * p->ds * p->D, s)) return rcu;
+    if (int rcu = gpmpc_upload_small(p->sf, sigma_f_host, sizeof(double) * p->ds, s)) return rcu;
     hipLaunchKernelGGL(k_pack_points, dim3((p->Np + 255) / 256), dim3(256), 0, s, X_dev, p->N, p->Np, p->D, p->X, p->XT);
     if (y_is_beta)
         hipLaunchKernelGGL(k_pack_copy_beta, dim3((p->Np + 255) / 256, p->ds), dim3(256), 0, s, Y_dev, p->N, p->Np, p->ds, p->beta);
@@ -434,7 +449,7 @@ extern "C" int gpmpc_build_ky(int n, int D, const double* X_dev, const double* l
     hipStream_t s = (hipStream_t)stream;
     double* lam = nullptr;
     GPMPC_HIP(hipMallocAsync((void**)&lam, sizeof(double) * D, s));
-    GPMPC_HIP(hipMemcpyAsync(lam, lambdas_host, sizeof(double) * D, hipMemcpyHostToDevice, s));
+    if (int rcu = gpmpc_upload_small(lam, lambdas_host, sizeof(double) * D, s)) { (void)hipFreeAsync(lam, s); return rcu; }
     hipLaunchKernelGGL(k_build_ky, dim3((n + 255) / 256, n), dim3(256), 0, s, X_dev, n, D, lam, sigma_f * sigma_f,
                        noise_var, Kf_dev, Ky_dev);
     GPMPC_HIP(hipGetLastError());

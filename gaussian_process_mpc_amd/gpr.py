@@ -197,7 +197,11 @@ class GaussianProcessRegression(object):
                 main = torch.cuda.current_stream(self.device.index)
                 for t in (Kf, Ky, Kinv):
                     t.record_stream(main)                          # allocated on the side stream, consumed here
-                for m in range(n_p, self.num_train):               # the observations that arrived while it ran
+                # the observations that arrived while it ran, one Schur step each.  (ONE block step for all of them -- S = K_kk + sn^2 I -
+                # K_kn Ky_inv K_nk, k x k -- was tried: its result is as close to the true inverse as the sequential one, but the appends
+                # that follow it blow up within a few steps at cond(Ky) ~ 1e7: abs error 1e-5 -> 1e+3 in ten appends, against a flat
+                # ~1e-4 for the sequential form, on the problem of tests/test_gpu_api.py::test_side_stream_rebuild_catches_up_and_swaps.)
+                for m in range(n_p, self.num_train):
                     Kf, Ky, Kinv = self._schur_append(self.X_train[:m], self.X_train[m:m + 1], Kf, Ky, Kinv)
                 self.Kf, self.Ky, self.Ky_inv = Kf, Ky, Kinv
                 self._beta = None
@@ -220,7 +224,7 @@ class GaussianProcessRegression(object):
             Ky = torch.empty((n, n), dtype=torch.float64, device=self.device)
             check(lib().gpmpc_build_ky(n, self.x_dim, ptr(X), lp, self.get_sigma_f(), self._noise_var(), ptr(Kf), ptr(Ky),
                                        ctypes.c_void_p(side.cuda_stream)), "gpmpc_build_ky")
-            Kinv = self._invert(Ky)
+            Kinv = self._invert(Ky, check=False)
             ev = torch.cuda.Event()
             ev.record(side)
         X.record_stream(side)
@@ -268,11 +272,15 @@ class GaussianProcessRegression(object):
             check(lib().gpmpc_build_ky(n, self.x_dim, ptr(X), lp, self.get_sigma_f(), noise, ptr(self.Kf), ptr(self.Ky),
                                        stream_ptr()), "gpmpc_build_ky")
 
-    def _invert(self, Ky):
-        """Explicit inverse of one matrix or of a (k, n, n) stack (one batched factorisation)."""
+    def _invert(self, Ky, check=True):
+        """Explicit inverse of one matrix or of a (k, n, n) stack (one batched factorisation).  check=False: no error check on
+        the host (torch.linalg.inv waits for the factorisation's status word: a host synchronisation, which would put a
+        side-stream rebuild back onto the step that starts it)."""
         if self.inverse == "lu":
-            return torch.linalg.inv(Ky)
+            return torch.linalg.inv(Ky) if check else torch.linalg.inv_ex(Ky, check_errors=False).inverse
         if self.inverse == "cholesky":
+            if not check:
+                return torch.cholesky_inverse(torch.linalg.cholesky_ex(Ky, check_errors=False).L)
             return torch.cholesky_inverse(torch.linalg.cholesky(Ky))
         raise ValueError("GaussianProcessRegression.inverse must be 'lu' or 'cholesky', got %r" % (self.inverse,))
 

@@ -19,6 +19,10 @@
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).
  *    All work is enqueued asynchronously on it; nothing synchronises the
  *    device.  Calls are re-entrant across streams as long as workspaces differ.
+ *    HOST arrays (hyper-parameters, cost parameters) are consumed before the call
+ *    returns -- they travel as kernel arguments --: the caller may free or overwrite
+ *    them at once, whatever `stream` is waiting for.  DEVICE buffers must stay valid
+ *    until the work enqueued on `stream` has run.
  *  - Return value: 0 on success, a negative GPMPC_E_* code otherwise.  No
  *    exception crosses the ABI.  NaNs produced by the arithmetic (negative
  *    variances, log of a non-positive determinant) are passed through, as in
