@@ -66,6 +66,8 @@ def parse_args():
     ap.add_argument("--cl-horizon", type=int, default=10)
     ap.add_argument("--cl-distinct", action="store_true", help="closed loop: a different lambda per GP (no shared inverse)")
     ap.add_argument("--cl-async", action="store_true", help="closed loop: the every-64 full rebuild on a side stream (catch-up + swap)")
+    ap.add_argument("--cl-newton", action="store_true",
+                    help="closed loop: every 64 appends a Newton-Schulz polish of the incrementally updated inverse instead of the full rebuild")
     ap.add_argument("--cl-rebuild", action="store_true", help="closed loop: the reference's O(N^3) rebuild on every step")
     ap.add_argument("--dist-timeout", type=float, default=120.0, help="process-group timeout in seconds (--gpus > 1)")
     ap.add_argument("--oversubscribe", action="store_true",
@@ -609,7 +611,10 @@ def run_closed_loop(args):
     # one-time load of its kernels: 15-60 ms)
     mpc.dynamics.pack(); a0 = mpc.get_optimal_trajectory(obs)[0, :]
     nxt0 = plant.step(a0)[0]
-    mpc.dynamics.append_train_data(obs, a0, nxt0, incremental=not args.cl_rebuild, async_rebuild=args.cl_async); sync()
+    if args.cl_newton:
+        mpc.dynamics.gpr_err[0]._newton_refresh(); sync()      # untimed: the GEMM library loads its fp64 kernels on first use (~12 ms once)
+    mpc.dynamics.append_train_data(obs, a0, nxt0, incremental=not args.cl_rebuild, async_rebuild=args.cl_async,
+                                   refresh="newton" if args.cl_newton else None); sync()
     obs = nxt0
     n0 += 1
     rows = []
@@ -633,7 +638,8 @@ def run_closed_loop(args):
                                + ", sigma_n = 1e-3, solver " + str(mpc.solver_used)
                                + (", full O(N^3) rebuild per step (the reference's update)" if args.cl_rebuild else
                                   ", O(N^2) Schur append per step, full rebuild every 64"
-                                  + (" on a side stream (catch-up + swap)" if args.cl_async else ""))},
+                                  + (" on a side stream (catch-up + swap)" if args.cl_async else "")
+                                  + (" -- replaced by a Newton-Schulz polish of the updated inverse" if args.cl_newton else ""))},
         "steps": args.cl_steps,
         "step_ms": {"median": float(np.median(total)), "mean": float(total.mean()), "max": float(total.max()),
                     "p95": float(np.percentile(total, 95)), "max_over_median": float(total.max() / np.median(total))},

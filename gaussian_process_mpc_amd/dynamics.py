@@ -27,14 +27,20 @@ class Dynamics(object):
         self._pack = None
         self._pack_key = None
 
-    def append_train_data(self, state, action, next_state, incremental=False, async_rebuild=None):
+    def append_train_data(self, state, action, next_state, incremental=False, async_rebuild=None, refresh=None):
         """(state, action, next_state) observations, one or many (src/dynamics.py:39-60).  incremental=True: O(N^2)
         update of every Ky_inv for a single new observation (see GaussianProcessRegression.append_train_data);
         async_rebuild (True / False; None leaves the GPs' setting): the periodic full rebuild of the incremental path on a
-        side stream instead of on the step that reaches `rebuild_every`."""
+        side stream instead of on the step that reaches `rebuild_every`; refresh ("rebuild" / "newton"; None leaves the GPs'
+        setting): a Newton-Schulz polish of the updated inverse instead of that rebuild (GaussianProcessRegression.refresh)."""
         if async_rebuild is not None:
             for g in self.gpr_err:
                 g.async_rebuild = bool(async_rebuild)
+        if refresh is not None:
+            if refresh not in ("rebuild", "newton"):
+                raise ValueError("refresh must be 'rebuild' or 'newton', got %r" % (refresh,))
+            for g in self.gpr_err:
+                g.refresh = refresh
         state, action, next_state = np.asarray(state), np.asarray(action), np.asarray(next_state)
         # Every GP receives the same input rows; GPs whose hyper-parameters are bit-identical then have identical Ky /
         # Ky_inv and share one build (GaussianProcessRegression.update_many).  That only holds while ALL data went through

@@ -40,6 +40,12 @@ class GaussianProcessRegression(object):
         # result (O(N^2) each) and the matrices are swapped -- the O(N^3) inverse never sits on an environment step.
         self.async_rebuild = False
         self._pending = None        # (n, hypers, Kf, Ky, Ky_inv, event, stream) of a rebuild in flight
+        # How the incremental path bounds its round-off every `rebuild_every` appends: "rebuild" (default): Kf, Ky from scratch and
+        # a fresh LU inverse, the reference's own update (O(N^3): 2.2 ms at N = 400, or `async_rebuild`); "newton": Newton-Schulz
+        # steps X <- X + X (I - Ky X) on the incrementally updated inverse -- it is already within ~1e-4 of the true one, each step
+        # squares the residual, and a step is two N x N GEMMs (a handful of launches instead of the LU's few hundred): the refresh
+        # costs 0.1-0.2 ms on the step it falls on.  Falls back to the rebuild when the residual is not safely contractive.
+        self.refresh = "rebuild"
         # "lu": torch.linalg.inv, the reference's own call (src/gpr.py:171) and the default, so that Ky_inv carries the
         # reference's round-off.  "cholesky": potrf + potri (SURVEY 8 f1 as sketched): a third of the flops and a symmetric
         # result, but NOT the reference's numerics -- the variances move by ~1e-5 relative at sigma_n = 1e-5.
@@ -116,7 +122,7 @@ class GaussianProcessRegression(object):
         # accumulates: fall back to the reference's full rebuild when the hypers changed and every `rebuild_every` appends.
         inc = (incremental and num_obs == 1 and self.num_train > 0 and self.Ky_inv is not None
                and self._built_hypers == self._current_hypers()
-               and (self._appends_since_rebuild < self.rebuild_every or self.async_rebuild))
+               and (self._appends_since_rebuild < self.rebuild_every or self.async_rebuild or self.refresh == "newton"))
         if not inc:
             self._pending = None                               # a full rebuild supersedes one in flight
         self.num_train += num_obs
@@ -183,8 +189,36 @@ class GaussianProcessRegression(object):
         self._beta = None
         self.version += 1
         self._appends_since_rebuild += 1
-        if self.async_rebuild:
+        if self.refresh == "newton":
+            if self._appends_since_rebuild >= self.rebuild_every:
+                self._newton_refresh()
+        elif self.async_rebuild:
             self._service_async_rebuild()
+
+    def _newton_refresh(self, max_steps=6):
+        """Newton-Schulz polish of the incrementally updated inverse (see `refresh`).  The residual R = I - Ky X is measured once
+        (one small device-to-host read); below 0.5 in the Frobenius norm the iteration X <- X + X R converges quadratically and is
+        run until the PREDICTED residual (r, r^2, r^4, ...) is below 1e-13; otherwise the matrices are rebuilt from scratch."""
+        n = self.num_train
+        eye = torch.eye(n, dtype=torch.float64, device=self.device)
+        X = self.Ky_inv
+        R = eye - self.Ky @ X
+        r = float(torch.linalg.matrix_norm(R).item())
+        if not (r < 0.5):
+            self.build_Ky_inv_mat()
+            return
+        steps = 0
+        while r > 1e-13 and steps < max_steps:
+            X = X + X @ R
+            steps += 1
+            r = r * r
+            if r > 1e-13 and steps < max_steps:
+                R = eye - self.Ky @ X
+        self.Ky_inv = X
+        self._beta = None
+        self.version += 1
+        self._appends_since_rebuild = 0
+        self.newton_steps_last = steps
 
     def _service_async_rebuild(self):
         """Side-stream rebuild: start one when `rebuild_every` appends have accumulated; once a started one has finished,

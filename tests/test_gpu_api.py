@@ -651,6 +651,44 @@ def test_side_stream_rebuild_catches_up_and_swaps(G):
     np.testing.assert_allclose(ci, cr, rtol=1e-5, atol=1e-9)
 
 
+def test_newton_refresh_of_the_incremental_inverse(G):
+    """refresh = "newton": every `rebuild_every` appends the incrementally updated inverse is polished by Newton-Schulz steps
+    instead of being rebuilt (two GEMMs per step).  Never a full rebuild on a step, the polished inverse within the tolerance of a
+    from-scratch one, a residual that is not safely contractive falls back to the rebuild."""
+    rng = np.random.default_rng(12)
+    D, n0, extra = 3, 120, 150
+    X = rng.uniform(-2, 2, (n0 + extra, D))
+    y = np.sin(X).sum(axis=1)
+    inc, ref = G.GaussianProcessRegression(D), G.GaussianProcessRegression(D)
+    for g in (inc, ref):
+        g.set_lambdas(np.array([1.5, 2.0, 1.0])); g.set_sigma_n(1e-2); g.set_sigma_f(1.2)
+    inc.rebuild_every, inc.refresh = 16, "newton"
+    inc.append_train_data(X[:n0], y[:n0])
+    refreshed = 0
+    for k in range(n0, n0 + extra):
+        v = inc.version
+        inc.append_train_data(X[k], float(y[k]), incremental=True)
+        if inc._appends_since_rebuild == 0:
+            refreshed += 1
+            assert inc.version == v + 2 and 1 <= inc.newton_steps_last <= 6        # append + polish, not a rebuild
+            fresh = torch.linalg.inv(inc.Ky)
+            scale = float(fresh.abs().max())
+            assert float((inc.Ky_inv - fresh).abs().max()) <= 1e-7 * scale
+    assert refreshed == extra // 16
+    ref.append_train_data(X, y)
+    np.testing.assert_allclose(inc.Ky.cpu().numpy(), ref.Ky.cpu().numpy(), rtol=1e-12, atol=1e-14)
+    Xp = rng.uniform(-2, 2, (5, D))
+    fi, ci = inc.predict_latent_vars(Xp, covar=True)
+    fr, cr = ref.predict_latent_vars(Xp, covar=True)
+    np.testing.assert_allclose(fi, fr, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(ci, cr, rtol=1e-4, atol=1e-8)
+    # an inverse that is far off (here: of other hyper-parameters' matrix) is rebuilt, not iterated on
+    inc.Ky_inv = 0.1 * inc.Ky_inv
+    inc._appends_since_rebuild = inc.rebuild_every
+    inc._newton_refresh()
+    np.testing.assert_allclose(inc.Ky_inv.cpu().numpy(), torch.linalg.inv(inc.Ky).cpu().numpy(), rtol=0, atol=1e-9 * scale)
+
+
 def test_numpy_forward_propagate_signature(G, golden):
     """Dynamics.forward_propagate (the reference's numpy rollout, src/dynamics.py:62-124): numpy in, numpy (H+1, ds) /
     (H+1, ds, ds) out, values of the torch rollout (the reference's own rung-4 test holds the two to 1e-7)."""

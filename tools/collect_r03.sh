@@ -31,7 +31,7 @@ for b in 8 16 32; do
 done
 python bench.py --gpus 2 --oversubscribe --backend gloo --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_2rank_gloo_one_card.json 2>/dev/null
 python bench.py --gpus 6 --config C4 --batch 2 --oversubscribe --backend gloo --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_C4_6rank_gloo_one_card.json 2>$O/bench_C4_6rank.err
-for v in "" "--cl-distinct" "--cl-rebuild"; do python bench.py --closed-loop $v > "$O/closed_loop$(echo $v | tr -d ' ').json" 2>/dev/null; done
+for v in "" "--cl-distinct" "--cl-rebuild" "--cl-async" "--cl-newton"; do python bench.py --closed-loop $v > "$O/closed_loop$(echo $v | tr -d ' ').json" 2>/dev/null; done
 python tools/callback_latency.py 2>/dev/null | tail -2 > $O/callback_latency.txt
 fi
 if [ $STEP = all ] || [ $STEP = maps ]; then
