@@ -74,6 +74,7 @@ SIGNATURES = {
     "gpmpc_rollout_jac": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gpmpc_rollout_vjp": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gpmpc_rollout_workspace_bytes": (_sz, [_vp, _i, _i, _u]),
+    "gpmpc_plan_describe": (_i, [_vp, _i, _i, _u, ctypes.c_char_p, _sz]),
     "gpmpc_rollout": (_i, [_vp, _i, _i, _vp, _vp, ctypes.POINTER(CostParamsC), _u, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gpmpc_objective_gradient": (_i, [_vp, _i, _dp, _dp, ctypes.POINTER(CostParamsC), _u, _dp, _vp]),
     "gpmpc_rollout_fullcov_workspace_bytes": (_sz, [_vp, _i, _i, _u]),
@@ -102,8 +103,16 @@ def lib():
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C gaussian_process_mpc_amd/csrc`. There is no CPU fallback.")
         h = ctypes.CDLL(LIB_PATH)
+        # A/B runs against an OLDER build of the library (GPMPC_LIB_PATH + GPMPC_LIB_ALLOW_MISSING=1, tools/lib_ab.py) may lack
+        # entry points added since; the product library must export every declared symbol
+        tolerant = bool(os.environ.get("GPMPC_LIB_PATH")) and os.environ.get("GPMPC_LIB_ALLOW_MISSING") == "1"
         for name, (res, args) in SIGNATURES.items():
-            fn = getattr(h, name)          # AttributeError if a declared symbol is missing
+            try:
+                fn = getattr(h, name)      # AttributeError if a declared symbol is missing
+            except AttributeError:
+                if tolerant:
+                    continue
+                raise
             fn.restype, fn.argtypes = res, args
         _lib = h
     return _lib

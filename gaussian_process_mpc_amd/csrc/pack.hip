@@ -239,7 +239,9 @@ extern "C" int gpmpc_pack_create(gpmpc_pack** out, int n_train, int state_dim, i
     if (!p) return GPMPC_E_ALLOC;
     p->N = n_train; p->Np = ((n_train + 63) / 64) * 64; p->ds = state_dim; p->da = action_dim; p->D = D;
     gpmpc_read_tuning(&p->tune);
-    if (hipError_t ed = hipGetDevice(&p->device); ed != hipSuccess) { gpmpc_set_error("gpmpc_pack_create: hipGetDevice", ed); free(p); return GPMPC_E_LAUNCH; }
+    p->lock = gpmpc_lock_create();
+    if (!p->lock) { free(p); return GPMPC_E_ALLOC; }
+    if (hipError_t ed = hipGetDevice(&p->device); ed != hipSuccess) { gpmpc_set_error("gpmpc_pack_create: hipGetDevice", ed); gpmpc_lock_destroy(p->lock); free(p); return GPMPC_E_LAUNCH; }
     if (hipDeviceGetAttribute(&p->num_cu, hipDeviceAttributeMultiprocessorCount, p->device) != hipSuccess || p->num_cu < 1) p->num_cu = 256;
     for (int a = 0; a < state_dim; ++a)
         for (int b = a + 1; b < state_dim; ++b) { p->pair_a[p->npairs] = a; p->pair_b[p->npairs] = b; ++p->npairs; }
@@ -315,6 +317,7 @@ extern "C" int gpmpc_pack_destroy(gpmpc_pack* p) {
     if (p->sf) (void)hipFree(p->sf);
     gpmpc_graph_cache_free(p->graph_cache);
     gpmpc_cb_cache_free(p->cb_cache);
+    gpmpc_lock_destroy(p->lock);
     if (p->pair_ab_dev) (void)hipFree(p->pair_ab_dev);
     for (int mode = 0; mode < 2; ++mode)
         for (int k = 0; k < 7; ++k) {

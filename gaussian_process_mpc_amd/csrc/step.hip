@@ -19,6 +19,7 @@
 #include "gpmpc_internal.h"
 #include "fast_exp.h"
 #include <cstdlib>
+#include <new>
 
 // Diagnostic build (-DGPMPC_SB_STAMPS): phase stamps of the head kernel, workgroup (0, 0, 0) of horizon step 5 (tools/sb_stamps.py)
 #ifdef GPMPC_SB_STAMPS
@@ -34,7 +35,7 @@ extern "C" int gpmpc_debug_head_stamps(unsigned long long* host_out) {
 struct RollArgs {
     // pack
     const double* XT; const double* beta; const double* lam; const double* sf;
-    int N, Np, ds, da, D;
+    int Np, ds, da, D;            // (padded size only: no rollout kernel may depend on the unpadded N, see gpmpc_pack_resize)
     // problem
     const double* x0; const double* U; int B, H;
     // state trajectory (outputs or workspace): [B][H+1][ds]
@@ -1131,6 +1132,50 @@ extern "C" size_t gpmpc_rollout_workspace_bytes(const gpmpc_pack* p, int B, int 
     return need;
 }
 
+// What a rollout call of this shape launches, as text (bench.py names the dominant kernel with it, the tests check which form a
+// shape reaches, tools/ compare plans): "form=<...> kernel=<...> tiling=<rows>x<cols> workgroups=<per step> launches_per_step=<n> split=<S> ..."
+extern "C" int gpmpc_plan_describe(const gpmpc_pack* p, int B, int H, unsigned flags, char* out, size_t out_bytes) {
+    if (!p || !out || out_bytes < 64 || B < 1 || H < 1) return GPMPC_E_ARG;
+    const bool grad = (flags & GPMPC_WANT_GRAD) != 0, lowprec = (flags & (GPMPC_FP32_ACCUM | GPMPC_FP32_ALL)) != 0;
+    RollPlan r;
+    plan_rollout(p, B, H, grad, true, &r, lowprec);
+    const int S = split_count(p, r, B, lowprec, (flags & GPMPC_USE_GRAPH) == 0);
+    static const int cfg[7][2] = {{256, 256}, {64, 64}, {256, 64}, {64, 128}, {256, 128}, {256, 32}, {256, 16}};
+    const int D = p->D, ds = p->ds;
+    char kern[160];
+    const char* form;
+    long wgs;
+    if (r.fused == 2) {
+        const int q = r.tiling == 2 ? 0 : cfg[r.tiling][1], ng = r.shared ? r.fng : 1;
+        const gpmpc_worklist& wsh = p->wl_sh[(r.fng == 2 && p->sh_ng != 2) ? 3 : 1];
+        form = r.shared ? "fused_sb_shared" : "fused_sb";
+        snprintf(kern, sizeof(kern), "k_step_fused<%d,%d,%s,%d,%d>", D, ds, grad ? "true" : "false", q, ng);
+        wgs = (long)B * ((r.shared ? wsh.nwork : r.nwork) + 2 * ds);
+    } else if (r.fused == 1) {
+        form = "fused_staged";
+        snprintf(kern, sizeof(kern), "k_step_fused<%d,%d,%s,%d,1>", D, ds, grad ? "true" : "false", r.fq);
+        wgs = (long)B * (r.nwork * r.fq + 2 * ds);
+    } else if (lowprec) {
+        form = "lowprec"; snprintf(kern, sizeof(kern), "k_pair_lowprec<%d>", D); wgs = (long)B * r.nwork;
+    } else if (r.shared) {
+        form = "head+pair_sbs";
+        snprintf(kern, sizeof(kern), "gpmpc_pair_kernel_sbs<%d,%d,%d,%s,false>", D, p->sh_ng, ds, grad ? "true" : "false");
+        wgs = (long)B * p->wl_sh[r.sh_list].nwork;
+    } else if (r.sb) {
+        form = "head+pair_sb";
+        snprintf(kern, sizeof(kern), "gpmpc_pair_kernel_sb<%d,%d,%d,%s,false,%d>", D, r.tb, ds, grad ? "true" : "false", r.colunroll == 4 ? 4 : 1);
+        wgs = (long)((B + r.tb - 1) / r.tb) * r.nwork;
+    } else {
+        form = "head+pair_staged";
+        snprintf(kern, sizeof(kern), "gpmpc_pair_kernel<%d,true,%s,%d>", D, grad ? "true" : "false", r.tb);
+        wgs = (long)((B + r.tb - 1) / r.tb) * r.nwork;
+    }
+    const int tl = r.shared && r.fused != 2 ? (r.sh_list == 0 ? 0 : (r.sh_list == 1 ? 2 : 4)) : r.tiling;
+    snprintf(out, out_bytes, "form=%s kernel=%s tiling=%dx%d workgroups=%ld launches_per_step=%d split=%d tb=%d shared=%d hchunks=%d workspace=%zu",
+             form, kern, cfg[tl][0], cfg[tl][1], wgs, r.fused ? 1 : 2, S, r.tb, r.shared, r.hchunks, r.total);
+    return GPMPC_OK;
+}
+
 static int launch_step_fused(int D, bool grad, int ns2, int q, int ng, const FusedArgs& a, int t, hipStream_t s) {
     switch (D) {
         case 1: return gpmpc_launch_step_fused_D<1>(grad, ns2, q, ng, a, t, s);
@@ -1170,7 +1215,7 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
     RollArgs A;
     memset(&A, 0, sizeof(A));
     A.XT = p->XT; A.beta = p->beta; A.lam = p->lam; A.sf = p->sf;
-    A.N = p->N; A.Np = p->Np; A.ds = p->ds; A.da = p->da; A.D = p->D;
+    A.Np = p->Np; A.ds = p->ds; A.da = p->da; A.D = p->D;
     A.x0 = x0; A.U = U; A.B = B; A.H = H;
     A.means = out_means ? out_means : (double*)(ws + r.off_means);
     A.vars = out_vars ? out_vars : (double*)(ws + r.off_vars);
@@ -1201,7 +1246,7 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
         const gpmpc_worklist& wsh = p->wl_sh[(r.fng == 2 && p->sh_ng != 2) ? 3 : 1];      // groups of two GPs | of the pack's group size
         F.XT = p->XT; F.beta = p->beta; F.lam = p->lam; F.sf = p->sf; F.M = p->M; F.work = fsh ? wsh.work_dev : wl.work_dev;
         const int nwg = r.nwork * r.fq;                     // partial sums per trajectory (= tile workgroups, except fsh: ds x tiles)
-        F.N = p->N; F.Np = p->Np; F.nwork = nwg;
+        F.Np = p->Np; F.nwork = nwg;
         F.ntile = fsh ? wsh.nwork : nwg; F.tiles = fsh ? p->sh_tiles[1] : 0;
         F.tri64 = (r.tiling == 1) ? 1 : 0;                  // 64x64 list: items decoded arithmetically (no dependent load)
         for (int a = 0; a <= p->ds; ++a) { F.ustart[a] = fsh ? a * p->sh_tiles[1] : wl.ustart_host[a] * r.fq; A.ust[a] = F.ustart[a]; }
@@ -1307,8 +1352,10 @@ void gpmpc_graph_cache_free(void* c) {
     free(g);
 }
 
-// The pack changed under its captured launch sequences (gpmpc_pack_resize: N is baked into the kernel arguments): drop the
-// instantiated graphs, keep the streams, events and staging buffers.
+// The pack changed under its captured launch sequences -- gpmpc_pack_build found that the "every GP has the same lambda" property
+// flipped, which selects other kernels --: drop the instantiated graphs, keep the streams, events and staging buffers.
+// (gpmpc_pack_resize does NOT come here: no rollout kernel takes the unpadded size N -- RollArgs / FusedArgs carry only the padded
+// Np, structurally --, so replays stay valid on the refilled buffers.)
 void gpmpc_graph_cache_invalidate(void* c) {
     gpmpc_graph_cache* g = (gpmpc_graph_cache*)c;
     if (!g) return;
@@ -1325,7 +1372,21 @@ extern "C" long long gpmpc_pack_graph_captures(const gpmpc_pack* p) {
     return g ? g->captures : 0;
 }
 
-// The pack's private streams / events (graph replay and split launches), created on first use.
+// Per-pack host lock (gpmpc_pack::lock, created with the pack).  It serialises, per pack, everything that touches the pack's OWN
+// streams, events and caches: the lazy creation of graph_cache / cb_cache, a stream capture from hipStreamBeginCapture to
+// hipStreamEndCapture (the auxiliary streams are in capture state meanwhile: a plain split launch of another host thread on them
+// would be recorded into that capture instead of executing), the fork / join of a split launch, and the solver-callback entry.
+// Calls that use only the caller's stream and workspace (unsplit plain launches) do not take it.
+void* gpmpc_lock_create() { return new (std::nothrow) std::recursive_mutex(); }
+void gpmpc_lock_destroy(void* l) { delete (std::recursive_mutex*)l; }
+struct PackGuard {
+    std::recursive_mutex* m;
+    explicit PackGuard(const gpmpc_pack* p) : m((std::recursive_mutex*)p->lock) { if (m) m->lock(); }
+    ~PackGuard() { if (m) m->unlock(); }
+    PackGuard(const PackGuard&) = delete; PackGuard& operator=(const PackGuard&) = delete;
+};
+
+// The pack's private streams / events (graph replay and split launches), created on first use (under the pack's lock).
 static int ensure_graph_cache(gpmpc_pack* p, gpmpc_graph_cache** out) {
     gpmpc_graph_cache* g = (gpmpc_graph_cache*)p->graph_cache;
     if (!g) {
@@ -1348,12 +1409,10 @@ static int ensure_graph_cache(gpmpc_pack* p, gpmpc_graph_cache** out) {
 
 // One rollout call as S sub-batches: sub-batch 0 on `origin`, the others on the pack's auxiliary streams, forked from and
 // joined back into `origin` with events (inside a stream capture these become parallel branches of the graph).  The
-// fork / join pairs of one pack are serialised (two host threads sharing a pack must not interleave them).
-static std::mutex g_split_mu;
+// caller holds the pack's lock (PackGuard): two host threads sharing a pack must not interleave their fork / join pairs.
 static int enqueue_split(gpmpc_pack* p, gpmpc_graph_cache* g, int S, const RollPlan& whole, hipStream_t origin, int B, int H,
                          const double* x0, const double* U, const gpmpc_cost_params* cost, unsigned flags, double* out_means,
                          double* out_vars, double* out_cost, double* out_grad, void* workspace) {
-    std::lock_guard<std::mutex> lk(g_split_mu);
     const bool grad = (flags & GPMPC_WANT_GRAD) != 0;
     int rc = GPMPC_OK;
     hipError_t ef = hipEventRecord(g->ev_fork, origin);
@@ -1396,6 +1455,7 @@ static int enqueue_split(gpmpc_pack* p, gpmpc_graph_cache* g, int S, const RollP
 static int graph_rollout(gpmpc_pack* p, int B, int H, const double* x0, const double* U, const gpmpc_cost_params* cost,
                          unsigned flags, double* out_means, double* out_vars, double* out_cost, double* out_grad,
                          void* workspace, size_t workspace_bytes, hipStream_t user) {
+    PackGuard lock(p);                                      // cache creation, capture (begin ... end) and replay: one host thread at a time
     gpmpc_graph_cache* g = nullptr;
     if (int rcg = ensure_graph_cache(p, &g)) return rcg;
     gpmpc_graph_key k;
@@ -1488,6 +1548,7 @@ extern "C" int gpmpc_objective_gradient(gpmpc_pack* p, int H, const double* x0_h
     if (!p || !x0_host || !U_host || !cost || !out_host || H < 1) return GPMPC_E_ARG;
     if (!p->built) return GPMPC_E_STATE;
     if (int rc_dev = gpmpc_check_device(p)) return rc_dev;
+    PackGuard lock(p);                                      // the entry owns per-pack staging buffers and is synchronous: one caller at a time
     // per-kernel events cannot be recorded inside a captured graph: with timing on the same work is enqueued uncaptured
     const bool eager = timing_on();
     flags &= GPMPC_WANT_GRAD;
@@ -1523,6 +1584,20 @@ extern "C" int gpmpc_objective_gradient(gpmpc_pack* p, int H, const double* x0_h
         if (ea != hipSuccess) { gpmpc_set_error("gpmpc_objective_gradient: staging allocation", ea); return GPMPC_E_ALLOC; }   // cap_H stays 0: retried next call
         g->cap_H = H;
     }
+    {   // the pack may have been refilled under a plan that needs more scratch (e.g. lambdas no longer shared: G rows per GP);
+        // checked on EVERY call -- a plan is a few hundred host instructions -- so that neither the captured nor the timed
+        // (uncaptured) path ever runs with a stale size
+        const size_t need = gpmpc_rollout_workspace_bytes(p, 1, H, GPMPC_WANT_GRAD);
+        if (need > g->ws_bytes) {
+            (void)hipStreamSynchronize(g->stream);
+            if (g->exec) { (void)hipGraphExecDestroy(g->exec); g->exec = nullptr; }
+            g->valid = 0;
+            if (g->ws) (void)hipFree(g->ws);
+            g->ws = nullptr; g->ws_bytes = 0;
+            if (hipError_t ea = hipMalloc(&g->ws, need); ea != hipSuccess) { gpmpc_set_error("gpmpc_objective_gradient: workspace", ea); g->cap_H = 0; return GPMPC_E_ALLOC; }
+            g->ws_bytes = need;
+        }
+    }
     if (eager) {                                          // timing on: upload, the H + 1 launches, download -- uncaptured
         memcpy(g->h_in, x0_host, sizeof(double) * p->ds);
         memcpy(g->h_in + p->ds, U_host, sizeof(double) * (size_t)H * p->da);
@@ -1541,14 +1616,6 @@ extern "C" int gpmpc_objective_gradient(gpmpc_pack* p, int H, const double* x0_h
         (void)hipStreamSynchronize(g->stream);
         if (g->exec) { (void)hipGraphExecDestroy(g->exec); g->exec = nullptr; }
         g->valid = 0;
-        // the pack may have been refilled under a plan that needs more scratch (e.g. lambdas no longer shared: G rows per GP)
-        const size_t need = gpmpc_rollout_workspace_bytes(p, 1, H, GPMPC_WANT_GRAD);
-        if (need > g->ws_bytes) {
-            if (g->ws) (void)hipFree(g->ws);
-            g->ws = nullptr; g->ws_bytes = 0;
-            if (hipError_t ea = hipMalloc(&g->ws, need); ea != hipSuccess) { gpmpc_set_error("gpmpc_objective_gradient: workspace", ea); g->cap_H = 0; return GPMPC_E_ALLOC; }
-            g->ws_bytes = need;
-        }
         hipGraph_t graph = nullptr;
         GPMPC_HIP(hipStreamBeginCapture(g->stream, hipStreamCaptureModeThreadLocal));
         hipError_t e1 = hipMemcpyAsync(g->d_in, g->h_in, sizeof(double) * nin, hipMemcpyHostToDevice, g->stream);
@@ -1595,6 +1662,7 @@ extern "C" int gpmpc_rollout(const gpmpc_pack* p, int B, int H, const double* x0
         plan_rollout(p, B, H, grad, true, &whole, false);
         const int S = split_count(p, whole, B, false, true);
         if (S > 1 && split_bytes(p, whole, B, H, grad, S) <= workspace_bytes) {
+            PackGuard lock(p);                              // the pack's auxiliary streams / events (shared with graph_rollout's captures)
             gpmpc_graph_cache* g = nullptr;
             if (int rcg = ensure_graph_cache(const_cast<gpmpc_pack*>(p), &g)) return rcg;
             return enqueue_split(const_cast<gpmpc_pack*>(p), g, S, whole, (hipStream_t)stream, B, H, x0, U, cost, flags, out_means,

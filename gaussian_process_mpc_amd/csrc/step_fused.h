@@ -73,6 +73,24 @@ static __device__ unsigned long long g_fused_wg[2 * 8192];         // [start | e
 #define GPMPC_FUSED_UNROLL 2
 #endif
 #define GPMPC_FUSED_PZ 4        // Z0 partials of one GP prefetched per thread: covers 256 * 4 workgroups per GP
+#ifndef GPMPC_FUSED_PZ_SB
+#define GPMPC_FUSED_PZ_SB 6     // ... of the 256-row forms: 384 per GP in the first round trip (N = 2048 on 256x32 tiles has 288), the rest 4 at a time
+#endif
+#ifndef GPMPC_FUSED_PIPE_ILP
+#define GPMPC_FUSED_PIPE_ILP 2      // columns whose dependency chains the scheduler may interleave (4 held ~20 more registers: spills at the 96 of 5 waves)
+#endif
+#ifndef GPMPC_FUSED_MEAN_UNROLL
+#define GPMPC_FUSED_MEAN_UNROLL 2   // points per round trip of the mean-sum workgroups of the 256-row forms
+#endif
+#ifndef GPMPC_FUSED_PIPE
+// 256-row forms (Q = 0 / 32 / 16, one GP per tile workgroup): the weight stream M_ij is software-pipelined -- the first group of
+// columns is requested in phase 0, behind every load the prologue waits for (vector-memory results return in order, so the prologue's
+// counted waits do not include it), and group g + 1 is requested before group g is evaluated.  One or a few trajectories of a large
+// training set stream M from HBM / Infinity Cache with a handful of waves per SIMD: a wave that issues its loads, waits, and only then
+// evaluates has nothing in flight half of the time (N = 2048, B = 1: 3.2 TB/s of the 67 MB per step; N = 4096, ds = 6: 3.3 TB/s).
+// Same sums in the same order: results are bit-identical to the unpipelined loop.  0 restores it (A/B).
+#define GPMPC_FUSED_PIPE 1
+#endif
 
 // Q = 0: the MID-SIZE form (round 3).  The tile workgroups take 256 x 64 tiles (work list 2) and run the SCALAR-BROADCAST column
 // loop of pair_kernel_sb.h (four columns in flight, table exp) instead of the staged one: a batch of B = 4...32 trajectories of
@@ -181,7 +199,8 @@ void k_step_fused(FusedArgs A, int t) {
         spp_v = A.sp[(((size_t)pprev * A.B + b) * DS + am) * A.sps + 3 + (lane < 4 * D ? lane : 4 * D - 1)];
     // Z0 partials of step t-1: wave a % 4 fetches those of GP a, GPMPC_FUSED_PZ per lane up front (covers 256 workgroups
     // per GP, i.e. every configuration with column pieces; more are looped over in phase 1)
-    double pzr[(DS + 3) / 4][GPMPC_FUSED_PZ];
+    constexpr int PZ = SB ? GPMPC_FUSED_PZ_SB : GPMPC_FUSED_PZ;
+    double pzr[(DS + 3) / 4][PZ];
     const double* pz = A.partz + ((size_t)pprev * A.B + b) * A.nwork;
     if (t > 1) {
 #pragma unroll
@@ -189,7 +208,7 @@ void k_step_fused(FusedArgs A, int t) {
             const int a = w + 4 * g;                                // wave-uniform
             if (a < DS) {
 #pragma unroll
-                for (int r = 0; r < GPMPC_FUSED_PZ; ++r) {
+                for (int r = 0; r < PZ; ++r) {
                     const int wi = ust[a < DS ? a : 0] + lane + r * 64;
                     const int we = ust[a < DS ? a + 1 : 1];
                     const double v = pz[wi < we ? wi : ust[a < DS ? a : 0]];           // clamped: always a valid address
@@ -236,6 +255,22 @@ void k_step_fused(FusedArgs A, int t) {
 #pragma unroll
         for (int r = 0; r < TABN; ++r) tabreg[r] = gpmpc_exp2_table[tid + r * NT];   // LDS write deferred: see below
     }
+    // 256-row forms: the first group of weight columns of this wave, requested LAST in phase 0 (see GPMPC_FUSED_PIPE above)
+    constexpr bool PIPE = SB && !SH && GPMPC_FUSED_PIPE;
+    constexpr int MG = 4;                                           // columns per group (two groups in flight)
+    double mga[PIPE ? MG : 1];
+    const int iw0_t = i0 + 64 * w;
+    const bool wave_on = role == 0 && iw0_t < Np && j0 >= iw0_t;    // tiles left of the wave's diagonal block carry no weight (wave-uniform)
+    __amdgpu_buffer_rsrc_t Mrs_t = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double*>(A.M + (size_t)unit * Np * Np + (size_t)j0 * Np + (wave_on ? iw0_t : 0)), 0, 0x7fffffff, 0x00020000);
+    if constexpr (PIPE) {
+        if (wave_on) {
+#pragma unroll
+            for (int q = 0; q < MG; ++q)
+                mga[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs_t, lane * 8, q * Np * 8, 0));
+        }
+        __builtin_amdgcn_sched_barrier(0);                          // ... and not moved in front of the loads above
+    }
     // mean sums: this thread's first points (the loop below loads the ones beyond)
     constexpr int PF = SB ? 1 : 2;                                  // (mid-size form: registers; N >= 1024 loops anyway)
     double xpt[PF][D], bpt[PF], sf_a = 0.0;
@@ -262,8 +297,16 @@ void k_step_fused(FusedArgs A, int t) {
             if (a < DS) {                                           // wave-uniform: wave a % 4 owns GP a's Z0 sum, fixed order
                 double s = 0.0;
 #pragma unroll
-                for (int r = 0; r < GPMPC_FUSED_PZ; ++r) s += pzr[g][r];
-                for (int wi = ust[a < DS ? a : 0] + lane + GPMPC_FUSED_PZ * 64; wi < ust[a < DS ? a + 1 : 1]; wi += 64) s += pz[wi];
+                for (int r = 0; r < PZ; ++r) s += pzr[g][r];
+                // beyond the prefetched ones (N = 4096 on 256x64 tiles: 544 per GP): four loads per round trip, added in index order
+                const int u0 = ust[a < DS ? a : 0], u1 = ust[a < DS ? a + 1 : 1];
+                for (int wb = u0 + PZ * 64; wb < u1; wb += 4 * 64) {
+                    double e[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const int wi = wb + lane + r * 64; const double v = pz[wi < u1 ? wi : u0]; e[r] = wi < u1 ? v : 0.0; }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s += e[r];
+                }
                 s = wave_sum(s);
                 if (lane == 0) s_zw[a] = s;
             }
@@ -441,9 +484,51 @@ void k_step_fused(FusedArgs A, int t) {
             // constant-address-space loads below (scalar loads) cannot be moved in front of the stores and the barrier
             const double* Gl = Gs;
             asm volatile("" : "+s"(Gl) :: "memory");
-            const __amdgpu_buffer_rsrc_t Mrs = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<double*>(A.M + (size_t)unit * Np * Np + (size_t)j0 * Np + iw0), 0, 0x7fffffff, 0x00020000);
+            const __amdgpu_buffer_rsrc_t Mrs = Mrs_t;
             const int lane8 = lane * 8;
+            typedef const double __attribute__((address_space(4))) gpmpc_cdouble;
+            // one column: exponent from the wave-uniform row G[j] (scalar loads), table exp, weight, moments (pair_kernel_sb.h)
+            auto column = [&](int j, double mij) {
+                const gpmpc_cdouble* __restrict__ g = (const gpmpc_cdouble*)(Gl + (size_t)j * GW);
+                double sx = qi + g[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k) sx = fma(hi2[k], g[k], sx);
+                const double P = mij * gpmpc_exp_neg_scaled(sx, s_tab);
+                acc[0] += P;
+                if (GRAD) {
+#pragma unroll
+                    for (int k = 0; k < D; ++k) acc[GRAD ? 1 + k : 0] = fma(P, g[k], acc[GRAD ? 1 + k : 0]);
+#pragma unroll
+                    for (int k = 0; k < NS2; ++k) acc[GRAD ? 1 + D + k : 0] = fma(P, g[D + 1 + k], acc[GRAD ? 1 + D + k : 0]);
+                }
+            };
+            if constexpr (PIPE) {
+                static_assert(NC % (2 * MG) == 0, "two groups of columns per iteration");
+                constexpr int PAIRW = GPMPC_FUSED_PIPE_ILP;
+                double mgb[MG];
+                for (int jc = 0; jc < NC; jc += 2 * MG) {
+#pragma unroll
+                    for (int q = 0; q < MG; ++q)                         // group jc + MG: in flight while group jc is evaluated
+                        mgb[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, (jc + MG + q) * Np * 8, 0));
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < MG; ++q) {
+                        column(jc + q, mga[q]);
+                        if (q % PAIRW == PAIRW - 1) __builtin_amdgcn_sched_barrier(0);      // PAIRW columns' dependency chains interleaved at a time
+                    }
+                    if (jc + 2 * MG < NC) {
+#pragma unroll
+                        for (int q = 0; q < MG; ++q)
+                            mga[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, (jc + 2 * MG + q) * Np * 8, 0));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < MG; ++q) {
+                        column(jc + MG + q, mgb[q]);
+                        if (q % PAIRW == PAIRW - 1) __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else {
             constexpr int CU = 4;
             for (int jc = 0; jc < NC; jc += CU) {
                 double mij[CU];
@@ -452,21 +537,8 @@ void k_step_fused(FusedArgs A, int t) {
                     mij[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, (jc + q) * Np * 8, 0));
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int q = 0; q < CU; ++q) {
-                    typedef const double __attribute__((address_space(4))) gpmpc_cdouble;
-                    const gpmpc_cdouble* __restrict__ g = (const gpmpc_cdouble*)(Gl + (size_t)(jc + q) * GW);
-                    double sx = qi + g[D];
-#pragma unroll
-                    for (int k = 0; k < D; ++k) sx = fma(hi2[k], g[k], sx);
-                    const double P = mij[q] * gpmpc_exp_neg_scaled(sx, s_tab);
-                    acc[0] += P;
-                    if (GRAD) {
-#pragma unroll
-                        for (int k = 0; k < D; ++k) acc[GRAD ? 1 + k : 0] = fma(P, g[k], acc[GRAD ? 1 + k : 0]);
-#pragma unroll
-                        for (int k = 0; k < NS2; ++k) acc[GRAD ? 1 + D + k : 0] = fma(P, g[D + 1 + k], acc[GRAD ? 1 + D + k : 0]);
-                    }
-                }
+                for (int q = 0; q < CU; ++q) column(jc + q, mij[q]);
+            }
             }
         }
         GPMPC_STAMP(5);
@@ -662,14 +734,30 @@ void k_step_fused(FusedArgs A, int t) {
 #pragma unroll
         for (int k = 0; k < D; ++k) { v[1 + k] = fma(p, d[k], v[1 + k]); v[1 + D + k] = fma(p * d[k], d[k], v[1 + D + k]); }
     }
-    for (int i = tid + PF * NT; i < Np; i += NT) {
-        double d[D], q = 0.0;
+    // the points beyond: UN per round trip (all loads first; a large training set otherwise walks Np / 256 dependent round trips while
+    // the tile workgroups stream -- N = 2048: this workgroup lived as long as a tile workgroup, profiles/r03/fused_wg_timeline.txt).
+    // Points past the end get zero weight: the same sums in the same order as one point at a time.
+    constexpr int UN = SB ? GPMPC_FUSED_MEAN_UNROLL : 1;
+    for (int ib = tid + PF * NT; ib < Np; ib += UN * NT) {
+        double xq[UN][D], bq[UN];
 #pragma unroll
-        for (int k = 0; k < D; ++k) { d[k] = u[k] - A.XT[(size_t)k * Np + i]; q = fma(Bk[k] * d[k], d[k], q); }
-        const double p = A.beta[(size_t)a * Np + i] * exp(-0.5 * q);
-        v[0] += p;
+        for (int r = 0; r < UN; ++r) {
+            const int i = ib + r * NT, ic = i < Np ? i : 0;
 #pragma unroll
-        for (int k = 0; k < D; ++k) { v[1 + k] = fma(p, d[k], v[1 + k]); v[1 + D + k] = fma(p * d[k], d[k], v[1 + D + k]); }
+            for (int k = 0; k < D; ++k) xq[r][k] = A.XT[(size_t)k * Np + ic];
+            const double bv = A.beta[(size_t)a * Np + ic];
+            bq[r] = i < Np ? bv : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < UN; ++r) {
+            double d[D], q = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) { d[k] = u[k] - xq[r][k]; q = fma(Bk[k] * d[k], d[k], q); }
+            const double p = bq[r] * exp(-0.5 * q);
+            v[0] += p;
+#pragma unroll
+            for (int k = 0; k < D; ++k) { v[1 + k] = fma(p, d[k], v[1 + k]); v[1 + D + k] = fma(p * d[k], d[k], v[1 + D + k]); }
+        }
     }
     GPMPC_STAMP(5);
     block_sum4_rows<NV>(v, s_red, s_out);

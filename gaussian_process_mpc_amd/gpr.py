@@ -46,6 +46,8 @@ class GaussianProcessRegression(object):
         # squares the residual, and a step is two N x N GEMMs (a handful of launches instead of the LU's few hundred): the refresh
         # costs 0.1-0.2 ms on the step it falls on.  Falls back to the rebuild when the residual is not safely contractive.
         self.refresh = "rebuild"
+        self.newton_accept = 1e-8   # measured Frobenius residual |I - Ky X| above which a Newton-Schulz refresh is discarded for a rebuild
+        self.newton_residual_last = None
         # "lu": torch.linalg.inv, the reference's own call (src/gpr.py:171) and the default, so that Ky_inv carries the
         # reference's round-off.  "cholesky": potrf + potri (SURVEY 8 f1 as sketched): a third of the flops and a symmetric
         # result, but NOT the reference's numerics -- the variances move by ~1e-5 relative at sigma_n = 1e-5.
@@ -214,6 +216,15 @@ class GaussianProcessRegression(object):
             r = r * r
             if r > 1e-13 and steps < max_steps:
                 R = eye - self.Ky @ X
+        # the loop runs on the PREDICTED residual (r, r^2, r^4, ...): measure the final one once -- an iteration that stalled in
+        # round-off (cond(Ky) ~ 1e7 and beyond) must not be accepted and the refresh counter reset on a prediction
+        if steps:
+            r_final = float(torch.linalg.matrix_norm(eye - self.Ky @ X).item())
+            self.newton_residual_last = r_final
+            if not (r_final < self.newton_accept):
+                self.build_Ky_inv_mat()
+                self.newton_steps_last = -1
+                return
         self.Ky_inv = X
         self._beta = None
         self.version += 1
@@ -334,10 +345,12 @@ class GaussianProcessRegression(object):
         factorisation of the (k, n, n) stack instead of k in a Python loop."""
         leaders = {}
         for g, mode in zip(gps, modes):
-            leaders.setdefault((g._current_hypers(), g.inverse, mode, g.num_train), []).append(g)
-        full = [grp[0] for (_, _, mode, _), grp in leaders.items() if mode == "full"]
-        for (_, _, mode, _), grp in leaders.items():
-            if mode == "incremental":
+            # followers take over the leader's matrices AND its refresh state (_adopt): a group must agree on the refresh policy too
+            leaders.setdefault((g._current_hypers(), g.inverse, mode, g.num_train, g.refresh, bool(g.async_rebuild), g.rebuild_every,
+                                g._appends_since_rebuild), []).append(g)
+        full = [grp[0] for key, grp in leaders.items() if key[2] == "full"]
+        for key, grp in leaders.items():
+            if key[2] == "incremental":
                 grp[0]._append_one_incremental(grp[0].X_train[-1:])
         by_kind = {}
         for g in full:

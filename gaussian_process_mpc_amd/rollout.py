@@ -147,6 +147,18 @@ class GPPack:
         self._ws = {}
         return self
 
+    def plan(self, B, H, want_grad=True, graph=False):
+        """What a rollout call of this shape launches (C ABI ``gpmpc_plan_describe``): dict with ``form``, ``kernel``, ``tiling``,
+        ``workgroups`` (per horizon step), ``launches_per_step``, ``split`` ..."""
+        buf = ctypes.create_string_buffer(512)
+        flags = (_lib.WANT_GRAD if want_grad else 0) | (_lib.USE_GRAPH if graph else 0)
+        check(lib().gpmpc_plan_describe(self._h, int(B), int(H), flags, buf, 512), "gpmpc_plan_describe")
+        out = {}
+        for kv in buf.value.decode().split():
+            k, v = kv.split("=", 1)
+            out[k] = int(v) if v.lstrip("-").isdigit() else v
+        return out
+
     @property
     def shared_lambda(self):
         """True when every GP of the pack has bit-identical length-scales (the shared-lambda pair kernel applies)."""

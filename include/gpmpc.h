@@ -207,6 +207,12 @@ int gpmpc_cost_grad(int B, int H, int state_dim, int action_dim, const gpmpc_cos
  * workgroups per horizon step) are one kernel launch per horizon step; larger ones two (head + pair kernel).
  * ------------------------------------------------------------------------- */
 size_t gpmpc_rollout_workspace_bytes(const gpmpc_pack* pack, int B, int H, unsigned flags);
+/* Diagnostic (no reference counterpart): what a rollout call of this shape launches, as one line of text --
+ * "form=<fused_staged|fused_sb|fused_sb_shared|head+pair_sb|head+pair_sbs|head+pair_staged|lowprec> kernel=<dominant kernel instance>
+ *  tiling=<rows>x<cols> workgroups=<per horizon step> launches_per_step=<1|2> split=<concurrent sub-batches> ..." --
+ * with GPMPC_USE_GRAPH in `flags` for the split a graph replay would use.  bench.py names its dominant kernel with it, the
+ * parity tests check which kernel form a shape reaches.  out_bytes >= 64; returns 0 or GPMPC_E_ARG. */
+int gpmpc_plan_describe(const gpmpc_pack* pack, int B, int H, unsigned flags, char* out, size_t out_bytes);
 int gpmpc_rollout(const gpmpc_pack* pack, int B, int H, const double* x0_dev, const double* U_dev,
                   const gpmpc_cost_params* cost_host, unsigned flags,
                   double* out_means, double* out_vars, double* out_cost, double* out_grad,
