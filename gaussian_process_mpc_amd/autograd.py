@@ -105,5 +105,27 @@ class MomentMatchFunction(torch.autograd.Function):
         return gu, gS, None
 
 
+class CrossCovFunction(torch.autograd.Function):
+    """(u (nq, D), S (nq, D, D)) -> q (nq,) = Cov[f_0, f_1] + mu_0 mu_1 = beta_0^T Qt beta_1 of a two-GP pack: the part of
+    covariance_prop_torch (src/tools/uncertainty_prop.py:402-465) that does not go through the caller's mean1 / mean2 (the caller
+    subtracts their product, so autograd treats them exactly as the reference's graph does).  Either cross-term form."""
+
+    @staticmethod
+    def forward(ctx, u, S, pack, bug_compatible):
+        r = moment_match(pack, _c(u), _c(S), want_cov=True, want_grad=True, bug_compatible=bug_compatible)
+        m0, m1 = r["mean"][:, 0], r["mean"][:, 1]
+        # d q = d cov + mu_1 d mu_0 + mu_0 d mu_1
+        dq_du = r["dcov_du"][:, 0, 1] + m1[:, None] * r["dmean_du"][:, 0] + m0[:, None] * r["dmean_du"][:, 1]
+        dq_dS = r["dcov_dS"][:, 0, 1] + m1[:, None, None] * r["dmean_dS"][:, 0] + m0[:, None, None] * r["dmean_dS"][:, 1]
+        ctx.save_for_backward(dq_du, dq_dS)
+        return r["cov"][:, 0, 1] + m0 * m1
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        dq_du, dq_dS = ctx.saved_tensors
+        return g[:, None] * dq_du, g[:, None, None] * dq_dS, None, None
+
+
 def wants_grad(*tensors):
     return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)

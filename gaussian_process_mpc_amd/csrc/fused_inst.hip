@@ -6,8 +6,8 @@
 #endif
 template int gpmpc_launch_step_fused_D<GPMPC_PAIR_D>(bool, int, int, int, const FusedArgs&, int, hipStream_t);
 
-#if defined(GPMPC_FUSED_STAMPS) && GPMPC_PAIR_D == 4
-// diagnostic build: the stamps of the D = 4 instances of this translation unit
+#if defined(GPMPC_FUSED_STAMPS) && GPMPC_PAIR_D == GPMPC_STAMP_D
+// diagnostic build: the stamps of the D = GPMPC_STAMP_D (default 4) instances of this translation unit
 extern "C" int gpmpc_debug_wg_times(unsigned long long* host_out) {      // [2][8192]
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_fused_wg), sizeof(unsigned long long) * 2 * 8192) == hipSuccess ? 0 : -3;
 }

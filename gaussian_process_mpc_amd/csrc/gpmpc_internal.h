@@ -47,6 +47,7 @@ struct gpmpc_tuning {
     int fused_sb;    // GPMPC_FUSED_SB    one launch per horizon step for mid-size batches (step_fused.h, Q = 0): 0 off | 1 on | -1 unset
     int split;       // GPMPC_SPLIT       sub-batches (parallel graph branches) of a graph-replayed rollout: 1 none | 2..4 | -1 unset (2 for mid-size batches)
     int shared;      // GPMPC_SHARED      0: never use the shared-lambda kernel (pair_kernel_sbs.h) | -1 unset (used when lambdas are shared)
+    int persist;     // GPMPC_PERSIST     whole-horizon kernel, one workgroup per trajectory (traj_persist.h): 0 off | 8 / 16 on with that many waves | -1 unset
 };
 void gpmpc_read_tuning(gpmpc_tuning* t);
 
@@ -177,6 +178,17 @@ struct FusedArgs {
     int tiles;                             // one lambda for all GPs: tiles per GP (partial sums are laid out [GP][tile], nwork = ds * tiles)
 };
 template <int D> int gpmpc_launch_step_fused_D(bool grad, int ns2, int q, int ng, const FusedArgs& a, int t, hipStream_t s);
+
+// Arguments of the trajectory-persistent whole-horizon kernel (traj_persist.h; instantiated per D in persist_d*.o)
+struct PersistArgs {
+    const double* XT; const double* beta; const double* lam; const double* sf; const double* M;
+    int Np;
+    const double* x0; const double* U; int B, H;
+    double* means; double* vars; double* jac;      // [B][H+1][ds] x2, [B][H][2ds][2ds+da] (jac may be null: objective only)
+    double* gscr;                                  // [B][ds][Np][GW] column rows, one slot per workgroup
+    int total;                                     // columns of the flattened (GP, row block, column) space: ds * 64 * T (T + 1) / 2
+};
+template <int D> int gpmpc_launch_persist_D(bool grad, int ns2, int waves, const PersistArgs& a, hipStream_t s);
 
 
 // Implemented in pair_d*.hip (one translation unit per D so the build parallelises).

@@ -385,12 +385,21 @@ __global__ __launch_bounds__(256) void k_mom_finish(MomArgs A) {
 // GPMPC_COV_BUG_COMPAT reproduces the reference's cross term z2_i^T Am z1_j (:446).
 // One workgroup per (query, ordered GP pair a<b): lane = i, j broadcast from LDS in chunks.
 // ---------------------------------------------------------------------------
-template <int D>
+// GRAD: also d Cov / d u and d Cov / d S (A.dcov_du [nq][ds][ds][D], A.dcov_dS [nq][ds][ds][D][D]; needs A.dmean_du / A.dmean_dS of
+// this call), the derivatives autograd takes of the reference's expression (:402-465) -- in either mode: with
+//   E_ij = 1/2 d_i^T P1 d_i + 1/2 d_j^T P2 d_j + d_i^T C d_j,  d = x - u,  P1 = -La^-1 + La^-1 Am La^-1,  P2 likewise with Lb,
+//   C = Lpc Am Lrc  (Lpc, Lrc = La^-1, Lb^-1; swapped in the bug-compatible form),   W0 = sum_ij beta_a,i beta_b,j e^E_ij,
+//   dW0/du = -(P1 m_i + P2 m_j + C m_j + C^T m_i),           m_i = sum w d_i,  m_j = sum w d_j
+//   dW0/dS = R^-T sym(G) R^-1 (symmetrised),                  G = sum w (1/2 p p^T + 1/2 r r^T + pc rc^T),  dAm = R^-1 dS R^-T
+//   K = sfa^2 sfb^2 det(R)^-1/2,  dK/dS = -1/2 K sym(L R^-1),  L = La^-1 + Lb^-1;      Cov = K W0 - mu_a mu_b.
+// The moments are grouped by row (lane = i): per lane r = sum_j e, v = sum_j e r_j, W = sum_j e r_j r_j^T in the column loop.
+template <int D, bool GRAD = false>
 __global__ __launch_bounds__(256) void k_cross_cov(MomArgs A, const int* __restrict__ pairs, int npairs) {
-    __shared__ double s_u[D], s_S[D * D], s_Am[D * D];
+    constexpr int NS = D * (D + 1) / 2, NV = GRAD ? 1 + 2 * D + NS : 1;
+    __shared__ double s_u[D], s_S[D * D], s_Am[D * D], s_Ri[D * D];
     __shared__ double s_det;
-    __shared__ __attribute__((aligned(16))) double s_j[64 * (D + 2)];
-    __shared__ double s_scr[16], s_out[1];
+    __shared__ __attribute__((aligned(16))) double s_j[64 * (2 * D + 2)];
+    __shared__ double s_scr[16 * NV], s_out[NV];
     const int q = blockIdx.x / npairs, pr = blockIdx.x - q * npairs;
     const int a = pairs[2 * pr], b = pairs[2 * pr + 1];
     const bool bug = (A.flags & GPMPC_COV_BUG_COMPAT) != 0;
@@ -403,6 +412,7 @@ __global__ __launch_bounds__(256) void k_cross_cov(MomArgs A, const int* __restr
         for (int r = 0; r < D; ++r) for (int c = 0; c < D; ++c) R[r * D + c] = s_S[r * D + c] * (1.0 / la[c] + 1.0 / lb[c]) + (r == c ? 1.0 : 0.0);
         s_det = small_inverse(D, R, Ri);
         for (int r = 0; r < D; ++r) for (int c = 0; c < D; ++c) { double s = 0.0; for (int l = 0; l < D; ++l) s += Ri[r * D + l] * s_S[l * D + c]; s_Am[r * D + c] = s; }
+        if (GRAD) for (int e = 0; e < D * D; ++e) s_Ri[e] = Ri[e];
     }
     __syncthreads();
     double Am[D * D], u[D], ila[D], ilb[D];
@@ -412,6 +422,14 @@ __global__ __launch_bounds__(256) void k_cross_cov(MomArgs A, const int* __restr
     for (int k = 0; k < D; ++k) { u[k] = s_u[k]; ila[k] = 1.0 / la[k]; ilb[k] = 1.0 / lb[k]; }
 
     double total = 0.0;
+    double gm1[GRAD ? D : 1], gm2[GRAD ? D : 1], gG[GRAD ? NS : 1];       // sum w d_i | sum w r2_j | sym part of G (upper triangle)
+    if (GRAD) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) { gm1[k] = 0.0; gm2[k] = 0.0; }
+#pragma unroll
+        for (int e = 0; e < NS; ++e) gG[e] = 0.0;
+    }
+    constexpr int SJ = GRAD ? 2 * D + 2 : D + 2;                           // doubles per staged column
     for (int i0 = 0; i0 < A.Np; i0 += blockDim.x) {
         const int i = i0 + threadIdx.x;
         // i side
@@ -431,6 +449,13 @@ __global__ __launch_bounds__(256) void k_cross_cov(MomArgs A, const int* __restr
         }
         const double bi = i < A.Np ? A.beta[(size_t)a * A.Np + i] : 0.0;
         double rowsum = 0.0;
+        double rv[GRAD ? D : 1], rW[GRAD ? NS : 1];
+        if (GRAD) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) rv[k] = 0.0;
+#pragma unroll
+            for (int e = 0; e < NS; ++e) rW[e] = 0.0;
+        }
         for (int jc = 0; jc < A.Np; jc += 64) {
             __syncthreads();
             if (threadIdx.x < 64) {
@@ -444,30 +469,107 @@ __global__ __launch_bounds__(256) void k_cross_cov(MomArgs A, const int* __restr
 #pragma unroll
                     for (int l = 0; l < D; ++l) s = fma(Am[k * D + l], r2[l], s);
                     gam = fma(0.5 * r2[k], s, gam);
-                    s_j[threadIdx.x * (D + 2) + k] = rc[k];
+                    s_j[threadIdx.x * SJ + k] = rc[k];
+                    if (GRAD) s_j[threadIdx.x * SJ + D + 2 + k] = r2[k];
                 }
-                s_j[threadIdx.x * (D + 2) + D] = gam;
-                s_j[threadIdx.x * (D + 2) + D + 1] = A.beta[(size_t)b * A.Np + j];
+                s_j[threadIdx.x * SJ + D] = gam;
+                s_j[threadIdx.x * SJ + D + 1] = A.beta[(size_t)b * A.Np + j];
             }
             __syncthreads();
             for (int jj = 0; jj < 64; ++jj) {
-                const double* sj = &s_j[jj * (D + 2)];
+                const double* sj = &s_j[jj * SJ];
                 double arg = alpha + sj[D];
 #pragma unroll
                 for (int k = 0; k < D; ++k) arg = fma(w[k], sj[k], arg);
-                rowsum = fma(sj[D + 1], exp(arg), rowsum);
+                const double e = sj[D + 1] * exp(arg);
+                rowsum += e;
+                if (GRAD) {
+                    int o = 0;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) {
+                        const double er = e * sj[D + 2 + k];
+                        rv[k] += er;
+#pragma unroll
+                        for (int l = k; l < D; ++l) { rW[o] = fma(er, sj[D + 2 + l], rW[o]); ++o; }
+                    }
+                }
             }
         }
-        if (i < A.Np) total = fma(bi, rowsum, total);
+        if (i < A.Np) {
+            total = fma(bi, rowsum, total);
+            if (GRAD) {
+                // rc_j = (Lrc Lb) r2_j elementwise: sum_j e rc_j follows from rv
+                int o = 0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    gm1[k] = fma(bi * rowsum, d[k], gm1[k]);
+                    gm2[k] = fma(bi, rv[k], gm2[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < D; ++k)
+#pragma unroll
+                    for (int l = k; l < D; ++l) {
+                        const double vck = bug ? ila[k] / ilb[k] * rv[k] : rv[k], vcl = bug ? ila[l] / ilb[l] * rv[l] : rv[l];
+                        const double g = 0.5 * rowsum * p1[k] * p1[l] + 0.5 * rW[o] + 0.5 * (pc[k] * vcl + pc[l] * vck);
+                        gG[o] = fma(bi, g, gG[o]);
+                        ++o;
+                    }
+            }
+        }
     }
-    double v[1] = {total};
-    block_sum<1>(v, s_scr, s_out);
+    double v[NV];
+    v[0] = total;
+    if (GRAD) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) { v[1 + k] = gm1[k]; v[1 + D + k] = gm2[k]; }
+#pragma unroll
+        for (int e = 0; e < NS; ++e) v[1 + 2 * D + e] = gG[e];
+    }
+    block_sum<NV>(v, s_scr, s_out);
     if (threadIdx.x == 0) {
         const double sfa = A.sf[a], sfb = A.sf[b];
         const double mua = A.out_mean[(size_t)q * A.ds + a], mub = A.out_mean[(size_t)q * A.ds + b];
-        const double cov = sfa * sfa * sfb * sfb / sqrt(s_det) * s_out[0] - mua * mub;
+        const double K = sfa * sfa * sfb * sfb / sqrt(s_det);
+        const double cov = K * s_out[0] - mua * mub;
         A.out_cov[((size_t)q * A.ds + a) * A.ds + b] = cov;
         if (!bug) A.out_cov[((size_t)q * A.ds + b) * A.ds + a] = cov;
+        if (GRAD) {
+            const int ds = A.ds;
+            double mi[D], mj[D], G[D * D], T1[D * D];
+            for (int k = 0; k < D; ++k) { mi[k] = s_out[1 + k]; mj[k] = s_out[1 + D + k] / ilb[k]; }      // sum w d_i | sum w d_j (d_j = Lb r2_j)
+            { int o = 0; for (int k = 0; k < D; ++k) for (int l = k; l < D; ++l) { G[k * D + l] = s_out[1 + 2 * D + o]; G[l * D + k] = s_out[1 + 2 * D + o]; ++o; } }
+            const double* dma_u = A.dmean_du + ((size_t)q * ds + a) * D; const double* dmb_u = A.dmean_du + ((size_t)q * ds + b) * D;
+            const double* dma_S = A.dmean_dS + ((size_t)q * ds + a) * D * D; const double* dmb_S = A.dmean_dS + ((size_t)q * ds + b) * D * D;
+            // d/du
+            for (int k = 0; k < D; ++k) {
+                double s1 = 0.0;                                          // (P1 m_i + P2 m_j + C m_j + C^T m_i)_k
+                for (int l = 0; l < D; ++l) {
+                    const double am = Am[k * D + l];
+                    const double P1 = ila[k] * am * ila[l] - (k == l ? ila[k] : 0.0), P2 = ilb[k] * am * ilb[l] - (k == l ? ilb[k] : 0.0);
+                    const double lpk = bug ? ilb[k] : ila[k], lrl = bug ? ila[l] : ilb[l];      // C_kl = Lpc_k Am_kl Lrc_l
+                    const double lpl = bug ? ilb[l] : ila[l], lrk = bug ? ila[k] : ilb[k];      // (C^T)_kl = C_lk = Lpc_l Am_lk Lrc_k
+                    s1 += P1 * mi[l] + P2 * mj[l] + lpk * am * lrl * mj[l] + lpl * Am[l * D + k] * lrk * mi[l];
+                }
+                const double dc = -K * s1 - dma_u[k] * mub - mua * dmb_u[k];
+                A.dcov_du[(((size_t)q * ds + a) * ds + b) * D + k] = dc;
+                if (!bug) A.dcov_du[(((size_t)q * ds + b) * ds + a) * D + k] = dc;
+            }
+            // d/dS: K R^-T G R^-1 - 1/2 K W0 sym(L R^-1), symmetrised, minus the mean terms
+            for (int m = 0; m < D; ++m) for (int l = 0; l < D; ++l) { double s2 = 0.0; for (int k = 0; k < D; ++k) s2 += s_Ri[k * D + m] * G[k * D + l]; T1[m * D + l] = s2; }
+            for (int m = 0; m < D; ++m)
+                for (int n = m; n < D; ++n) {
+                    double g1 = 0.0, g2 = 0.0;
+                    for (int l = 0; l < D; ++l) { g1 += T1[m * D + l] * s_Ri[l * D + n]; g2 += T1[n * D + l] * s_Ri[l * D + m]; }
+                    const double lm = ila[m] + ilb[m], ln = ila[n] + ilb[n];
+                    const double dK = -0.25 * K * (ln * s_Ri[n * D + m] + lm * s_Ri[m * D + n]);            // sym(-1/2 K L R^-1)
+                    const double base = 0.5 * K * (g1 + g2) + dK * s_out[0];
+                    const double d_mn = base - dma_S[m * D + n] * mub - mua * dmb_S[m * D + n];
+                    const double d_nm = base - dma_S[n * D + m] * mub - mua * dmb_S[n * D + m];
+                    double* o1 = A.dcov_dS + (((size_t)q * ds + a) * ds + b) * D * D;
+                    o1[m * D + n] = d_mn; o1[n * D + m] = d_nm;
+                    if (!bug) { double* o2 = A.dcov_dS + (((size_t)q * ds + b) * ds + a) * D * D; o2[m * D + n] = d_mn; o2[n * D + m] = d_nm; }
+                }
+        }
     }
 }
 
@@ -545,7 +647,8 @@ static int run_mom(const gpmpc_pack* p, MomArgs& A, const MomPlan& r, bool grad,
                 h[2 * n] = a; h[2 * n + 1] = b; ++n;
             }
         if (int rcu = gpmpc_upload_small(pairs_dev, h, sizeof(int) * 2 * n, s)) return rcu;      // (h is on this stack frame)
-        hipLaunchKernelGGL(k_cross_cov<D>, dim3(A.nq * n), dim3(256), 0, s, A, pairs_dev, n);
+        if (A.dcov_du) hipLaunchKernelGGL((k_cross_cov<D, true>), dim3(A.nq * n), dim3(256), 0, s, A, pairs_dev, n);
+        else hipLaunchKernelGGL((k_cross_cov<D, false>), dim3(A.nq * n), dim3(256), 0, s, A, pairs_dev, n);
     }
     GPMPC_HIP(hipGetLastError());
     return GPMPC_OK;
@@ -565,7 +668,7 @@ int gpmpc_moment_match_ex(const gpmpc_pack* p, int nq, const double* u, const do
     if ((dcov_du == nullptr) != (dcov_dS == nullptr)) return GPMPC_E_ARG;
     // cross-covariances through the pair kernel (with Jacobians) need the cross weight matrices of the pack
     const bool pair_cov = out_cov && !bug && p->fullcov && p->npairs > 0;
-    if (dcov_du && (!grad || !out_cov || bug || (p->npairs > 0 && !p->fullcov))) return GPMPC_E_STATE;
+    if (dcov_du && (!grad || !out_cov)) return GPMPC_E_STATE;       // (bug-compatible form / no cross weights: the direct kernel k_cross_cov<D, true>)
     if (ns2 < 1 || ns2 > p->D) return GPMPC_E_ARG;
     MomPlan r;
     plan_mom(p, nq, grad, pair_cov, ns2, &r);

@@ -218,6 +218,7 @@ void gpmpc_read_tuning(gpmpc_tuning* t) {
     t->colunroll = geti("GPMPC_SB_UNROLL", -1);
     t->split = geti("GPMPC_SPLIT", -1);
     t->fused_sb = geti("GPMPC_FUSED_SB", -1);
+    t->persist = geti("GPMPC_PERSIST", -1);
 }
 
 extern "C" int gpmpc_pack_reload_tuning(gpmpc_pack* p) {

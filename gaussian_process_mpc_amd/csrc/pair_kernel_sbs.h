@@ -99,13 +99,37 @@ void gpmpc_pair_kernel_sbs(PairSbsArgs A) {
 #define GPMPC_SBS_CU 1       /* columns per loop iteration (A/B knob; 1 measured best, see profiles/r03/ab_shared_columns.txt) */
 #endif
         constexpr int CU = GPMPC_SBS_CU;
+#ifndef GPMPC_SBS_PREFETCH
+#define GPMPC_SBS_PREFETCH 0     /* 1: the NG weights of column jc + 1 are requested before column jc is evaluated (register double buffer, 124 instead of
+                                    114 VGPRs, still 4 waves per SIMD).  Measured -2...-4 % (C3 sizes with one lambda, B = 256: 26.5 -> 27.4 ms per batch;
+                                    N = 1024, B = 256: 7.31 -> 7.60 ms; profiles/r04/ab_shared_prefetch.txt): A/B build only */
+#endif
+        constexpr bool PRE = GPMPC_SBS_PREFETCH && CU == 1;
+        double mnext[NG];
+        if (PRE) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) mnext[g] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs[g], lane8, 0, 0));
+        }
         for (int jc = jstart; jc < j1; jc += CU) {
             double mij[CU][NG];
+            if (PRE) {
+                // this kernel runs 3-4 waves per SIMD (NG x (1 + D + ds) accumulators): a wave that issues its NG loads, waits for
+                // them and only then evaluates the column leaves its SIMD to 2-3 others for a whole L2 round trip -- VALU-busy 0.81
+                // against 0.88-0.95 of the distinct-lambda kernels (profiles/r03/pmc_C3_shared.json).  One column ahead costs 2 NG
+                // registers.  The last iteration re-requests its own column (in bounds, unused).
+                const int jn = jc + 1 < j1 ? jc + 1 : jc;
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    mij[0][g] = mnext[g];
+                    mnext[g] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs[g], lane8, (jn - jstart) * Np * 8, 0));
+                }
+            } else {
 #pragma unroll
             for (int c = 0; c < CU; ++c)
 #pragma unroll
                 for (int g = 0; g < NG; ++g)
                     mij[c][g] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs[g], lane8, (jc - jstart + c) * Np * 8, 0));
+            }
             __builtin_amdgcn_sched_barrier(0);            // loads stay at the top of the iteration (pair_kernel_sb.h)
 #pragma unroll
             for (int c = 0; c < CU; ++c) {

@@ -60,6 +60,8 @@ struct RollArgs {
     // then also forms mu and its derivatives; sp carries c_m and B_k instead (layout below).  hchunks <= 1: as before.
     int hchunks, hrows;
     double* mpart;
+    int finished;      // every horizon step (H included) is already finished -- means, variances, Jacobians written -- by the whole-horizon
+                       // kernel (traj_persist.h): the tail kernel goes straight to the cost terms
     // outputs of the tail
     double* out_cost; double* out_grad;
     gpmpc_cost_params cost;
@@ -661,7 +663,7 @@ __global__ __launch_bounds__(256) void k_roll_tail(RollArgs A) {
     const int b = blockIdx.x, ds = A.ds, da = A.da, H = A.H, tid = threadIdx.x;
     const int nz = 2 * ds, nc = 2 * ds + da;
     __shared__ double s_ms[GPMPC_MAX_DS * (1 + 2 * GPMPC_MAX_D) + 4 * GPMPC_MAX_DS];      // mean sums | Z0 wave sums
-    finish_step(A, b, H, -1, s_z, s_zred, s_mu, s_var, s_ms);
+    if (!A.finished) finish_step(A, b, H, -1, s_z, s_zred, s_mu, s_var, s_ms);
     double* s_ct = s_dyn;
     double* s_dl = s_ct + (H + 1);
     double* s_gU = s_dl + (size_t)(H + 1) * nz;
@@ -875,7 +877,8 @@ int gpmpc_timed_pair_sbf(int D, bool grad, int ns2, int waves, const PairSbfArgs
     return timed_launch(GPMPC_TIME_FULL, s, [&] { return gpmpc_launch_pair_sbf(D, grad, ns2, waves, a, s); });
 }
 
-struct RollPlan { int tiling, tb, waves, nwork, nm, pps, sps, sb, gw, rgroup, fused, fq, hchunks, hrows, shared, sh_list, colunroll /* columns per iteration of the sb kernel */, fng /* GPs per tile workgroup of the one-launch form with one lambda */; size_t off_mpart; size_t off_G; size_t off_pp, off_sp, off_part, off_partz, off_jac, off_means, off_vars, total; };
+#define GPMPC_PERSIST_MAXNP_HOST 1024
+struct RollPlan { int tiling, tb, waves, nwork, nm, pps, sps, sb, gw, rgroup, fused, fq, hchunks, hrows, shared, sh_list, colunroll /* columns per iteration of the sb kernel */, fng /* GPs per tile workgroup of the one-launch form with one lambda */, pwaves /* waves per workgroup of the whole-horizon kernel (fused = 3) */; size_t off_mpart; size_t off_G; size_t off_pp, off_sp, off_part, off_partz, off_jac, off_means, off_vars, total; };
 
 // shape (optional): take every SHAPE decision (tiling, kernel, trajectories per wave, row chunks ...) from this plan of a larger
 // batch and only size the buffers for B: the sub-batches of a split call then run exactly the launches the whole batch would,
@@ -1039,6 +1042,16 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
         r->rgroup = shape->rgroup; r->fused = shape->fused; r->fq = shape->fq; r->shared = shape->shared; r->sh_list = shape->sh_list; r->fng = shape->fng;
         r->colunroll = shape->colunroll;
     }
+    // Whole-horizon kernel, one workgroup per trajectory (traj_persist.h): large batches of a small training set -- at least about one
+    // trajectory per CU, X within the kernel's LDS budget.  r->fused = 3; r->pwaves = waves per workgroup.
+    r->pwaves = 0;
+    if (diag && !lowprec && p->da >= 1 && p->da <= 2 && p->Np <= GPMPC_PERSIST_MAXNP_HOST && H * p->da <= 1024 && tn.persist != 0 &&
+        (tn.persist > 0 || (B >= (3 * p->num_cu) / 4 && p->Np <= 640))) {
+        r->fused = 3; r->sb = 0; r->shared = 0; r->tb = 1; r->rgroup = 1; r->colunroll = 1; r->fq = 1;
+        r->pwaves = tn.persist == 8 ? 8 : 16;
+        r->nwork = 0;
+    }
+    if (shape) { r->fused = shape->fused; r->pwaves = shape->pwaves; if (r->fused == 3) { r->sb = 0; r->shared = 0; r->nwork = 0; } }
     r->nm = gpmpc_num_moments(D, diag, grad);
     r->pps = D + D * D;
     r->sps = sps_of(D);
@@ -1063,7 +1076,7 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     r->off_jac = take(grad ? (size_t)B * H * 2 * p->ds * (2 * p->ds + p->da) : 0);
     r->gw = gpmpc_sb_gw(D, p->ds);
     // column rows: [B][GP][Np][gw] written by the head kernel, or one [64][gw] slot per tile workgroup of the mid-size fused form
-    r->off_G = take(r->fused == 2 ? (size_t)B * (r->shared ? p->wl_sh[(r->fng == 2 && p->sh_ng != 2) ? 3 : 1].nwork : r->nwork) * p->wl[0][r->tiling].jt * r->gw
+    r->off_G = take(r->fused == 3 ? (size_t)B * p->ds * p->Np * r->gw : r->fused == 2 ? (size_t)B * (r->shared ? p->wl_sh[(r->fng == 2 && p->sh_ng != 2) ? 3 : 1].nwork : r->nwork) * p->wl[0][r->tiling].jt * r->gw
                                   : (r->sb ? (size_t)B * (r->shared ? 1 : p->ds) * p->Np * r->gw : 0));
     r->off_means = take((size_t)B * (H + 1) * p->ds);
     r->off_vars = take((size_t)B * (H + 1) * p->ds);
@@ -1145,7 +1158,11 @@ extern "C" int gpmpc_plan_describe(const gpmpc_pack* p, int B, int H, unsigned f
     char kern[160];
     const char* form;
     long wgs;
-    if (r.fused == 2) {
+    if (r.fused == 3) {
+        form = "persist";
+        snprintf(kern, sizeof(kern), "k_traj_persist<%d,%d,%s>x%dwaves", D, ds, grad ? "true" : "false", r.pwaves);
+        wgs = B;
+    } else if (r.fused == 2) {
         const int q = r.tiling == 2 ? 0 : cfg[r.tiling][1], ng = r.shared ? r.fng : 1;
         const gpmpc_worklist& wsh = p->wl_sh[(r.fng == 2 && p->sh_ng != 2) ? 3 : 1];
         form = r.shared ? "fused_sb_shared" : "fused_sb";
@@ -1172,8 +1189,21 @@ extern "C" int gpmpc_plan_describe(const gpmpc_pack* p, int B, int H, unsigned f
     }
     const int tl = r.shared && r.fused != 2 ? (r.sh_list == 0 ? 0 : (r.sh_list == 1 ? 2 : 4)) : r.tiling;
     snprintf(out, out_bytes, "form=%s kernel=%s tiling=%dx%d workgroups=%ld launches_per_step=%d split=%d tb=%d shared=%d hchunks=%d workspace=%zu",
-             form, kern, cfg[tl][0], cfg[tl][1], wgs, r.fused ? 1 : 2, S, r.tb, r.shared, r.hchunks, r.total);
+             form, kern, cfg[tl][0], cfg[tl][1], wgs, r.fused == 3 ? 0 : (r.fused ? 1 : 2), S, r.tb, r.shared, r.hchunks, r.total);
     return GPMPC_OK;
+}
+
+static int launch_persist(int D, bool grad, int ns2, int waves, const PersistArgs& a, hipStream_t s) {
+    switch (D) {
+        case 2: return gpmpc_launch_persist_D<2>(grad, ns2, waves, a, s);
+        case 3: return gpmpc_launch_persist_D<3>(grad, ns2, waves, a, s);
+        case 4: return gpmpc_launch_persist_D<4>(grad, ns2, waves, a, s);
+        case 5: return gpmpc_launch_persist_D<5>(grad, ns2, waves, a, s);
+        case 6: return gpmpc_launch_persist_D<6>(grad, ns2, waves, a, s);
+        case 7: return gpmpc_launch_persist_D<7>(grad, ns2, waves, a, s);
+        case 8: return gpmpc_launch_persist_D<8>(grad, ns2, waves, a, s);
+    }
+    return GPMPC_E_ARG;
 }
 
 static int launch_step_fused(int D, bool grad, int ns2, int q, int ng, const FusedArgs& a, int t, hipStream_t s) {
@@ -1238,6 +1268,19 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
     P.Np = p->Np; P.B = B; P.nunits = p->ds; P.nwork = r.nwork; P.pps = r.pps; P.nm = r.nm;
     P.jside_off = 0; P.ntri = p->ds; P.ns2 = p->ds; P.colsplit = (r.tiling == 1 || r.tiling == 3) ? 1 : 0;
 
+    if (r.fused == 3) {
+        PersistArgs Q;
+        memset(&Q, 0, sizeof(Q));
+        Q.XT = p->XT; Q.beta = p->beta; Q.lam = p->lam; Q.sf = p->sf; Q.M = p->M; Q.Np = p->Np;
+        Q.x0 = x0; Q.U = U; Q.B = B; Q.H = H;
+        Q.means = A.means; Q.vars = A.vars; Q.jac = A.jac;
+        Q.gscr = (double*)(ws + r.off_G);
+        const int T = p->Np / 64;
+        Q.total = p->ds * 32 * T * (T + 1);
+        const int rc = timed_launch(GPMPC_TIME_FUSED, s, [&] { return launch_persist(p->D, grad, p->ds, r.pwaves, Q, s); });
+        if (rc != GPMPC_OK) return rc;
+        A.finished = 1;
+    } else
     if (r.fused) {
         FusedArgs F;
         memset(&F, 0, sizeof(F));

@@ -47,6 +47,9 @@ __device__ __forceinline__ void gpmpc_tri_decode(int q, int T, int* r_out, int* 
 // Diagnostic build only (-DGPMPC_FUSED_STAMPS): s_memtime stamps of the phases of one tile workgroup and of the mean-sum
 // workgroup of GP 0 at horizon step 5, read back with gpmpc_debug_stamps (tools/fused_stamps.py).  The product build
 // executes no stamp.
+#ifndef GPMPC_STAMP_D
+#define GPMPC_STAMP_D 4
+#endif
 #ifdef GPMPC_FUSED_STAMPS
 static __device__ unsigned long long g_fused_stamps[64];
 static __device__ unsigned long long g_fused_wg[2 * 8192];         // [start | end] of every workgroup of trajectory 0 at step 5 (100 MHz counter)
@@ -76,6 +79,9 @@ static __device__ unsigned long long g_fused_wg[2 * 8192];         // [start | e
 #ifndef GPMPC_FUSED_PZ_SB
 #define GPMPC_FUSED_PZ_SB 6     // ... of the 256-row forms: 384 per GP in the first round trip (N = 2048 on 256x32 tiles has 288), the rest 4 at a time
 #endif
+#ifndef GPMPC_FUSED_PIPE_EARLY
+#define GPMPC_FUSED_PIPE_EARLY 1    // first group requested in phase 0 (1) or when the column loop starts (0)
+#endif
 #ifndef GPMPC_FUSED_PIPE_ILP
 #define GPMPC_FUSED_PIPE_ILP 2      // columns whose dependency chains the scheduler may interleave (4 held ~20 more registers: spills at the 96 of 5 waves)
 #endif
@@ -88,8 +94,15 @@ static __device__ unsigned long long g_fused_wg[2 * 8192];         // [start | e
 // counted waits do not include it), and group g + 1 is requested before group g is evaluated.  One or a few trajectories of a large
 // training set stream M from HBM / Infinity Cache with a handful of waves per SIMD: a wave that issues its loads, waits, and only then
 // evaluates has nothing in flight half of the time (N = 2048, B = 1: 3.2 TB/s of the 67 MB per step; N = 4096, ds = 6: 3.3 TB/s).
-// Same sums in the same order: results are bit-identical to the unpipelined loop.  0 restores it (A/B).
-#define GPMPC_FUSED_PIPE 1
+// Same sums in the same order: results are bit-identical to the unpipelined loop.
+// MEASURED (round 4, profiles/r04/ab_fused_pipeline.txt): it LOSES 4-20 % everywhere it applies, with the first group requested in
+// phase 0 or at the loop, two or four columns interleaved -- N = 2048, B = 1: 0.485 -> 0.509 ms per rollout; N = 4096, ds = 6, B = 1:
+// 3.59 -> 3.90 ms; N = 1024, B = 16: 0.98 -> 1.07 ms.  The in-kernel timeline (tools/fused_stamps.py, profiles/r04/fused_stamps_*.txt)
+// says why: at N = 2048, B = 1 the 4.5 waves per SIMD of the single workgroup generation already saturate VALU issue in the column loop
+// (2170 cycles per four columns = 4.5 waves x 4 x 27 instructions x 4.4 cycles), the launch is prologue + loop + reduction in lock-step;
+// at N = 4096, ds = 6 a column costs a wave 834 cycles against 145 of issue because its G row (28 SGPRs) is fetched by scalar loads one
+// column at a time -- the SGPR file holds two of them -- and neither is a matter of weight loads in flight.  Kept as an A/B build (1).
+#define GPMPC_FUSED_PIPE 0
 #endif
 
 // Q = 0: the MID-SIZE form (round 3).  The tile workgroups take 256 x 64 tiles (work list 2) and run the SCALAR-BROADCAST column
@@ -257,13 +270,14 @@ void k_step_fused(FusedArgs A, int t) {
     }
     // 256-row forms: the first group of weight columns of this wave, requested LAST in phase 0 (see GPMPC_FUSED_PIPE above)
     constexpr bool PIPE = SB && !SH && GPMPC_FUSED_PIPE;
+    constexpr bool EARLY = PIPE && GPMPC_FUSED_PIPE_EARLY;
     constexpr int MG = 4;                                           // columns per group (two groups in flight)
     double mga[PIPE ? MG : 1];
     const int iw0_t = i0 + 64 * w;
     const bool wave_on = role == 0 && iw0_t < Np && j0 >= iw0_t;    // tiles left of the wave's diagonal block carry no weight (wave-uniform)
     __amdgpu_buffer_rsrc_t Mrs_t = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<double*>(A.M + (size_t)unit * Np * Np + (size_t)j0 * Np + (wave_on ? iw0_t : 0)), 0, 0x7fffffff, 0x00020000);
-    if constexpr (PIPE) {
+    if constexpr (EARLY) {
         if (wave_on) {
 #pragma unroll
             for (int q = 0; q < MG; ++q)
@@ -503,6 +517,11 @@ void k_step_fused(FusedArgs A, int t) {
                 }
             };
             if constexpr (PIPE) {
+                if constexpr (!EARLY) {
+#pragma unroll
+                    for (int q = 0; q < MG; ++q)
+                        mga[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, q * Np * 8, 0));
+                }
                 static_assert(NC % (2 * MG) == 0, "two groups of columns per iteration");
                 constexpr int PAIRW = GPMPC_FUSED_PIPE_ILP;
                 double mgb[MG];
@@ -516,10 +535,12 @@ void k_step_fused(FusedArgs A, int t) {
                         column(jc + q, mga[q]);
                         if (q % PAIRW == PAIRW - 1) __builtin_amdgcn_sched_barrier(0);      // PAIRW columns' dependency chains interleaved at a time
                     }
-                    if (jc + 2 * MG < NC) {
+                    {   // group jc + 2 MG; UNCONDITIONAL (the last iteration re-requests its own first group, unused): under a
+                        // branch the compiler's wait counts merge both paths and every wait below becomes "all loads done"
+                        const int jn = jc + 2 * MG < NC ? jc + 2 * MG : jc;
 #pragma unroll
                         for (int q = 0; q < MG; ++q)
-                            mga[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, (jc + 2 * MG + q) * Np * 8, 0));
+                            mga[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, (jn + q) * Np * 8, 0));
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

@@ -1,0 +1,376 @@
+// Whole-horizon rollout of ONE trajectory by ONE workgroup: the form for LARGE batches of a SMALL training set (the N = 200...400
+// points the reference's experiments run with, evaluated for hundreds of candidate plans at once: sampling / multi-start MPC).
+//
+// There a horizon step of the batch is a few tens of microseconds of arithmetic, and the step-per-launch forms spend more than that
+// around it: the head kernel in front of every pair launch, the tail of partly filled workgroup generations, the launch boundaries
+// and the round trip of the per-tile partial sums through global memory (N = 300, ds = 4, B = 256: 124 us per step, ~57 us of it pair
+// arithmetic -- profiles/r03/batch_size_map.txt).  Trajectories never depend on each other, so a workgroup can keep
+// one for all H steps: every dependency of the recursion (src/dynamics.py:152-189) is then inside the workgroup and costs a
+// __syncthreads, nothing is handed between workgroups, and a rollout is ONE launch (+ the tail kernel: cost and reverse sweep).
+//
+//   grid = B workgroups x (64 NW) threads, NW = 16 (or 8: two trajectories per CU)
+//   per horizon step t, all inside the workgroup:
+//     1  threads (a, k): the per-GP, per-dimension scalars of the step -- B_k, A_k, the pair transform sc_k, c_m, c
+//        (src/tools/uncertainty_prop.py:329-337, :374-377; closed forms at the top of step.hip)
+//     2  column rows G[a][j] = [h_j | q_j N/ln2 | h_jk^2] of every (GP, point) -> this workgroup's scratch slot in global memory (read
+//        back through SCALAR loads in 4, as step_fused.h does); the O(N) mean sums of every GP (a group of NW / ds waves per GP)
+//     3  the N^2 sum: the (GP, row block, column) space of the upper triangle, flattened, is cut into NW equal contiguous ranges, one
+//        per wave; a wave walks its range with the scalar-broadcast column loop of pair_kernel_sb.h (software-pipelined weight loads),
+//        re-deriving the row side whenever the range enters a new (GP, row block); moments are summed per lane across the row blocks of
+//        a GP and reduced once per GP (a range touches at most two GPs)
+//     4  fixed-order combine of the waves' partial sums; mean, variance and the (2 ds) x (2 ds + da) step Jacobian of every GP
+//        (step.hip::finish_step); the outputs are the next step's input moments
+//   The training inputs X live in LDS for the whole kernel, M (a few MB) is L2 / Infinity-Cache resident across the workgroups.
+// Same expressions as the step-per-launch forms (step.hip, step_fused.h, pair_kernel_sb.h); summation orders differ, results agree to
+// rounding.  Static ranges, partial sums written (not atomically added), fixed-order combines: bit-reproducible run to run.
+#pragma once
+#include "gpmpc_internal.h"
+#include "fast_exp.h"
+
+
+// Diagnostic build (-DGPMPC_PERSIST_STAMPS, D = GPMPC_STAMP_D instances): s_memtime stamps of workgroup 0 at horizon step 3 -- per
+// phase by thread 0, and the column-loop interval of every wave -- read back with gpmpc_debug_persist_stamps (tools/persist_stamps.py).
+#if defined(GPMPC_PERSIST_STAMPS)
+static __device__ unsigned long long g_persist_stamps[64];
+#define GPMPC_PST(slot) do { if (t == 3 && blockIdx.x == 0 && tid == 0) g_persist_stamps[slot] = __builtin_amdgcn_s_memtime(); } while (0)
+#define GPMPC_PSTW(slot) do { if (t == 3 && blockIdx.x == 0 && lane == 0) g_persist_stamps[(slot) + w] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GPMPC_PST(slot) do { } while (0)
+#define GPMPC_PSTW(slot) do { } while (0)
+#endif
+#ifndef GPMPC_PERSIST_ROTPRIO
+#define GPMPC_PERSIST_ROTPRIO 1
+#endif
+#ifndef GPMPC_PERSIST_MAXNP
+#define GPMPC_PERSIST_MAXNP 1024                   // X in LDS: Np * D doubles (57 KB at D = 7)
+#endif
+
+template <int D, int NS2, bool GRAD>
+__global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
+    constexpr int DS = NS2, DA = D - NS2, NM = GRAD ? 1 + 2 * D : 1, NA = GRAD ? 1 + D + NS2 : 1, NV = 1 + 2 * D;
+    constexpr int GW = (D + 1 + NS2 + 1) & ~1;     // doubles per G row, as PairSbTraits
+    constexpr int MG = 4;                          // weight columns per group (two groups in flight)
+    extern __shared__ double s_dyn[];              // X: [D][Np]
+    __shared__ double s_tab[GPMPC_EXP_N];
+    __shared__ double s_part[16 * 2 * 4 * NM];     // [wave][first | second GP of the wave's range][row of 16 lanes][moment]
+    __shared__ double s_mred[16 * 4 * NV];         // mean sums: [wave][row of 16 lanes][value]
+    __shared__ double s_z[DS * NM], s_ms[DS * NV];
+    __shared__ double s_uin[D], s_sin[D];
+    __shared__ double s_B[DS * D], s_Ak[DS * D], s_sc[DS * D], s_cv[DS * D], s_r1[DS * D], s_r2[DS * D];
+    __shared__ double s_c[DS], s_cm[DS], s_sf2[DS];
+    __shared__ int s_rng[17];                      // range boundaries of the waves in the flattened column space
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), NW = nthr >> 6;
+    const int Np = A.Np, T = Np >> 6;
+    const int per_gp = 32 * T * (T + 1);           // columns of one GP: 64 * T (T + 1) / 2
+    double* __restrict__ s_X = s_dyn;
+    double* __restrict__ s_U = s_dyn + (size_t)D * Np;       // the trajectory's actions, [H][da]
+
+    gpmpc_exp_table_to_lds(s_tab);
+    for (int e = tid; e < D * Np; e += nthr) s_X[e] = A.XT[e];
+    for (int e = tid; e < A.H * DA; e += nthr) s_U[e] = A.U[(size_t)b * A.H * DA + e];
+    // boundaries on multiples of 8 columns (row blocks start on multiples of 64); computed once (64-bit divisions)
+    if (tid <= NW) s_rng[tid] = tid == NW ? A.total : (int)(((long)A.total * tid / NW + 4) & ~7L);
+    const double lam_mine = A.lam[tid < DS * D ? tid : 0];
+    if (tid < DS) { s_uin[tid] = A.x0[(size_t)b * DS + tid]; s_sin[tid] = GPMPC_INIT_VAR; }
+    if (tid < DS) {
+        A.means[((size_t)b * (A.H + 1)) * DS + tid] = s_uin[tid];
+        A.vars[((size_t)b * (A.H + 1)) * DS + tid] = GPMPC_INIT_VAR;
+    }
+    // this wave's range of the flattened column space
+    const int r_lo = (int)(((long)A.total * w / NW + 4) & ~7L), r_hi = w == NW - 1 ? A.total : (int)(((long)A.total * (w + 1) / NW + 4) & ~7L);
+    const int gp_first = r_lo < A.total ? r_lo / per_gp : DS;     // the GP the range starts in (slot 0 of s_part; slot 1 = the next)
+    // mean sums: a group of wpg waves per GP
+    const int wpg = NW / DS > 0 ? NW / DS : 1;
+    const int am = w / wpg, tg = (w - am * wpg) * 64 + lane;       // GP of this wave in phase 2, index of the thread within the group
+    double* __restrict__ Gs = A.gscr + (size_t)b * DS * Np * GW;
+    const int lane8 = lane * 8;
+
+    for (int t = 1; t <= A.H; ++t) {
+        GPMPC_PST(0);
+        // ---- 1: input moments of the action dimensions, then the per-(GP, dimension) scalars ------------------------------------
+        if (DA > 0 && tid >= DS && tid < D) { s_uin[tid] = s_U[(t - 1) * DA + (tid - DS)]; s_sin[tid] = GPMPC_ACTION_VAR; }
+        __syncthreads();
+        if (tid < DS * D) {
+            const int a = tid / D, k = tid - a * D;
+            const double lam = lam_mine, sk = s_sin[k], uk = s_uin[k];
+            s_B[tid] = 1.0 / (sk + lam);
+            s_Ak[tid] = 1.0 / (0.5 * lam + sk);
+            const double sc = rsqrt(8.0 * (0.5 * lam + sk));       // the pair transform h = sc (u - x), as step_fused.h
+            s_sc[tid] = sc;
+            s_cv[tid] = sc * uk;
+            s_r1[tid] = sk / lam + 1.0;
+            s_r2[tid] = 2.0 * sk / lam + 1.0;
+        }
+        __syncthreads();
+        GPMPC_PST(1);
+        // ---- 2a: column rows of every (GP, point) -> scratch (stores in flight while the mean sums run) --------------------------
+        for (int e = tid; e < DS * Np; e += nthr) {
+            const int a = e / Np, j = e - a * Np;
+            double g[GW], qh = 0.0;
+#pragma unroll
+            for (int k = 0; k < GW; ++k) g[k] = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const double h = fma(-s_sc[a * D + k], s_X[k * Np + j], s_cv[a * D + k]);
+                g[k] = h;
+                qh = fma(h, h, qh);
+                if (k < NS2) g[D + 1 + k] = h * h;
+            }
+            g[D] = GPMPC_EXP_NEG_INV_C * qh;
+            double2* dst = reinterpret_cast<double2*>(Gs + (size_t)e * GW);
+#pragma unroll
+            for (int k = 0; k < GW / 2; ++k) dst[k] = make_double2(g[2 * k], g[2 * k + 1]);
+        }
+        GPMPC_PST(2);
+        // ---- 2b: mean sums of GP am over the N points (step.hip::prep_step) -------------------------------------------------------
+        {
+            double v[NV];
+#pragma unroll
+            for (int m = 0; m < NV; ++m) v[m] = 0.0;
+            if (am < DS) {
+                double u[D], Bk[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k) { u[k] = s_uin[k]; Bk[k] = s_B[am * D + k]; }
+                for (int i = tg; i < Np; i += 64 * wpg) {
+                    double d[D], q = 0.0;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) { d[k] = u[k] - s_X[k * Np + i]; q = fma(Bk[k] * d[k], d[k], q); }
+                    const double p = A.beta[(size_t)am * Np + i] * exp(-0.5 * q);
+                    v[0] += p;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) { v[1 + k] = fma(p, d[k], v[1 + k]); v[1 + D + k] = fma(p * d[k], d[k], v[1 + D + k]); }
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < NV; ++m) {
+                const double sr = wave_row_sum(v[m]);
+                if ((lane & 15) == 0) s_mred[(w * 4 + (lane >> 4)) * NV + m] = sr;
+            }
+        }
+        GPMPC_PST(3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's G rows are in L2
+        GPMPC_PST(4);
+        __syncthreads();
+        GPMPC_PST(5);
+        __builtin_amdgcn_s_dcache_inv();                           // the scalar cache may hold the previous step's rows
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (tid < DS * NV) {                                       // combine the mean sums: waves of the GP's group, rows in fixed order
+            const int a = tid / NV, m = tid - a * NV;
+            double sum = 0.0;
+            for (int ww = a * wpg; ww < (a + 1) * wpg; ++ww) {
+                const double* r4 = &s_mred[ww * 4 * NV + m];
+                sum += (r4[0] + r4[NV]) + (r4[2 * NV] + r4[3 * NV]);
+            }
+            s_ms[tid] = sum;
+        }
+        GPMPC_PST(6);
+        GPMPC_PSTW(16);
+        // ---- 3: this wave's range of the N^2 sum ------------------------------------------------------------------------------
+        {
+            double zsum[NM];
+#pragma unroll
+            for (int m = 0; m < NM; ++m) zsum[m] = 0.0;
+            int pos = r_lo, slot = 0, a_cur = gp_first;
+            const double* Gl = Gs;
+            asm volatile("" : "+s"(Gl) :: "memory");               // rows written a moment ago: keep the scalar loads behind the barrier
+            typedef const double __attribute__((address_space(4))) gpmpc_cdouble;
+            auto flush = [&](int sl) {                              // reduce the lane sums of one GP, rows of 16 lanes
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    const double sr = wave_row_sum(zsum[m]);
+                    if ((lane & 15) == 0) s_part[((w * 2 + sl) * 4 + (lane >> 4)) * NM + m] = sr;
+                    zsum[m] = 0.0;
+                }
+            };
+            while (pos < r_hi) {
+                const int a = pos / per_gp, rem = pos - a * per_gp;
+                if (a != a_cur) { flush(slot); slot = 1; a_cur = a; }
+                // row block r: the largest r with start(r) = 64 (r T - r (r - 1) / 2) <= rem
+                int r = 0;
+                while (r + 1 < T && 64 * ((r + 1) * T - (r + 1) * r / 2) <= rem) ++r;
+                const int bstart = 64 * (r * T - r * (r - 1) / 2);
+                const int j0 = 64 * r + (rem - bstart);            // first column of the segment
+                const int blen = Np - 64 * r;                      // columns of the row block
+                int n = bstart + blen - rem;                       // ... left in it
+                if (n > r_hi - pos) n = r_hi - pos;
+                const int i0 = 64 * r;
+                const __amdgpu_buffer_rsrc_t Mrs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<double*>(A.M + ((size_t)a * Np + j0) * Np + i0), 0, 0x7fffffff, 0x00020000);
+                double mga[MG], mgb[MG];
+#pragma unroll
+                for (int q = 0; q < MG; ++q) mga[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, q * Np * 8, 0));
+                double hi2[D], qi;
+                {
+                    double q = 0.0;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) {
+                        const double h = fma(-s_sc[a * D + k], s_X[k * Np + i0 + lane], s_cv[a * D + k]);
+                        hi2[k] = (2.0 * GPMPC_EXP_NEG_INV_C) * h;
+                        q = fma(h, h, q);
+                    }
+                    qi = GPMPC_EXP_NEG_INV_C * q;
+                }
+                double acc[NA];
+#pragma unroll
+                for (int m = 0; m < NA; ++m) acc[m] = 0.0;
+                const double* Ga = Gl + ((size_t)a * Np + j0) * GW;
+                auto column = [&](int j, double mij) {
+                    const gpmpc_cdouble* __restrict__ g = (const gpmpc_cdouble*)(Ga + (size_t)j * GW);
+                    double sx = qi + g[D];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) sx = fma(hi2[k], g[k], sx);
+                    const double P = mij * gpmpc_exp_neg_scaled(sx, s_tab);
+                    acc[0] += P;
+                    if (GRAD) {
+#pragma unroll
+                        for (int k = 0; k < D; ++k) acc[GRAD ? 1 + k : 0] = fma(P, g[k], acc[GRAD ? 1 + k : 0]);
+#pragma unroll
+                        for (int k = 0; k < NS2; ++k) acc[GRAD ? 1 + D + k : 0] = fma(P, g[D + 1 + k], acc[GRAD ? 1 + D + k : 0]);
+                    }
+                };
+                for (int jc = 0; jc < n; jc += 2 * MG) {           // n is a multiple of 8
+#if GPMPC_PERSIST_ROTPRIO
+                    // The four waves a SIMD holds of this workgroup are arbitrated by age: left alone the oldest runs ahead and the
+                    // youngest finishes 40 % later, the SIMD half empty at the end (stamps: wave 2 109 k cycles, wave 15 165 k for
+                    // equal ranges).  Rotating the issue priority every few iterations lets them advance together.
+                    switch (((jc >> 5) + (w >> 2)) & 3) {
+                        case 0: __builtin_amdgcn_s_setprio(0); break;
+                        case 1: __builtin_amdgcn_s_setprio(1); break;
+                        case 2: __builtin_amdgcn_s_setprio(2); break;
+                        default: __builtin_amdgcn_s_setprio(3); break;
+                    }
+#endif
+#pragma unroll
+                    for (int q = 0; q < MG; ++q)
+                        mgb[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, (jc + MG + q) * Np * 8, 0));
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < MG; ++q) { column(jc + q, mga[q]); if (q & 1) __builtin_amdgcn_sched_barrier(0); }
+                    {   // unconditional (the last iteration re-requests its own first group, unused): under a branch the compiler's
+                        // wait counts merge both paths and every wait below becomes "all loads done"
+                        const int jn = jc + 2 * MG < n ? jc + 2 * MG : jc;
+#pragma unroll
+                        for (int q = 0; q < MG; ++q)
+                            mga[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, (jn + q) * Np * 8, 0));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < MG; ++q) { column(jc + MG + q, mgb[q]); if (q & 1) __builtin_amdgcn_sched_barrier(0); }
+                }
+                // per-lane combination into the m-moments of this row block (pair_kernel_sb.h), summed over the row blocks of the GP
+                {
+                    const double rs = acc[0];
+                    zsum[0] += rs;
+                    if (GRAD) {
+#pragma unroll
+                        for (int k = 0; k < D; ++k) {
+                            const double h = (0.5 / GPMPC_EXP_NEG_INV_C) * hi2[k], v = acc[GRAD ? 1 + k : 0];
+                            zsum[GRAD ? 1 + k : 0] += fma(h, rs, v);
+                            if (k < NS2) zsum[GRAD ? 1 + D + k : 0] += fma(h * h, rs, fma(2.0 * h, v, acc[GRAD ? 1 + D + (k < NS2 ? k : 0) : 0]));
+                        }
+                    }
+                }
+                pos += n;
+            }
+            GPMPC_PSTW(32);
+#if GPMPC_PERSIST_ROTPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
+            if (r_lo < r_hi) flush(slot);
+            GPMPC_PSTW(48);
+        }
+        GPMPC_PST(7);
+        __syncthreads();
+        GPMPC_PST(8);
+        // ---- 4: combine, outputs and Jacobian rows of step t, input moments of step t + 1 ------------------------------------
+        if (tid >= 64 && tid < 64 + DS) {                          // c_m, c of the step (wave 1, beside the combine of wave 0)
+            const int a = tid - 64;
+            double detm = 1.0, detv = 1.0;
+            for (int l = 0; l < D; ++l) { detm *= s_r1[a * D + l]; detv *= s_r2[a * D + l]; }
+            const double sf = A.sf[a], sf2 = sf * sf;
+            s_sf2[a] = sf2; s_cm[a] = sf2 / sqrt(detm); s_c[a] = 1.0 / sqrt(detv);
+        }
+        if (tid < DS * NM) {
+            const int a = tid / NM, m = tid - a * NM;
+            double sum = 0.0;
+            for (int ww = 0; ww < NW; ++ww) {                      // fixed order: waves, their (at most two) GPs, rows as (0 + 1) + (2 + 3)
+                const int lo = s_rng[ww], hi = s_rng[ww + 1];
+                if (lo >= hi) continue;
+                const int a0 = lo / per_gp, a1 = (hi - 1) / per_gp;
+                if (a < a0 || a > a1) continue;
+                const double* r4 = &s_part[((ww * 2 + (a - a0)) * 4) * NM + m];
+                sum += (r4[0] + r4[NM]) + (r4[2 * NM] + r4[3 * NM]);
+            }
+            s_z[tid] = sum;
+        }
+        __syncthreads();
+        if (tid < DS * D) {
+            const int a = tid / D, k = tid - a * D, nc = 2 * DS + DA;
+            const double c = s_c[a], cm = s_cm[a], sf2 = s_sf2[a];
+            const double mu = cm * s_ms[a * NV];
+            const double Tt = c * s_z[a * NM];
+            const double var = sf2 - Tt - mu * mu;                 // no clamp (src/tools/uncertainty_prop.py:399)
+            if (k == 0) {
+                A.means[((size_t)b * (A.H + 1) + t) * DS + a] = mu;
+                A.vars[((size_t)b * (A.H + 1) + t) * DS + a] = var;
+            }
+            if (GRAD) {
+                const double Bq = s_B[tid], Ak = s_Ak[tid], sc = s_sc[tid];
+                const double dmu_du = -Bq * cm * s_ms[a * NV + 1 + k];
+                const double dmu_ds = -0.5 * mu * Bq + 0.5 * Bq * Bq * cm * s_ms[a * NV + 1 + D + k];
+                const double dT_du = -4.0 * sc * c * s_z[a * NM + (GRAD ? 1 + k : 0)];
+                const double dv_du = -dT_du - 2.0 * mu * dmu_du;
+                double* jm = A.jac + (((size_t)b * A.H + (t - 1)) * 2 * DS + a) * nc;          // row of mu_a
+                double* jv = A.jac + (((size_t)b * A.H + (t - 1)) * 2 * DS + DS + a) * nc;     // row of var_a
+                if (k < DS) {
+                    const double dT_ds = Ak * (c * s_z[a * NM + (GRAD ? 1 + D + (k < NS2 ? k : 0) : 0)] - 0.5 * Tt);
+                    const double dv_ds = -dT_ds - 2.0 * mu * dmu_ds;
+                    jm[k] = dmu_du; jm[DS + k] = dmu_ds;
+                    jv[k] = dv_du;  jv[DS + k] = dv_ds;
+                } else {                                           // action input: its variance is a constant
+                    jm[2 * DS + (k - DS)] = dmu_du;
+                    jv[2 * DS + (k - DS)] = dv_du;
+                }
+            }
+        }
+        GPMPC_PST(9);
+        __syncthreads();                                           // every reader of s_uin / s_sin of step t is done
+        GPMPC_PST(10);
+        if (tid < DS) {
+            const double mu = s_cm[tid] * s_ms[tid * NV];
+            s_uin[tid] = mu;
+            s_sin[tid] = s_sf2[tid] - s_c[tid] * s_z[tid * NM] - mu * mu;
+        }
+    }
+}
+
+template <int D, int NS2, bool GRAD>
+static int launch_persist_one(const PersistArgs& a, int waves, hipStream_t s) {
+    const size_t lds = sizeof(double) * ((size_t)D * a.Np + (size_t)a.H * (D - NS2));
+    if (a.Np > GPMPC_PERSIST_MAXNP || a.Np % 64 != 0 || (waves != 8 && waves != 16) || a.H * (D - NS2) > 2 * 512) return GPMPC_E_ARG;
+    if (lds > 32 * 1024) {                         // static + dynamic LDS beyond the default 64 KB of a launch: opt in (160 KB per CU on gfx950)
+        static bool raised = false;                 // (per instance; a benign race: the attribute is idempotent)
+        if (!raised) {
+            if (hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_traj_persist<D, NS2, GRAD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * (D * GPMPC_PERSIST_MAXNP + 2 * 512)));
+                ea != hipSuccess) { gpmpc_set_error("trajectory-persistent kernel: LDS attribute", ea); return GPMPC_E_LAUNCH; }
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL((k_traj_persist<D, NS2, GRAD>), dim3(a.B), dim3(64 * waves), lds, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { gpmpc_set_error("trajectory-persistent rollout kernel launch", e); return GPMPC_E_LAUNCH; }
+    return GPMPC_OK;
+}
+
+// ns2 = state_dim (D - ns2 in {1, 2} action dimensions); waves per workgroup 16 | 8
+template <int D>
+int gpmpc_launch_persist_D(bool grad, int ns2, int waves, const PersistArgs& a, hipStream_t s) {
+    if constexpr (D >= 2) {
+        if (ns2 == D - 1) return grad ? launch_persist_one<D, (D >= 2 ? D - 1 : 1), true>(a, waves, s) : launch_persist_one<D, (D >= 2 ? D - 1 : 1), false>(a, waves, s);
+    }
+    if constexpr (D >= 3) {
+        if (ns2 == D - 2) return grad ? launch_persist_one<D, (D >= 3 ? D - 2 : 1), true>(a, waves, s) : launch_persist_one<D, (D >= 3 ? D - 2 : 1), false>(a, waves, s);
+    }
+    return GPMPC_E_ARG;
+}

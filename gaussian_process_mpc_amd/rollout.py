@@ -324,8 +324,11 @@ def moment_match(pack, u, S, want_cov=False, want_grad=False, bug_compatible=Fal
         out["l"] = e(nq, ds, pack.N)
     if want_grad:
         out.update(dmean_du=e(nq, ds, D), dmean_dS=e(nq, ds, D, D), dvar_du=e(nq, ds, D), dvar_dS=e(nq, ds, D, D))
-        if want_cov and pack.fullcov and not bug_compatible:
-            out.update(dcov_du=e(nq, ds, ds, D), dcov_dS=e(nq, ds, ds, D, D))
+        if want_cov and ds > 1:
+            # pair kernel's cross units when the pack has them (enable_fullcov) and the consistent form is asked for, else the direct
+            # kernel (either form); diagonal (a, a) entries are not written: zero-filled
+            out.update(dcov_du=torch.zeros((nq, ds, ds, D), dtype=torch.float64, device=dev),
+                       dcov_dS=torch.zeros((nq, ds, ds, D, D), dtype=torch.float64, device=dev))
     nbytes = lib().gpmpc_moment_match_workspace_bytes(pack.handle, nq)
     ws = pack.workspace(nbytes)
     with torch.cuda.device(dev):

@@ -12,7 +12,7 @@ Like the reference's, the results carry an autograd graph when ``u`` or ``S`` re
 import numpy as np
 import torch
 
-from .autograd import MomentMatchFunction, wants_grad
+from .autograd import CrossCovFunction, MomentMatchFunction, wants_grad
 from .rollout import GPPack, moment_match
 
 
@@ -86,9 +86,21 @@ def covariance_prop_torch(lambdas1, lambdas2, u, S, X_train, mean1, mean2, beta1
     """Cov[f1, f2] -- src/tools/uncertainty_prop.py:402-465.  The reference's cross term (:446) is
     index-transposed; ``bug_compatible=True`` (default) reproduces it, ``False`` gives the consistent
     form that matches the reference's numpy ``covariance_prop``.  Only the betas enter (rank-one
-    weights), so the pack is built without Ky_inv; mean1/mean2 are recomputed on the device."""
+    weights), so the pack is built without Ky_inv.  Without a graph mean1 / mean2 are recomputed on the device; when ``u``, ``S``,
+    ``mean1`` or ``mean2`` requires grad the result carries the reference's graph (``autograd.CrossCovFunction``: analytic
+    d/du, d/dS of beta1^T Qt beta2 from the device, minus the product of the caller's means in torch)."""
     l1, l2 = _np(lambdas1), _np(lambdas2)
     pack = _cached_pack((X_train, beta1, beta2), ("cov", l1.tobytes(), l2.tobytes(), float(sigma_f1), float(sigma_f2)),
                         lambda: GPPack(X_train, np.stack((_np(beta1).reshape(-1), _np(beta2).reshape(-1)), axis=1), None,
                                        np.stack((l1, l2)), np.array([float(sigma_f1), float(sigma_f2)]), y_is_beta=True))
+    if wants_grad(u, S, mean1, mean2):
+        # the graph of the reference's expression: beta1^T Qt beta2 as a function of (u, S) on the device, the product of the CALLER's
+        # means subtracted in torch -- attached means carry their own graph, detached ones are constants, as in the reference (:465)
+        dev = pack.device
+        ud = torch.as_tensor(u).to(dev, torch.float64).reshape(1, pack.D)
+        Sd = torch.as_tensor(S).to(dev, torch.float64).reshape(1, pack.D, pack.D)
+        q = CrossCovFunction.apply(ud, Sd, pack, bool(bug_compatible))[0]
+        m1 = torch.as_tensor(mean1).to(dev, torch.float64).reshape(())
+        m2 = torch.as_tensor(mean2).to(dev, torch.float64).reshape(())
+        return q - m1 * m2
     return moment_match(pack, u, S, want_cov=True, bug_compatible=bug_compatible)["cov"][0, 0, 1]

@@ -13,7 +13,8 @@ reference's results) stored as ``.npz``; no reference source is stored.
 
 Fixtures:
   g1_single_step.npz   test-suite geometry, N=100/200, D=2, full S
-  g2_adversarial.npz   N=48, D=3..5, non-proportional lambdas, diag and full S, autograd d/du, d/dS
+  g2_adversarial.npz   N=48, D=3..5, non-proportional lambdas, diag and full S, autograd d/du, d/dS of mean, variance and
+                       (round 4) of covariance_prop_torch, with graph-attached and with constant means
   g3_rollout_c1.npz    N=100, ds=2, da=2, H=10, gamma in {-1, 1e-5, 1}
   g4_rollout_c2.npz    N=128, ds=3, da=1, H=20, R_delta + nonzero references
   g5_cost.npz          literal cost cases of the reference's tests
@@ -128,6 +129,10 @@ def g2():
         m2, d2 = mean_prop_torch(Ki2, T(lam2), ut, St, T(X), T(y2), sf2)
         v2 = variance_prop_torch(Ki2, T(lam2), ut, St, T(X), m2, d2["beta"], sf2)
         cv = covariance_prop_torch(T(lam1), T(lam2), ut, St, T(X), m1, m2, d1["beta"], d2["beta"], sf1, sf2)
+        # autograd of the covariance: total (through the graph-attached means) and with the means as constants
+        dc_du, dc_dS = torch.autograd.grad(cv, (ut, St), retain_graph=True)
+        cv0 = covariance_prop_torch(T(lam1), T(lam2), ut, St, T(X), m1.detach(), m2.detach(), d1["beta"], d2["beta"], sf1, sf2)
+        dc0_du, dc0_dS = torch.autograd.grad(cv0, (ut, St), retain_graph=True)
         # numpy loop covariance (sigma_f = 1 and one shared y): the mathematically consistent form
         Ky1u = se_K(X, lam1) + sn ** 2 * np.eye(N)
         Ky2u = se_K(X, lam2) + sn ** 2 * np.eye(N)
@@ -142,6 +147,8 @@ def g2():
                     p + "Kinv1": Ki1.numpy(), p + "Kinv2": Ki2.numpy(),
                     p + "mu": np.array([m1.item(), m2.item()]), p + "var": np.array([v1.item(), v2.item()]),
                     p + "cov_torch": np.array(cv.item()),
+                    p + "dcov_du": dc_du.numpy(), p + "dcov_dS": dc_dS.numpy(),
+                    p + "dcov_du_means_const": dc0_du.numpy(), p + "dcov_dS_means_const": dc0_dS.numpy(),
                     p + "dm_du": dm_du.numpy(), p + "dm_dS": dm_dS.numpy(),
                     p + "dv_du": dv_du.numpy(), p + "dv_dS": dv_dS.numpy(),
                     p + "unit_Kinv1": Ki1u.numpy(), p + "unit_Kinv2": Ki2u.numpy(),

@@ -200,6 +200,53 @@ def test_batched_function_on_the_mid_size_form(G, N, ds, da, B):
 
 
 @pytest.mark.parametrize("k", range(6))
+def test_covariance_prop_torch_carries_the_graph(G, golden, k):
+    """covariance_prop_torch with u, S requiring grad (src/tools/uncertainty_prop.py:402-465): value, d/du and symmetrised d/dS against
+    the REFERENCE's autograd values in g2 -- with graph-attached means (the total derivative) and with the means as constants --; the
+    consistent cross-term form against central differences of itself."""
+    from gaussian_process_mpc_amd import uncertainty_prop as up
+    z = golden("g2_adversarial.npz")
+    p = f"c{k}_"
+    X = torch.tensor(z[p + "X"])
+    lam1, lam2 = torch.tensor(z[p + "lam1"]), torch.tensor(z[p + "lam2"])
+    K1, K2 = torch.tensor(z[p + "Kinv1"]), torch.tensor(z[p + "Kinv2"])
+    y1, y2 = torch.tensor(z[p + "y1"]), torch.tensor(z[p + "y2"])
+    sf1, sf2 = float(z[p + "hyp"][0]), float(z[p + "hyp"][1])
+    u = torch.tensor(z[p + "u"], requires_grad=True)
+    S = torch.tensor(z[p + "S"], requires_grad=True)
+    m1, a1 = up.mean_prop_torch(K1, lam1, u, S, X, y1, sf1)
+    m2, a2 = up.mean_prop_torch(K2, lam2, u, S, X, y2, sf2)
+    sym = lambda a: 0.5 * (a + a.T)  # noqa: E731
+    cov = up.covariance_prop_torch(lam1, lam2, u, S, X, m1, m2, a1["beta"], a2["beta"], sf1, sf2)
+    np.testing.assert_allclose(cov.item(), z[p + "cov_torch"], rtol=1e-7, atol=1e-12)
+    g_u, g_S = torch.autograd.grad(cov, (u, S), retain_graph=True)
+    scale = np.abs(z[p + "dcov_du"]).max()
+    np.testing.assert_allclose(g_u.cpu().numpy(), z[p + "dcov_du"], rtol=1e-6, atol=1e-9 * max(1.0, scale))
+    np.testing.assert_allclose(sym(g_S.cpu().numpy()), sym(z[p + "dcov_dS"]), rtol=1e-6, atol=1e-9 * max(1.0, np.abs(z[p + "dcov_dS"]).max()))
+    cov0 = up.covariance_prop_torch(lam1, lam2, u, S, X, m1.detach(), m2.detach(), a1["beta"], a2["beta"], sf1, sf2)
+    h_u, h_S = torch.autograd.grad(cov0, (u, S))
+    np.testing.assert_allclose(h_u.cpu().numpy(), z[p + "dcov_du_means_const"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(sym(h_S.cpu().numpy()), sym(z[p + "dcov_dS_means_const"]), rtol=1e-6, atol=1e-9)
+    # without a graph: a plain value, as before
+    assert not up.covariance_prop_torch(lam1, lam2, u.detach(), S.detach(), X, m1.detach(), m2.detach(), a1["beta"], a2["beta"], sf1, sf2).requires_grad
+    # the consistent form (bug_compatible=False): analytic gradient against central differences of the same function
+    f = lambda uu, SS: up.covariance_prop_torch(lam1, lam2, uu, SS, X, m1.detach(), m2.detach(), a1["beta"], a2["beta"], sf1, sf2,  # noqa: E731
+                                                bug_compatible=False)
+    c1 = f(u, S)
+    q_u, q_S = torch.autograd.grad(c1, (u, S))
+    eps = 1e-6
+    D = u.shape[0]
+    for kk in range(D):
+        e = torch.zeros(D, dtype=torch.float64); e[kk] = eps
+        fd = (f(u.detach() + e, S.detach()).item() - f(u.detach() - e, S.detach()).item()) / (2 * eps)
+        np.testing.assert_allclose(q_u[kk].item(), fd, rtol=2e-5, atol=1e-8)
+    E = torch.zeros((D, D), dtype=torch.float64); E[0, D - 1] = E[D - 1, 0] = eps; E[1, 1] = eps
+    fd = (f(u.detach(), S.detach() + E).item() - f(u.detach(), S.detach() - E).item()) / (2 * eps)
+    qs = sym(q_S.cpu().numpy())
+    np.testing.assert_allclose(qs[0, D - 1] + qs[D - 1, 0] + qs[1, 1], fd, rtol=2e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("k", range(6))
 def test_single_step_functions_carry_the_graph(G, golden, k):
     """mean_prop_torch / variance_prop_torch with u, S requiring grad: d/du and (diagonal / symmetrised) d/dS against the
     reference's autograd values in g2; the pack behind the functional interface is built once per argument set."""

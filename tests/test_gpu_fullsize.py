@@ -204,6 +204,39 @@ def test_c4_full_horizon_against_cport(G):
     np.testing.assert_allclose(r["vars"][pick].cpu().numpy(), c["vars"], rtol=1e-4)                    # north star
     np.testing.assert_allclose(r["cost"][pick].cpu().numpy(), c["cost"], rtol=1e-6)
     np.testing.assert_allclose(r["grad"][pick].cpu().numpy(), c["grad"], rtol=1e-4, atol=1e-7)
+    # the SAME problem at B = 1 and B = 2 (what one rank's solver callbacks would run: the one-launch-per-step form on 256x64 tiles at
+    # D = 7), whole horizon, eager and as a captured graph, held directly to the C port as well
+    forms = set()
+    for B in (1, 2):
+        forms.add(pack.plan(B, cfg["H"])["kernel"])
+        for graph in (False, True):
+            rs = G.rollout(pack, pb["x0"][pick[:B]], pb["U"][pick[:B]], G.CostParams(cfg["gamma"], pb["Q"], pb["R"]), graph=graph)
+            np.testing.assert_allclose(rs["means"].cpu().numpy(), c["means"][:B], rtol=1e-5, atol=1e-9, err_msg=f"B={B}")
+            np.testing.assert_allclose(rs["vars"].cpu().numpy(), c["vars"][:B], rtol=1e-4, err_msg=f"B={B}")
+            np.testing.assert_allclose(rs["cost"].cpu().numpy(), c["cost"][:B], rtol=1e-6, err_msg=f"B={B}")
+            np.testing.assert_allclose(rs["grad"].cpu().numpy(), c["grad"][:B], rtol=1e-4, atol=1e-7, err_msg=f"B={B}")
+    assert forms and all(k for k in forms)
+    del pack
+    torch.cuda.empty_cache()
+
+
+def test_n4096_ds4_single_and_pair_of_trajectories_against_cport(G):
+    """N = 4096 with FOUR state dimensions (D = 5 instances: the one-launch-per-step form was extended to N <= ~4300 for them),
+    B = 1 and B = 2, whole horizon H = 20, directly against the C port."""
+    from oracle import cport, gpmpc_oracle as O
+    from gaussian_process_mpc_amd.synth import synth_problem
+    pb = synth_problem(7, 4096, 4, 1, 20, 2)
+    torch.set_num_threads(16)
+    kinv = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"]).Ky_inv.numpy()
+    pack = G.GPPack(pb["X"], pb["Y"], kinv, pb["lambdas"], pb["sigma_f"])
+    cost = G.CostParams(-1.0, pb["Q"], pb["R"])
+    c = cport.rollout(pb, kinv, -1.0, x0=pb["x0"], U=pb["U"], nthreads=16)
+    for B in (1, 2):
+        r = G.rollout(pack, pb["x0"][:B], pb["U"][:B], cost)
+        np.testing.assert_allclose(r["means"].cpu().numpy(), c["means"][:B], rtol=1e-5, atol=1e-9, err_msg=f"B={B}")      # north star
+        np.testing.assert_allclose(r["vars"].cpu().numpy(), c["vars"][:B], rtol=1e-4, err_msg=f"B={B}")                   # north star
+        np.testing.assert_allclose(r["cost"].cpu().numpy(), c["cost"][:B], rtol=1e-6, err_msg=f"B={B}")
+        np.testing.assert_allclose(r["grad"].cpu().numpy(), c["grad"][:B], rtol=1e-4, atol=1e-7, err_msg=f"B={B}")
     del pack
     torch.cuda.empty_cache()
 
@@ -240,6 +273,29 @@ def test_c3_full_horizon_against_cport(G, c3):
     np.testing.assert_allclose(r["vars"].cpu().numpy(), c["vars"], rtol=1e-4)                    # north star
     np.testing.assert_allclose(r["cost"].cpu().numpy(), c["cost"], rtol=1e-6)
     np.testing.assert_allclose(r["grad"].cpu().numpy(), c["grad"], rtol=1e-4, atol=1e-7)
+
+
+def test_c3_small_and_mid_batches_directly_against_cport(G, c3):
+    """N = 2048, ds = 4, H = 20 at B = 1, 2, 4, 8, 16 and 24 -- the narrow-tile and the 256x64 one-launch forms, their two-branch split,
+    head + pair kernel on 256x64 and the 256x128 two-trajectory tiling -- EVERY trajectory of every batch held directly to the C port
+    over the whole horizon (B = 1 used to be tied to the B = 8 batch only), eager and graph replay."""
+    from oracle import cport
+    from gaussian_process_mpc_amd.synth import synth_problem
+    pb, gp, pack = c3
+    big = synth_problem(3, pb["N"], pb["ds"], pb["da"], pb["H"], 24)
+    cost = G.CostParams(-1.0, pb["Q"], pb["R"])
+    c = cport.rollout(big, gp.Ky_inv.numpy(), -1.0, x0=big["x0"], U=big["U"], nthreads=16)
+    kernels = set()
+    for B in (1, 2, 4, 8, 16, 24):
+        pl = pack.plan(B, pb["H"])
+        kernels.add((pl["kernel"], pl["tiling"]))
+        for graph in ((False, True) if B <= 8 else (False,)):
+            r = G.rollout(pack, big["x0"][:B], big["U"][:B], cost, graph=graph)
+            np.testing.assert_allclose(r["means"].cpu().numpy(), c["means"][:B], rtol=1e-5, atol=1e-9, err_msg=f"B={B} {pl}")   # north star
+            np.testing.assert_allclose(r["vars"].cpu().numpy(), c["vars"][:B], rtol=1e-4, err_msg=f"B={B} {pl}")                # north star
+            np.testing.assert_allclose(r["cost"].cpu().numpy(), c["cost"][:B], rtol=1e-6, err_msg=f"B={B} {pl}")
+            np.testing.assert_allclose(r["grad"].cpu().numpy(), c["grad"][:B], rtol=1e-4, atol=1e-7, err_msg=f"B={B} {pl}")
+    assert len(kernels) >= 3, kernels          # the batch sizes really reach different kernel shapes
 
 
 def test_beyond_baseline_sizes_n8192_against_cport(G):

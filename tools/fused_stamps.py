@@ -14,7 +14,8 @@ from oracle import gpmpc_oracle as O
 cfg = dict(CONFIGS["C2"])
 if len(sys.argv) > 1:
     cfg["N"], cfg["ds"], cfg["da"], cfg["H"], cfg["B"] = (int(v) for v in sys.argv[1].split(":"))
-assert cfg["ds"] + cfg["da"] == 4, "the stamps are compiled into the D = 4 instances"
+import os
+assert cfg["ds"] + cfg["da"] == int(os.environ.get("GPMPC_STAMP_D", "4")), "the stamps are compiled into the D = GPMPC_STAMP_D instances (default 4; build with -DGPMPC_STAMP_D=<D>)"
 pb = synth_problem(2, cfg["N"], cfg["ds"], cfg["da"], cfg["H"], cfg["B"])
 gp = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"])
 pack = g.GPPack(pb["X"], pb["Y"], gp.Ky_inv.numpy(), pb["lambdas"], pb["sigma_f"])
