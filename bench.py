@@ -420,8 +420,13 @@ def run_rank(args):
                 torch.save(kinv.cpu(), args.kinv_cache)
     else:
         kinv = torch.empty((ds, N, N), dtype=torch.float64, device=device)
+    bcast_ms = None
     if world > 1:
+        torch.cuda.synchronize(); dist.barrier()
+        tb0 = time.perf_counter()
         dist.broadcast(kinv, src=0)
+        torch.cuda.synchronize()
+        bcast_ms = (time.perf_counter() - tb0) * 1e3       # Ky_inv broadcast (once per data update; not in the rate)
     t0 = time.perf_counter()
     pack = g.GPPack(pb["X"], pb["Y"], kinv, pb["lambdas"], pb["sigma_f"], device=device)
     torch.cuda.synchronize()
@@ -473,9 +478,41 @@ def run_rank(args):
         L.gpmpc_pair_kernel_time_class(cls, ctypes.byref(ms), ctypes.byref(nl))
         tcls.append((ms.value, nl.value))
     L.gpmpc_timing_enable(0)
+    multi = None
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        # instrumentation of the first real multi-GPU run (outside the timed region): were it to scale below expectation, these
+        # say whether the ranks differ (per-rank elapsed of the timed region, rollout-only rate without the collective) or the
+        # collective costs (latency of the fused all_gather of [cost | grad] alone, 100 repetitions)
+        el_all = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(world)]
+        dist.all_gather(el_all, torch.tensor([elapsed], dtype=torch.float64, device=device))
+        torch.cuda.synchronize()
+        tq = time.perf_counter()
+        for _ in range(max(2, min(args.steps, 5))):
+            if fullcov:
+                g.rollout_fullcov(pack, x0, U, cost, want_grad=want_grad)
+            else:
+                g.rollout(pack, x0, U, cost, want_grad=want_grad, want_traj=False, graph=args.graph)
+        torch.cuda.synchronize()
+        local_rate = max(2, min(args.steps, 5)) * (hi - lo) / (time.perf_counter() - tq)
+        lr_all = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(world)]
+        dist.all_gather(lr_all, torch.tensor([local_rate], dtype=torch.float64, device=device))
+        c0 = torch.zeros(hi - lo, dtype=torch.float64, device=device)
+        g0 = torch.zeros((hi - lo, H, da), dtype=torch.float64, device=device) if want_grad else None
+        for _ in range(5):
+            gather_results(c0, g0, dist)
+        torch.cuda.synchronize(); dist.barrier()
+        tg = time.perf_counter()
+        for _ in range(100):
+            gather_results(c0, g0, dist)
+        torch.cuda.synchronize()
+        ag_us = (time.perf_counter() - tg) / 100 * 1e6
+        multi = {"per_rank_elapsed_s": [float(t.item()) for t in el_all],
+                 "per_rank_rollouts_per_s_without_collective": [float(t.item()) for t in lr_all],
+                 "rollouts_per_s_min_max_over_ranks": [min(float(t.item()) for t in lr_all), max(float(t.item()) for t in lr_all)],
+                 "all_gather_cost_grad_latency_us": ag_us, "all_gather_bytes_per_rank": 8 * (hi - lo) * (1 + (H * da if want_grad else 0)),
+                 "kinv_broadcast_ms": bcast_ms, "kinv_bytes": 8 * ds * N * N}
         elapsed = float(tmax.item())
 
     if rank == 0:
@@ -610,6 +647,8 @@ def run_rank(args):
             },
             "pack_build_ms": pack_ms,
         }
+        if multi is not None:
+            out["multi_gpu"] = multi
         if world == 1 and not args.graph and not args.no_extras:
             # PCIe-inclusive rate, outside the timed region: U from pinned host memory in, [cost | grad] back out, per step
             Uh = torch.as_tensor(pb["U"][lo:hi]).pin_memory()

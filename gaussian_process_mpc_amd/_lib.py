@@ -75,6 +75,8 @@ SIGNATURES = {
     "gpmpc_rollout_vjp": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gpmpc_rollout_workspace_bytes": (_sz, [_vp, _i, _i, _u]),
     "gpmpc_plan_describe": (_i, [_vp, _i, _i, _u, ctypes.c_char_p, _sz]),
+    "gpmpc_pack_autotune": (_i, [_vp, _i, _i, _u, ctypes.c_char_p, _sz]),
+    "gpmpc_pack_autotune_clear": (_i, [_vp]),
     "gpmpc_rollout": (_i, [_vp, _i, _i, _vp, _vp, ctypes.POINTER(CostParamsC), _u, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gpmpc_objective_gradient": (_i, [_vp, _i, _dp, _dp, ctypes.POINTER(CostParamsC), _u, _dp, _vp]),
     "gpmpc_rollout_fullcov_workspace_bytes": (_sz, [_vp, _i, _i, _u]),

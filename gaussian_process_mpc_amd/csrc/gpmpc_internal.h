@@ -73,6 +73,7 @@ struct gpmpc_pack {
     double sf_host[GPMPC_MAX_DS];
     void* graph_cache;         // captured rollout (GPMPC_USE_GRAPH), owned by step.hip
     void* cb_cache;            // buffers + captured graph of gpmpc_objective_gradient (solver callbacks), owned by step.hip
+    void* tuned;               // plans measured by gpmpc_pack_autotune (gpmpc_tuned_table, step.hip), or null
     void* lock;                // host lock of the pack's own streams / events / caches (std::recursive_mutex, step.hip::PackGuard)
     // [0: variance units only | 1: + cross units][0: 256x256 tiles | 1: 64x64 | 2: 256x64 | 3: 64x128 | 4: 256x128 | 5: 256x32 | 6: 256x16
     //  (4...6: mode 0 only)]
@@ -211,6 +212,8 @@ static inline int gpmpc_check_device(const gpmpc_pack* p) {
 // pair-kernel timing classes (gpmpc_pair_kernel_time_class): the horizon-step-1 variant is cheaper than the full kernel
 // (the fused small-batch step kernel -- mean sums, finish work and tiles of one horizon step in one launch -- has its own class)
 enum { GPMPC_TIME_FULL = 0, GPMPC_TIME_FIRST = 1, GPMPC_TIME_FUSED = 2, GPMPC_TIME_CLASSES = 3 };
+void gpmpc_tuned_free(void* table);
+void gpmpc_tuned_clear(void* table);
 void* gpmpc_lock_create();
 void gpmpc_lock_destroy(void* lock);
 void gpmpc_graph_cache_free(void* cache);

@@ -229,6 +229,7 @@ extern "C" int gpmpc_pack_reload_tuning(gpmpc_pack* p) {
     p->tune.no_xcd_sort = keep;
     if (p->graph_cache) { gpmpc_graph_cache_free(p->graph_cache); p->graph_cache = nullptr; }   // captured under the old plan
     if (p->cb_cache) { gpmpc_cb_cache_free(p->cb_cache); p->cb_cache = nullptr; }
+    gpmpc_tuned_clear(p->tuned);
     return GPMPC_OK;
 }
 
@@ -318,6 +319,7 @@ extern "C" int gpmpc_pack_destroy(gpmpc_pack* p) {
     if (p->sf) (void)hipFree(p->sf);
     gpmpc_graph_cache_free(p->graph_cache);
     gpmpc_cb_cache_free(p->cb_cache);
+    gpmpc_tuned_free(p->tuned);
     gpmpc_lock_destroy(p->lock);
     if (p->pair_ab_dev) (void)hipFree(p->pair_ab_dev);
     for (int mode = 0; mode < 2; ++mode)
@@ -366,6 +368,7 @@ static int pack_build_impl(gpmpc_pack* p, const double* X_dev, const double* Y_d
     if (p->shared_lambda != shared_before) {
         gpmpc_graph_cache_invalidate(p->graph_cache);
         gpmpc_cb_cache_invalidate(p->cb_cache);
+        gpmpc_tuned_clear(p->tuned);                         // measured plans name the kernel family too
     }
     // hyper-parameters are tiny: as kernel arguments (consumed before this call returns, gpmpc_upload_small)
     if (int rcu = gpmpc_upload_small(p->lam, lambdas_host, sizeof(double) * p->ds * p->D, s)) return rcu;

@@ -883,9 +883,28 @@ struct RollPlan { int tiling, tb, waves, nwork, nm, pps, sps, sb, gw, rgroup, fu
 // shape (optional): take every SHAPE decision (tiling, kernel, trajectories per wave, row chunks ...) from this plan of a larger
 // batch and only size the buffers for B: the sub-batches of a split call then run exactly the launches the whole batch would,
 // so their results are bit-identical to the unsplit call.
+// Plans MEASURED for this pack (gpmpc_pack_autotune): a call shape found here takes its kernel form from the table instead of
+// from the thresholds below.  Owned by the pack (gpmpc_pack::tuned), written only by gpmpc_pack_autotune.
+#define GPMPC_TUNED_SLOTS 16
+struct gpmpc_tuned_entry { int B, H, grad, graph, S, valid; RollPlan plan; double ms_default, ms_best; };
+struct gpmpc_tuned_table { gpmpc_tuned_entry e[GPMPC_TUNED_SLOTS]; int next; };
+static const gpmpc_tuned_entry* tuned_lookup(const gpmpc_pack* p, int B, int H, bool grad) {
+    const gpmpc_tuned_table* t = (const gpmpc_tuned_table*)p->tuned;
+    if (!t) return nullptr;
+    for (int k = 0; k < GPMPC_TUNED_SLOTS; ++k)
+        if (t->e[k].valid && t->e[k].B == B && t->e[k].H == H && t->e[k].grad == (grad ? 1 : 0)) return &t->e[k];
+    return nullptr;
+}
+void gpmpc_tuned_free(void* t) { free(t); }
+void gpmpc_tuned_clear(void* t) { if (t) memset(t, 0, sizeof(gpmpc_tuned_table)); }      // plans measured under another kernel selection (lambdas no longer shared, new GPMPC_* overrides)
+
+// tn_over (optional): GPMPC_* overrides to plan under instead of the pack's (gpmpc_pack_autotune enumerates candidates with it).
 static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag, RollPlan* r, bool lowprec = false,
-                         const RollPlan* shape = nullptr) {
+                         const RollPlan* shape = nullptr, const gpmpc_tuning* tn_over = nullptr) {
     const int D = p->D;
+    if (!shape && !tn_over && !lowprec && diag)                 // a measured plan for this call shape
+        if (const gpmpc_tuned_entry* te = tuned_lookup(p, B, H, grad)) shape = &te->plan;
+    const gpmpc_tuning& tn = tn_over ? *tn_over : p->tune;        // GPMPC_* overrides, read once at pack creation
     // The selection as it stands (diagonal rollout, da <= 2; every threshold is a measured crossover -- its numbers are in the
     // comment at its line, the method in DESIGN.md section 5, the maps in profiles/r02 and r03/batch_size_map.txt):
     //   W64 = B x tiles(256x64) < ~150 (~400 for N < 512), or N < 256           ONE launch per step, 64-row tiles, staged column loop
@@ -922,8 +941,8 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     // N = 512, ds = 3, B = 8 / 12 / 16 / 32 x1.01 / 1.16 / 1.19 / 1.38; N = 300, ds = 2, B = 32 / 64 x1.02 / 1.15; below ~300 workgroups
     // it loses (N = 1024, B = 1 x0.92; N = 512, B = 4 x0.77), and so do training sets of less than one row tile (N = 128, B = 128 x0.89)
     const long wg2 = (long)B * p->wl[0][2].nwork;
-    const bool shared_on = p->shared_lambda && p->tune.shared != 0 && p->sh_ng >= 2;
-    const bool fsb_can = sb_ok && !lowprec && p->da >= 1 && p->tune.fused_sb != 0 && (p->Np >= 256 || p->tune.fused_sb == 1) &&
+    const bool shared_on = p->shared_lambda && tn.shared != 0 && p->sh_ng >= 2;
+    const bool fsb_can = sb_ok && !lowprec && p->da >= 1 && tn.fused_sb != 0 && (p->Np >= 256 || tn.fused_sb == 1) &&
                          p->wl[0][2].nwork <= 600 * p->ds;           // (N <= ~4300; measured up to N = 4096: B = 1 / 2 x1.22 / 1.18 at ds = 4, level at ds = 6)
     // ... and with NARROWER tiles (256x32, 256x16: work lists 5, 6) further down for training sets of at least two row tiles: a launch
     // of a few hundred 256x64 workgroups leaves most of the chip empty while each workgroup walks its 64 columns one L2 round trip
@@ -945,14 +964,13 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     // ... but only beyond the reach of the one-launch form, which is ahead of it wherever both apply (N = 1024, B = 40 2.27 vs 2.57 ms;
     // N = 768, B = 72 2.35 vs 2.58; N = 600, B = 96 2.36 vs 2.64)
     const long fsb_max = shared_on ? 7000 : (p->wl[0][2].nwork <= 200 ? 7000 : 4700);
-    const bool fsb_take = fsb_can && p->tune.fused_sb != 0 && wg2 <= fsb_max;
+    const bool fsb_take = fsb_can && tn.fused_sb != 0 && wg2 <= fsb_max;
     const bool big128 = !big && !fsb_take && sb_ok && tb2 && p->Np > 512 && (long)((B + 1) / 2) * p->wl[0][4].nwork >= 1600;
     r->sb = (sb_ok && (big || mid)) ? 1 : 0;
     const bool many = (long)p->wl[0][1].nwork > 256L * p->ds;        // > 256 one-wave tiles per GP (N >= 1472)
     r->tiling = big ? 0 : (big128 ? 4 : (mid ? 2 : (many ? 3 : 1)));
     if (r->tiling == 2 && narrow_ok && wg2 < 1000)           // 32 columns from ~300 workgroups of 64, 16 below (while the partial sums
         r->tiling = (wg2 >= 300 || p->wl[0][6].nwork > 1300) ? 5 : 6;      // of a trajectory stay within ~1300)
-    const gpmpc_tuning& tn = p->tune;                        // GPMPC_* overrides, read once at pack creation
     if (tn.pair_sb >= 0) {                                   // 0 = staged kernel, 1 = scalar broadcast
         r->sb = (tn.pair_sb != 0 && sb_ok) ? 1 : 0;
         r->tiling = r->sb ? (big ? 0 : (big128 ? 4 : 2)) : (big ? 0 : (many ? 3 : 1));
@@ -1088,8 +1106,11 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
 // kernel runs B ds workgroups, the pair kernel ends in a partly filled generation: tools/sb_stamps.py); two independent chains
 // fill each other's gaps.
 #define GPMPC_MAX_SPLIT 4
-static int split_count(const gpmpc_pack* p, const RollPlan& r, int B, bool lowprec, bool eager = false) {
+static int split_count(const gpmpc_pack* p, const RollPlan& r, int B, bool lowprec, bool eager = false, int split_over = 0,
+                       int H = 0, int grad = -1) {
     if (lowprec || !r.sb) return 1;
+    if (!split_over && H > 0 && grad >= 0)
+        if (const gpmpc_tuned_entry* te = tuned_lookup(p, B, H, grad != 0)) { int S = te->S; if (eager && S > 2) S = 2; return S < 1 ? 1 : (S > B ? B : S); }
     const bool mid = r.shared ? r.sh_list == 1 : r.tiling == 2;
     // measured (tools/env_ab.py --var GPMPC_SPLIT, profiles/r03/split_ab.txt): N = 1024, B = 16: 11.3 -> 13.8 (2 branches) -> 14.3 k
     // rollouts/s (4); N = 2048, B = 4 / 16: +15 % / +13 %; a branch must keep at least two trajectories, and branches whose
@@ -1119,6 +1140,7 @@ static int split_count(const gpmpc_pack* p, const RollPlan& r, int B, bool lowpr
     // -- profiles/r03/split_eager_branches.txt); two are ahead in every process measured.
     if (eager && S > 2) S = 2;
     if (p->tune.split >= 1) S = p->tune.split;
+    if (split_over >= 1) S = split_over;
     if (S > GPMPC_MAX_SPLIT) S = GPMPC_MAX_SPLIT;
     if (S > B) S = B;
     return S;
@@ -1140,7 +1162,7 @@ extern "C" size_t gpmpc_rollout_workspace_bytes(const gpmpc_pack* p, int B, int 
     const bool grad = (flags & GPMPC_WANT_GRAD) != 0, lowprec = (flags & (GPMPC_FP32_ACCUM | GPMPC_FP32_ALL)) != 0;
     plan_rollout(p, B, H, grad, true, &r, lowprec);
     size_t need = r.total;
-    const int S = split_count(p, r, B, lowprec);           // mid-size batches run as S concurrent sub-batches, each with its own slice
+    const int S = split_count(p, r, B, lowprec, false, 0, H, grad ? 1 : 0);     // mid-size batches run as S concurrent sub-batches, each with its own slice
     if (S > 1) { const size_t sb = split_bytes(p, r, B, H, grad, S); if (sb > need) need = sb; }
     return need;
 }
@@ -1152,7 +1174,7 @@ extern "C" int gpmpc_plan_describe(const gpmpc_pack* p, int B, int H, unsigned f
     const bool grad = (flags & GPMPC_WANT_GRAD) != 0, lowprec = (flags & (GPMPC_FP32_ACCUM | GPMPC_FP32_ALL)) != 0;
     RollPlan r;
     plan_rollout(p, B, H, grad, true, &r, lowprec);
-    const int S = split_count(p, r, B, lowprec, (flags & GPMPC_USE_GRAPH) == 0);
+    const int S = split_count(p, r, B, lowprec, (flags & GPMPC_USE_GRAPH) == 0, 0, H, grad ? 1 : 0);
     static const int cfg[7][2] = {{256, 256}, {64, 64}, {256, 64}, {64, 128}, {256, 128}, {256, 32}, {256, 16}};
     const int D = p->D, ds = p->ds;
     char kern[160];
@@ -1522,7 +1544,7 @@ static int graph_rollout(gpmpc_pack* p, int B, int H, const double* x0, const do
         const bool grad = (flags & GPMPC_WANT_GRAD) != 0, lowprec = (flags & (GPMPC_FP32_ACCUM | GPMPC_FP32_ALL)) != 0;
         RollPlan whole;
         plan_rollout(p, B, H, grad, true, &whole, lowprec);
-        const int S = split_count(p, whole, B, lowprec);
+        const int S = split_count(p, whole, B, lowprec, false, 0, H, grad ? 1 : 0);
         if (S > 1 && split_bytes(p, whole, B, H, grad, S) > workspace_bytes) return GPMPC_E_WORKSPACE;
         GPMPC_HIP(hipStreamBeginCapture(g->stream, hipStreamCaptureModeThreadLocal));
         int rc = GPMPC_OK;
@@ -1703,7 +1725,7 @@ extern "C" int gpmpc_rollout(const gpmpc_pack* p, int B, int H, const double* x0
         const bool grad = (flags & GPMPC_WANT_GRAD) != 0;
         RollPlan whole;
         plan_rollout(p, B, H, grad, true, &whole, false);
-        const int S = split_count(p, whole, B, false, true);
+        const int S = split_count(p, whole, B, false, true, 0, H, grad ? 1 : 0);
         if (S > 1 && split_bytes(p, whole, B, H, grad, S) <= workspace_bytes) {
             PackGuard lock(p);                              // the pack's auxiliary streams / events (shared with graph_rollout's captures)
             gpmpc_graph_cache* g = nullptr;
@@ -1714,6 +1736,164 @@ extern "C" int gpmpc_rollout(const gpmpc_pack* p, int B, int H, const double* x0
     }
     return enqueue_rollout(p, B, H, x0, U, cost, flags, out_means, out_vars, out_cost, out_grad, workspace,
                            workspace_bytes, stream);
+}
+
+// ---------------------------------------------------------------------------
+// Plan selection that measures: time the candidate plans of ONE call shape on this device and keep the winner
+// ---------------------------------------------------------------------------
+static bool same_shape(const RollPlan& a, const RollPlan& b) {
+    return a.tiling == b.tiling && a.tb == b.tb && a.sb == b.sb && a.fused == b.fused && a.fq == b.fq && a.shared == b.shared &&
+           a.sh_list == b.sh_list && a.fng == b.fng && a.colunroll == b.colunroll && a.hchunks == b.hchunks && a.pwaves == b.pwaves &&
+           a.rgroup == b.rgroup && a.nwork == b.nwork;
+}
+
+extern "C" int gpmpc_pack_autotune(gpmpc_pack* p, int B, int H, unsigned flags, char* report, size_t report_bytes) {
+    if (!p || B < 1 || H < 1) return GPMPC_E_ARG;
+    if (!p->built) return GPMPC_E_STATE;
+    if (int rc_dev = gpmpc_check_device(p)) return rc_dev;
+    PackGuard lock(p);
+    const bool grad = (flags & GPMPC_WANT_GRAD) != 0, use_graph = (flags & GPMPC_USE_GRAPH) != 0;
+    gpmpc_tuned_table* tab = (gpmpc_tuned_table*)p->tuned;
+    if (!tab) { tab = (gpmpc_tuned_table*)calloc(1, sizeof(gpmpc_tuned_table)); if (!tab) return GPMPC_E_ALLOC; p->tuned = tab; }
+    for (int k = 0; k < GPMPC_TUNED_SLOTS; ++k)                   // re-tuning a shape replaces its entry
+        if (tab->e[k].valid && tab->e[k].B == B && tab->e[k].H == H && tab->e[k].grad == (grad ? 1 : 0)) tab->e[k].valid = 0;
+    // ---- candidates: the default plan, then the plans the GPMPC_* overrides would force, de-duplicated -------------------------
+    struct Cand { RollPlan r; int S; double ms; const char* why; };
+    Cand cand[40]; int nc = 0;
+    auto add = [&](const gpmpc_tuning& tn, int split, const char* why) {
+        if (nc >= 40) return;
+        RollPlan r;
+        plan_rollout(p, B, H, grad, true, &r, false, nullptr, &tn);
+        int S = split_count(p, r, B, false, !use_graph, split);
+        if (S > 1 && r.fused == 3) S = 1;
+        for (int k = 0; k < nc; ++k) if (same_shape(cand[k].r, r) && cand[k].S == S) return;
+        cand[nc].r = r; cand[nc].S = S; cand[nc].ms = -1.0; cand[nc].why = why; ++nc;
+    };
+    const gpmpc_tuning base = p->tune;
+    add(base, 0, "default");
+    { gpmpc_tuning t = base; t.fused_sb = 0; add(t, 0, "fused_sb=0"); }
+    { gpmpc_tuning t = base; t.fused_sb = 1; add(t, 0, "fused_sb=1"); }
+    for (int tl : {0, 2, 4, 5, 6}) { gpmpc_tuning t = base; t.tiling = tl; add(t, 0, "tiling"); t.fused_sb = 1; add(t, 0, "tiling+fused_sb=1"); t.fused_sb = 0; add(t, 0, "tiling+fused_sb=0"); }
+    { gpmpc_tuning t = base; t.persist = 16; add(t, 0, "persist=16"); t.persist = 8; add(t, 0, "persist=8"); t.persist = 0; add(t, 0, "persist=0"); }
+    { gpmpc_tuning t = base; t.pair_sb = 0; t.persist = 0; add(t, 0, "pair_sb=0"); t.fused = 0; add(t, 0, "pair_sb=0,fused=0"); }
+    { gpmpc_tuning t = base; t.fused = 0; t.persist = 0; add(t, 0, "fused=0"); }
+    if (p->shared_lambda) { gpmpc_tuning t = base; t.shared = 0; t.persist = 0; add(t, 0, "shared=0"); }
+    for (int sp : {1, 2, 4}) { gpmpc_tuning t = base; t.persist = 0; add(t, sp, "split"); }
+    // ---- scratch: inputs (zeros: a valid problem), outputs, the largest workspace --------------------------------------------
+    size_t wsb = 0;
+    for (int k = 0; k < nc; ++k) {
+        size_t need = cand[k].r.total;
+        if (cand[k].S > 1) { const size_t sb = split_bytes(p, cand[k].r, B, H, grad, cand[k].S); if (sb > need) need = sb; }
+        if (need > wsb) wsb = need;
+    }
+    const size_t nU = (size_t)B * H * p->da, nx = (size_t)B * p->ds;
+    double *x0 = nullptr, *U = nullptr, *oc = nullptr, *og = nullptr; void* ws = nullptr;
+    hipError_t e = hipMalloc((void**)&x0, sizeof(double) * nx);
+    if (e == hipSuccess) e = hipMalloc((void**)&U, sizeof(double) * (nU ? nU : 1));
+    if (e == hipSuccess) e = hipMalloc((void**)&oc, sizeof(double) * B);
+    if (e == hipSuccess) e = hipMalloc((void**)&og, sizeof(double) * (nU ? nU : 1));
+    if (e == hipSuccess) e = hipMalloc(&ws, wsb);
+    hipStream_t st = nullptr; hipEvent_t ea = nullptr, eb = nullptr;
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&ea);
+    if (e == hipSuccess) e = hipEventCreate(&eb);
+    if (e == hipSuccess) e = hipMemsetAsync(x0, 0, sizeof(double) * nx, st);
+    if (e == hipSuccess) e = hipMemsetAsync(U, 0, sizeof(double) * (nU ? nU : 1), st);
+    gpmpc_graph_cache* gc = nullptr;
+    int rc = e == hipSuccess ? ensure_graph_cache(p, &gc) : GPMPC_E_ALLOC;
+    gpmpc_cost_params cost;
+    memset(&cost, 0, sizeof(cost));
+    cost.gamma = 0.0;
+    for (int k = 0; k < p->ds; ++k) cost.Q[k * p->ds + k] = 1.0;
+    for (int k = 0; k < p->da; ++k) cost.R[k * p->da + k] = 0.01;
+    const unsigned fl = grad ? GPMPC_WANT_GRAD : 0;
+    const bool was_timing = timing_on();
+    if (was_timing) gpmpc_timing_enable(0);                   // per-kernel events cannot be recorded inside the captures below
+    // ---- time every candidate: one captured graph (or the plain launches), one warm-up, then replays for >= ~2 ms or 3 times ----
+    for (int k = 0; k < nc && rc == GPMPC_OK; ++k) {
+        const Cand& c = cand[k];
+        auto enqueue = [&](hipStream_t s) {
+            return c.S <= 1 ? enqueue_rollout(p, B, H, x0, U, &cost, fl, nullptr, nullptr, oc, og, ws, wsb, s, nullptr, false, &c.r)
+                            : enqueue_split(p, gc, c.S, c.r, s, B, H, x0, U, &cost, fl, nullptr, nullptr, oc, og, ws);
+        };
+        hipGraphExec_t exec = nullptr;
+        if (use_graph) {
+            hipGraph_t graph = nullptr;
+            if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { rc = GPMPC_E_LAUNCH; break; }
+            const int r1 = enqueue(st);
+            const hipError_t e1 = hipStreamEndCapture(st, &graph);
+            if (r1 != GPMPC_OK || e1 != hipSuccess) { if (graph) (void)hipGraphDestroy(graph); cand[k].ms = -1.0; continue; }
+            const hipError_t e2 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (e2 != hipSuccess) { cand[k].ms = -1.0; continue; }
+        }
+        auto run = [&]() { return use_graph ? (hipGraphLaunch(exec, st) == hipSuccess ? GPMPC_OK : GPMPC_E_LAUNCH) : enqueue(st); };
+        int r2 = run();
+        if (r2 == GPMPC_OK && hipStreamSynchronize(st) != hipSuccess) r2 = GPMPC_E_LAUNCH;
+        double best = -1.0;
+        for (int rep = 0; rep < 3 && r2 == GPMPC_OK; ++rep) {     // best of three blocks
+            int n = 1;
+            (void)hipEventRecord(ea, st);
+            r2 = run();
+            (void)hipEventRecord(eb, st);
+            if (hipEventSynchronize(eb) != hipSuccess) { r2 = GPMPC_E_LAUNCH; break; }
+            float ms1 = 0.f; (void)hipEventElapsedTime(&ms1, ea, eb);
+            if (ms1 < 0.7f) {                                     // short call: a block of replays instead of one
+                n = ms1 > 0.f ? (int)(2.0f / ms1) + 1 : 20; if (n > 200) n = 200;
+                (void)hipEventRecord(ea, st);
+                for (int q = 0; q < n && r2 == GPMPC_OK; ++q) r2 = run();
+                (void)hipEventRecord(eb, st);
+                if (hipEventSynchronize(eb) != hipSuccess) { r2 = GPMPC_E_LAUNCH; break; }
+                (void)hipEventElapsedTime(&ms1, ea, eb);
+            }
+            const double per = (double)ms1 / n;
+            if (best < 0.0 || per < best) best = per;
+        }
+        if (exec) (void)hipGraphExecDestroy(exec);
+        cand[k].ms = r2 == GPMPC_OK ? best : -1.0;
+    }
+    (void)hipStreamSynchronize(st);
+    if (was_timing) gpmpc_timing_enable(1);
+    int win = -1;
+    for (int k = 0; k < nc; ++k) if (cand[k].ms > 0.0 && (win < 0 || cand[k].ms < cand[win].ms)) win = k;
+    // the default keeps its place unless a candidate beats it by more than the noise of this measurement (2 %)
+    if (win > 0 && cand[0].ms > 0.0 && cand[win].ms > 0.98 * cand[0].ms) win = 0;
+    if (rc == GPMPC_OK && win >= 0) {
+        gpmpc_tuned_entry& te = tab->e[tab->next % GPMPC_TUNED_SLOTS];
+        tab->next = (tab->next + 1) % GPMPC_TUNED_SLOTS;
+        te.B = B; te.H = H; te.grad = grad ? 1 : 0; te.graph = use_graph ? 1 : 0; te.S = cand[win].S; te.plan = cand[win].r;
+        te.ms_default = cand[0].ms; te.ms_best = cand[win].ms; te.valid = 1;
+        gpmpc_graph_cache_invalidate(p->graph_cache);           // captured under the plan the thresholds chose
+        gpmpc_cb_cache_invalidate(p->cb_cache);
+    }
+    if (report && report_bytes > 0) {
+        size_t off = 0;
+        report[0] = 0;
+        for (int k = 0; k < nc && off + 96 < report_bytes; ++k)
+            off += snprintf(report + off, report_bytes - off, "%s%s:fused=%d,tiling=%d,sb=%d,tb=%d,shared=%d,pwaves=%d,split=%d:%.5f",
+                            k ? ";" : "", k == win ? "*" : "", cand[k].r.fused, cand[k].r.tiling, cand[k].r.sb, cand[k].r.tb, cand[k].r.shared,
+                            cand[k].r.pwaves, cand[k].S, cand[k].ms);
+    }
+    if (ea) (void)hipEventDestroy(ea);
+    if (eb) (void)hipEventDestroy(eb);
+    if (st) (void)hipStreamDestroy(st);
+    if (x0) (void)hipFree(x0);
+    if (U) (void)hipFree(U);
+    if (oc) (void)hipFree(oc);
+    if (og) (void)hipFree(og);
+    if (ws) (void)hipFree(ws);
+    if (e != hipSuccess) { gpmpc_set_error("gpmpc_pack_autotune: scratch", e); return GPMPC_E_ALLOC; }
+    if (rc != GPMPC_OK) return rc;
+    return win < 0 ? GPMPC_E_LAUNCH : nc;
+}
+
+extern "C" int gpmpc_pack_autotune_clear(gpmpc_pack* p) {
+    if (!p) return GPMPC_E_ARG;
+    PackGuard lock(p);
+    if (p->tuned) memset(p->tuned, 0, sizeof(gpmpc_tuned_table));
+    gpmpc_graph_cache_invalidate(p->graph_cache);
+    gpmpc_cb_cache_invalidate(p->cb_cache);
+    return GPMPC_OK;
 }
 
 extern "C" int gpmpc_cost_grad(int B, int H, int ds, int da, const gpmpc_cost_params* cost, const double* means,

@@ -38,6 +38,9 @@ static __device__ unsigned long long g_persist_stamps[64];
 #define GPMPC_PST(slot) do { } while (0)
 #define GPMPC_PSTW(slot) do { } while (0)
 #endif
+#ifndef GPMPC_PERSIST_ILP
+#define GPMPC_PERSIST_ILP 2        // columns whose dependency chains the scheduler may interleave
+#endif
 #ifndef GPMPC_PERSIST_ROTPRIO
 #define GPMPC_PERSIST_ROTPRIO 1
 #endif
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
     __shared__ double s_uin[D], s_sin[D];
     __shared__ double s_B[DS * D], s_Ak[DS * D], s_sc[DS * D], s_cv[DS * D], s_r1[DS * D], s_r2[DS * D];
     __shared__ double s_c[DS], s_cm[DS], s_sf2[DS];
-    __shared__ int s_rng[17];                      // range boundaries of the waves in the flattened column space
+    __shared__ int s_rng[17], s_ga[16];            // range boundaries of the waves in the flattened column space; GP a range starts in
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6), NW = nthr >> 6;
     const int Np = A.Np, T = Np >> 6;
@@ -70,7 +73,11 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
     for (int e = tid; e < D * Np; e += nthr) s_X[e] = A.XT[e];
     for (int e = tid; e < A.H * DA; e += nthr) s_U[e] = A.U[(size_t)b * A.H * DA + e];
     // boundaries on multiples of 8 columns (row blocks start on multiples of 64); computed once (64-bit divisions)
-    if (tid <= NW) s_rng[tid] = tid == NW ? A.total : (int)(((long)A.total * tid / NW + 4) & ~7L);
+    if (tid <= NW) {
+        const int lo = tid == NW ? A.total : (int)(((long)A.total * tid / NW + 4) & ~7L);
+        s_rng[tid] = lo;
+        if (tid < NW) s_ga[tid] = lo / per_gp;
+    }
     const double lam_mine = A.lam[tid < DS * D ? tid : 0];
     if (tid < DS) { s_uin[tid] = A.x0[(size_t)b * DS + tid]; s_sin[tid] = GPMPC_INIT_VAR; }
     if (tid < DS) {
@@ -104,6 +111,15 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
         }
         __syncthreads();
         GPMPC_PST(1);
+        // weights of this thread's points in the mean sums of GP am: requested now, used in 2b
+        constexpr int PT = 4;
+        double bpre[PT];
+#pragma unroll
+        for (int q = 0; q < PT; ++q) {
+            const int i = tg + q * 64 * wpg;
+            const double bv = A.beta[(size_t)(am < DS ? am : 0) * Np + (i < Np ? i : 0)];
+            bpre[q] = (am < DS && i < Np) ? bv : 0.0;
+        }
         // ---- 2a: column rows of every (GP, point) -> scratch (stores in flight while the mean sums run) --------------------------
         for (int e = tid; e < DS * Np; e += nthr) {
             const int a = e / Np, j = e - a * Np;
@@ -132,11 +148,17 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
                 double u[D], Bk[D];
 #pragma unroll
                 for (int k = 0; k < D; ++k) { u[k] = s_uin[k]; Bk[k] = s_B[am * D + k]; }
-                for (int i = tg; i < Np; i += 64 * wpg) {
+                int it = 0;
+                for (int i = tg; i < Np; i += 64 * wpg, ++it) {
                     double d[D], q = 0.0;
 #pragma unroll
                     for (int k = 0; k < D; ++k) { d[k] = u[k] - s_X[k * Np + i]; q = fma(Bk[k] * d[k], d[k], q); }
-                    const double p = A.beta[(size_t)am * Np + i] * exp(-0.5 * q);
+                    double bw = bpre[0];                            // (static indices: the array stays in registers)
+                    if (it == 1) bw = bpre[1];
+                    if (it == 2) bw = bpre[2];
+                    if (it == 3) bw = bpre[3];
+                    if (it >= PT) bw = A.beta[(size_t)am * Np + i];
+                    const double p = bw * exp(-0.5 * q);
                     v[0] += p;
 #pragma unroll
                     for (int k = 0; k < D; ++k) { v[1 + k] = fma(p, d[k], v[1 + k]); v[1 + D + k] = fma(p * d[k], d[k], v[1 + D + k]); }
@@ -246,7 +268,7 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
                         mgb[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, (jc + MG + q) * Np * 8, 0));
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int q = 0; q < MG; ++q) { column(jc + q, mga[q]); if (q & 1) __builtin_amdgcn_sched_barrier(0); }
+                    for (int q = 0; q < MG; ++q) { column(jc + q, mga[q]); if (q % GPMPC_PERSIST_ILP == GPMPC_PERSIST_ILP - 1) __builtin_amdgcn_sched_barrier(0); }
                     {   // unconditional (the last iteration re-requests its own first group, unused): under a branch the compiler's
                         // wait counts merge both paths and every wait below becomes "all loads done"
                         const int jn = jc + 2 * MG < n ? jc + 2 * MG : jc;
@@ -256,7 +278,7 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int q = 0; q < MG; ++q) { column(jc + MG + q, mgb[q]); if (q & 1) __builtin_amdgcn_sched_barrier(0); }
+                    for (int q = 0; q < MG; ++q) { column(jc + MG + q, mgb[q]); if (q % GPMPC_PERSIST_ILP == GPMPC_PERSIST_ILP - 1) __builtin_amdgcn_sched_barrier(0); }
                 }
                 // per-lane combination into the m-moments of this row block (pair_kernel_sb.h), summed over the row blocks of the GP
                 {
@@ -297,8 +319,8 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
             for (int ww = 0; ww < NW; ++ww) {                      // fixed order: waves, their (at most two) GPs, rows as (0 + 1) + (2 + 3)
                 const int lo = s_rng[ww], hi = s_rng[ww + 1];
                 if (lo >= hi) continue;
-                const int a0 = lo / per_gp, a1 = (hi - 1) / per_gp;
-                if (a < a0 || a > a1) continue;
+                const int a0 = s_ga[ww];                           // the range ends in GP a0 or a0 + 1: hi <= (a0 + 2) per_gp
+                if (a != a0 && !(a == a0 + 1 && hi > (a0 + 1) * per_gp)) continue;
                 const double* r4 = &s_part[((ww * 2 + (a - a0)) * 4) * NM + m];
                 sum += (r4[0] + r4[NM]) + (r4[2 * NM] + r4[3 * NM]);
             }

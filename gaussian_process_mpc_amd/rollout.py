@@ -159,6 +159,33 @@ class GPPack:
             out[k] = int(v) if v.lstrip("-").isdigit() else v
         return out
 
+    def autotune(self, B, H, want_grad=True, graph=False):
+        """Time the candidate plans of this call shape on this device and keep the fastest for later calls (C ABI
+        ``gpmpc_pack_autotune``).  Returns a list of dicts (``name``, ``ms``, ``winner``, plan fields), the default plan first."""
+        buf = ctypes.create_string_buffer(8192)
+        flags = (_lib.WANT_GRAD if want_grad else 0) | (_lib.USE_GRAPH if graph else 0)
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize(self.device)
+            rc = lib().gpmpc_pack_autotune(self._h, int(B), int(H), flags, buf, 8192)
+        if rc < 0:
+            check(rc, "gpmpc_pack_autotune")
+        self._graph_bufs = {}
+        self._ws = {}
+        out = []
+        for item in buf.value.decode().split(";"):
+            name, fields, ms = item.split(":")
+            d = {"name": name.lstrip("*"), "winner": name.startswith("*"), "ms": float(ms)}
+            for kv in fields.split(","):
+                k, v = kv.split("=")
+                d[k] = int(v)
+            out.append(d)
+        return out
+
+    def autotune_clear(self):
+        check(lib().gpmpc_pack_autotune_clear(self._h), "gpmpc_pack_autotune_clear")
+        self._graph_bufs = {}
+        self._ws = {}
+
     @property
     def shared_lambda(self):
         """True when every GP of the pack has bit-identical length-scales (the shared-lambda pair kernel applies)."""

@@ -213,6 +213,18 @@ size_t gpmpc_rollout_workspace_bytes(const gpmpc_pack* pack, int B, int H, unsig
  * with GPMPC_USE_GRAPH in `flags` for the split a graph replay would use.  bench.py names its dominant kernel with it, the
  * parity tests check which kernel form a shape reaches.  out_bytes >= 64; returns 0 or GPMPC_E_ARG. */
 int gpmpc_plan_describe(const gpmpc_pack* pack, int B, int H, unsigned flags, char* out, size_t out_bytes);
+/* Plan selection that MEASURES (no reference counterpart).  The kernel form of a rollout call -- tiling, one or two launches per
+ * horizon step or the whole-horizon kernel, trajectories per wave, concurrent sub-batches -- is chosen from thresholds measured on
+ * one MI355X; this call times the candidate plans of ONE call shape (B, H, objective-only or with gradient; GPMPC_USE_GRAPH in
+ * `flags`: as graph replays, else as plain launches) on THIS device with the pack's own data -- each candidate a warm-up and the best
+ * of three timed blocks, on scratch buffers of its own -- and makes the pack remember the fastest (up to 16 shapes; the default plan
+ * stays unless beaten by more than 2 %).  Every plan sums in a fixed order: results stay bit-reproducible per plan, and differ between
+ * plans by rounding only.  Synchronous (tens of milliseconds); not to be called while other host threads use the pack.
+ * `report` (optional): "name:fused=..,tiling=..,...:ms;..." per candidate, the winner marked with '*', the default first.
+ * Returns the number of candidates timed (> 0) or a negative code.  gpmpc_pack_autotune_clear forgets every measured plan; so do
+ * gpmpc_pack_reload_tuning and a gpmpc_pack_build that changes the "all GPs share their length-scales" property. */
+int gpmpc_pack_autotune(gpmpc_pack* pack, int B, int H, unsigned flags, char* report, size_t report_bytes);
+int gpmpc_pack_autotune_clear(gpmpc_pack* pack);
 int gpmpc_rollout(const gpmpc_pack* pack, int B, int H, const double* x0_dev, const double* U_dev,
                   const gpmpc_cost_params* cost_host, unsigned flags,
                   double* out_means, double* out_vars, double* out_cost, double* out_grad,

@@ -8,7 +8,7 @@ cd "$(dirname "$0")/.."
 NAME=$1; TMO=$2; shift 2
 rm -rf .stage/$NAME
 mkdir -p .stage/$NAME gpurun_out
-for d in gaussian_process_mpc_amd oracle tests tools include profiles bench.py __graft_entry__.py BASELINE.json; do
+for d in gaussian_process_mpc_amd oracle tests tools include profiles examples bench.py __graft_entry__.py BASELINE.json *.md; do
     [ -e $d ] && cp -a $d .stage/$NAME/
 done
 rm -rf .stage/$NAME/gaussian_process_mpc_amd/csrc/build* .stage/$NAME/tools/ubench
