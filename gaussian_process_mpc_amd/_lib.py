@@ -61,6 +61,7 @@ SIGNATURES = {
     "gpmpc_pack_graph_captures": (ctypes.c_longlong, [_vp]),
     "gpmpc_build_ky": (_i, [_i, _i, _vp, _dp, _d, _d, _vp, _vp, _vp]),
     "gpmpc_pack_build": (_i, [_vp, _vp, _vp, _vp, _dp, _dp, _vp]),
+    "gpmpc_pack_build_strided": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _dp, _dp, _vp]),
     "gpmpc_pack_build_beta": (_i, [_vp, _vp, _vp, _vp, _dp, _dp, _vp]),
     "gpmpc_pack_enable_fullcov": (_i, [_vp, _vp]),
     "gpmpc_pack_dims": (_i, [_vp] + [ctypes.POINTER(_i)] * 4),
@@ -87,6 +88,8 @@ SIGNATURES = {
     "gpmpc_matvec": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
     "gpmpc_kinv_append_workspace_bytes": (_sz, [_i]),
     "gpmpc_kinv_append": (_i, [_i, _vp, _vp, _d, _vp, _vp, _sz, _vp]),
+    "gpmpc_gp_append_workspace_bytes": (_sz, [_i, _i]),
+    "gpmpc_gp_append": (_i, [_i, _i, _vp, _vp, _dp, _d, _d, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
     "gpmpc_predict_workspace_bytes": (_sz, [_i, _i, _i]),
     "gpmpc_predict": (_i, [_i, _i, _vp, _dp, _d, _vp, _vp, _d, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gpmpc_ml_grad_workspace_bytes": (_sz, [_i, _i]),

@@ -182,15 +182,15 @@ extern "C" int gpmpc_predict(int n, int D, const double* X, const double* lambda
 //   Ky' = [[Ky, k],[k^T, kappa]],   v = Ky_inv k,  w = Ky_inv^T k,  q = 1 / (kappa - k^T v)
 //   Ky'_inv = [[Ky_inv + q v w^T, -q v], [-q w^T, q]]
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_append_vw(const double* __restrict__ Kinv, const double* __restrict__ k, int n,
+__global__ __launch_bounds__(256) void k_append_vw(const double* __restrict__ Kinv, size_t ld, const double* __restrict__ k, int n,
                                                     double* __restrict__ v, double* __restrict__ wv) {
     // row r: v[r] = Kinv[r] . k ; wv[r] = Kinv[:, r] . k  (second read is strided; n^2 doubles once per append)
     __shared__ double s_scr[32], s_out[2];
     const int r = blockIdx.x;
     double acc[2] = {0.0, 0.0};
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        acc[0] = fma(Kinv[(size_t)r * n + i], k[i], acc[0]);
-        acc[1] = fma(Kinv[(size_t)i * n + r], k[i], acc[1]);
+        acc[0] = fma(Kinv[(size_t)r * ld + i], k[i], acc[0]);
+        acc[1] = fma(Kinv[(size_t)i * ld + r], k[i], acc[1]);
     }
     block_sum<2>(acc, s_scr, s_out);
     if (threadIdx.x == 0) { v[r] = s_out[0]; wv[r] = s_out[1]; }
@@ -205,17 +205,40 @@ __global__ __launch_bounds__(256) void k_append_q(const double* __restrict__ k, 
     if (threadIdx.x == 0) q[0] = 1.0 / (kappa - s_out[0]);
 }
 
-__global__ void k_append_fill(const double* __restrict__ Kinv, const double* __restrict__ v, const double* __restrict__ wv,
-                              const double* __restrict__ q, int n, double* __restrict__ out) {
+// Kf_in / Ky_in / Kf_out / Ky_out (optional, all or none): the kernel matrices follow in the same pass -- old block copied, new row and
+// column k, corner kff (+ noise on Ky) -- so that an append is ONE set of launches and no host-side concatenation.
+__global__ void k_append_fill(const double* __restrict__ Kinv, size_t ld_in, const double* __restrict__ v, const double* __restrict__ wv,
+                              const double* __restrict__ q, int n, double* __restrict__ out, size_t ld_out,
+                              const double* __restrict__ k, const double* __restrict__ Kf_in, const double* __restrict__ Ky_in, size_t ld_k,
+                              double* __restrict__ Kf_out, double* __restrict__ Ky_out, double kff, double noise_var) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y, m = n + 1;
     if (j >= m) return;
     const double qq = q[0];
     double val;
-    if (i < n && j < n) val = fma(qq * v[i], wv[j], Kinv[(size_t)i * n + j]);
+    if (i < n && j < n) val = fma(qq * v[i], wv[j], Kinv[(size_t)i * ld_in + j]);
     else if (i < n) val = -qq * v[i];
     else if (j < n) val = -qq * wv[j];
     else val = qq;
-    out[(size_t)i * m + j] = val;
+    out[(size_t)i * ld_out + j] = val;
+    if (Kf_out) {
+        double kf, ky;
+        if (i < n && j < n) { kf = Kf_in[(size_t)i * ld_k + j]; ky = Ky_in[(size_t)i * ld_k + j]; }
+        else if (i < n) { kf = k[i]; ky = kf; }
+        else if (j < n) { kf = k[j]; ky = kf; }
+        else { kf = kff; ky = kff + noise_var; }
+        Kf_out[(size_t)i * ld_out + j] = kf;
+        Ky_out[(size_t)i * ld_out + j] = ky;
+    }
+}
+
+// k[i] = sigma_f^2 exp(-1/2 sum_d (x_i - x_new)_d^2 / lambda_d)   (src/gpr.py:124-135 against every training input)
+__global__ void k_append_kvec(const double* __restrict__ X, int n, int D, const double* __restrict__ xnew, const double* __restrict__ lam,
+                              double sf2, double* __restrict__ k) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double d2 = 0.0;
+    for (int d = 0; d < D; ++d) { const double t = X[(size_t)i * D + d] - xnew[d]; d2 = fma(t * t, 1.0 / lam[d], d2); }
+    k[i] = sf2 * exp(-0.5 * d2);
 }
 
 extern "C" size_t gpmpc_kinv_append_workspace_bytes(int n) { return n < 1 ? 0 : sizeof(double) * (2 * (size_t)n + 8); }
@@ -226,9 +249,39 @@ extern "C" int gpmpc_kinv_append(int n, const double* Kinv_dev, const double* k_
     if (workspace_bytes < gpmpc_kinv_append_workspace_bytes(n)) return GPMPC_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     double* v = (double*)workspace; double* wv = v + n; double* q = wv + n;
-    hipLaunchKernelGGL(k_append_vw, dim3(n), dim3(256), 0, s, Kinv_dev, k_dev, n, v, wv);
+    hipLaunchKernelGGL(k_append_vw, dim3(n), dim3(256), 0, s, Kinv_dev, (size_t)n, k_dev, n, v, wv);
     hipLaunchKernelGGL(k_append_q, dim3(1), dim3(256), 0, s, k_dev, v, n, kappa, q);
-    hipLaunchKernelGGL(k_append_fill, dim3((n + 1 + 255) / 256, n + 1), dim3(256), 0, s, Kinv_dev, v, wv, q, n, out_dev);
+    hipLaunchKernelGGL(k_append_fill, dim3((n + 1 + 255) / 256, n + 1), dim3(256), 0, s, Kinv_dev, (size_t)n, v, wv, q, n, out_dev,
+                       (size_t)(n + 1), (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, (size_t)0, (double*)nullptr,
+                       (double*)nullptr, 0.0, 0.0);
+    GPMPC_HIP(hipGetLastError());
+    return GPMPC_OK;
+}
+
+// The whole data-update of ONE appended observation for a GP kept in capacity-padded buffers (closed loop, src/simulator.py:55 ->
+// src/gpr.py:90-122, :159-171): k = K_f(X, x_new), then Kf, Ky and Ky_inv of the n + 1 points written into the OUTPUT buffers (leading
+// dimension ld_out >= n + 1) from the INPUT buffers (ld_in >= n); input and output must not alias (ping-pong two buffer sets).
+// Four launches, no allocation, no host round trip.
+extern "C" size_t gpmpc_gp_append_workspace_bytes(int n, int D) { return n < 1 ? 0 : sizeof(double) * (3 * (size_t)n + 8 + D + 8); }
+
+extern "C" int gpmpc_gp_append(int n, int D, const double* X_dev, const double* xnew_dev, const double* lambdas_host, double sigma_f,
+                               double noise_var, const double* Kf_in, const double* Ky_in, size_t ld_k_in, const double* Kinv_in, size_t ld_in,
+                               double* Kf_out, double* Ky_out, double* Kinv_out, size_t ld_out, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+    if (n < 1 || D < 1 || D > GPMPC_MAX_D || !X_dev || !xnew_dev || !lambdas_host || !Kf_in || !Ky_in || !Kinv_in || !Kf_out || !Ky_out ||
+        !Kinv_out || !workspace || ld_in < (size_t)n || ld_k_in < (size_t)n || ld_out < (size_t)n + 1)
+        return GPMPC_E_ARG;
+    if (Kf_in == Kf_out || Ky_in == Ky_out || Kinv_in == Kinv_out) return GPMPC_E_ARG;
+    if (workspace_bytes < gpmpc_gp_append_workspace_bytes(n, D)) return GPMPC_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    double* v = (double*)workspace; double* wv = v + n; double* k = wv + n; double* q = k + n; double* lam = q + 8;
+    if (int rcu = gpmpc_upload_small(lam, lambdas_host, sizeof(double) * D, s)) return rcu;
+    const double sf2 = sigma_f * sigma_f;
+    hipLaunchKernelGGL(k_append_kvec, dim3((n + 255) / 256), dim3(256), 0, s, X_dev, n, D, xnew_dev, lam, sf2, k);
+    hipLaunchKernelGGL(k_append_vw, dim3(n), dim3(256), 0, s, Kinv_in, ld_in, k, n, v, wv);
+    hipLaunchKernelGGL(k_append_q, dim3(1), dim3(256), 0, s, k, v, n, sf2 + noise_var, q);
+    hipLaunchKernelGGL(k_append_fill, dim3((n + 1 + 255) / 256, n + 1), dim3(256), 0, s, Kinv_in, ld_in, v, wv, q, n, Kinv_out, ld_out,
+                       (const double*)k, Kf_in, Ky_in, ld_k_in, Kf_out, Ky_out, sf2, noise_var);
     GPMPC_HIP(hipGetLastError());
     return GPMPC_OK;
 }

@@ -18,7 +18,7 @@ __global__ void k_pack_points(const double* __restrict__ X, int N, int Np, int D
 }
 
 // beta_a = Ky_inv_a @ y_a  (src/tools/uncertainty_prop.py:327); one wave per row.
-__global__ __launch_bounds__(256) void k_pack_beta(const double* __restrict__ Kinv, const double* __restrict__ Y,
+__global__ __launch_bounds__(256) void k_pack_beta(const double* __restrict__ Kinv, size_t ld, size_t gstride, const double* __restrict__ Y,
                                                     int N, int Np, int ds, double* __restrict__ beta) {
     const int a = blockIdx.y;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void k_pack_beta(const double* __restrict__ Ki
     if (row >= Np) return;
     double s = 0.0;
     if (row < N) {
-        const double* __restrict__ r = Kinv + ((size_t)a * N + row) * N;
+        const double* __restrict__ r = Kinv + (size_t)a * gstride + (size_t)row * ld;
         for (int j = lane; j < N; j += 64) s = fma(r[j], Y[(size_t)j * ds + a], s);
         s = wave_sum(s);
     }
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void k_pack_beta(const double* __restrict__ Ki
 //   w_ij * ( (Kinv[i][j] + Kinv[j][i])/2 - beta_i beta_j ) * sigma_f^4 * exp(-1/4 sum_k (x_ik - x_jk)^2 / lambda_k)
 // with w = 1 on the diagonal and 2 above it; everything else (lower triangle, padding) is zero.
 // 32x32 tiles staged through LDS so that both Kinv[i][j] and Kinv[j][i] are read coalesced.
-__global__ __launch_bounds__(256) void k_pack_weights(const double* __restrict__ Kinv, const double* __restrict__ beta,
+__global__ __launch_bounds__(256) void k_pack_weights(const double* __restrict__ Kinv, size_t ld, size_t gstride, const double* __restrict__ beta,
                                                        const double* __restrict__ XT, const double* __restrict__ lam,
                                                        const double* __restrict__ sf, int N, int Np, int D,
                                                        double* __restrict__ M) {
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void k_pack_weights(const double* __restrict__
     const int a = blockIdx.z;
     const int ti = blockIdx.x * 32, tj = blockIdx.y * 32;   // tile origin: rows i in [ti,ti+32), cols j in [tj,tj+32)
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
-    const double* __restrict__ Ka = Kinv + (size_t)a * N * N;
+    const double* __restrict__ Ka = Kinv + (size_t)a * gstride;
     double* __restrict__ Ma = M + (size_t)a * Np * Np;
     if (tj + 31 < ti) {   // strictly below the diagonal
         for (int r = ty; r < 32; r += 8) {
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k_pack_weights(const double* __restrict__
     // s_t[r][c] = Kinv[ti + r][tj + c]  (row-major read, coalesced over c)
     for (int r = ty; r < 32; r += 8) {
         const int i = ti + r, j = tj + tx;
-        s_t[r][tx] = (i < N && j < N) ? Ka[(size_t)i * N + j] : 0.0;
+        s_t[r][tx] = (i < N && j < N) ? Ka[(size_t)i * ld + j] : 0.0;
     }
     __syncthreads();
     const double sf2 = sf[a] * sf[a], sf4 = sf2 * sf2;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void k_pack_weights(const double* __restrict__
         if (j >= Np || i >= Np) continue;
         double out = 0.0;
         if (i <= j && j < N) {
-            const double kji = Ka[(size_t)j * N + i];        // coalesced over i
+            const double kji = Ka[(size_t)j * ld + i];       // coalesced over i
             const double kij = s_t[tx][r];
             double d2 = 0.0;
             for (int k = 0; k < D; ++k) {
@@ -343,10 +343,14 @@ __global__ void k_pack_copy_beta(const double* __restrict__ Bsrc, int N, int Np,
     if (i < Np) beta[(size_t)a * Np + i] = i < N ? Bsrc[(size_t)i * ds + a] : 0.0;
 }
 
+// ld / gstride: row stride of a Ky_inv matrix and the stride from one GP's matrix to the next, in doubles (0, 0 = packed [ds][N][N];
+// gstride 0 with ld > 0: ONE matrix for every GP -- GPs with identical hyper-parameters and inputs share Ky_inv, src/gpr.py:159-171)
 static int pack_build_impl(gpmpc_pack* p, const double* X_dev, const double* Y_dev, bool y_is_beta,
                            const double* Ky_inv_dev, const double* lambdas_host, const double* sigma_f_host,
-                           void* stream) {
+                           void* stream, size_t ld = 0, size_t gstride = 0) {
     if (!p || !X_dev || !Y_dev || !lambdas_host || !sigma_f_host) return GPMPC_E_ARG;
+    if (ld == 0) { ld = (size_t)p->N; gstride = (size_t)p->N * p->N; }
+    if (ld < (size_t)p->N) return GPMPC_E_ARG;
     if (int rc_dev = gpmpc_check_device(p)) return rc_dev;
     if (!Ky_inv_dev && !y_is_beta) return GPMPC_E_ARG;
     hipStream_t s = (hipStream_t)stream;
@@ -377,10 +381,10 @@ static int pack_build_impl(gpmpc_pack* p, const double* X_dev, const double* Y_d
     if (y_is_beta)
         hipLaunchKernelGGL(k_pack_copy_beta, dim3((p->Np + 255) / 256, p->ds), dim3(256), 0, s, Y_dev, p->N, p->Np, p->ds, p->beta);
     else
-        hipLaunchKernelGGL(k_pack_beta, dim3((p->Np + 3) / 4, p->ds), dim3(256), 0, s, Ky_inv_dev, Y_dev, p->N, p->Np, p->ds, p->beta);
+        hipLaunchKernelGGL(k_pack_beta, dim3((p->Np + 3) / 4, p->ds), dim3(256), 0, s, Ky_inv_dev, ld, gstride, Y_dev, p->N, p->Np, p->ds, p->beta);
     if (Ky_inv_dev)
         hipLaunchKernelGGL(k_pack_weights, dim3(p->Np / 32, p->Np / 32, p->ds), dim3(256), 0, s,
-                           Ky_inv_dev, p->beta, p->XT, p->lam, p->sf, p->N, p->Np, p->D, p->M);
+                           Ky_inv_dev, ld, gstride, p->beta, p->XT, p->lam, p->sf, p->N, p->Np, p->D, p->M);
     else
         GPMPC_HIP(hipMemsetAsync(p->M, 0, sizeof(double) * (size_t)p->Np * p->Np * p->ds, s));
     if (p->fullcov && p->npairs > 0)
@@ -420,6 +424,12 @@ extern "C" int gpmpc_pack_enable_fullcov(gpmpc_pack* p, void* stream) {
 extern "C" int gpmpc_pack_build(gpmpc_pack* p, const double* X_dev, const double* Y_dev, const double* Ky_inv_dev,
                                 const double* lambdas_host, const double* sigma_f_host, void* stream) {
     return pack_build_impl(p, X_dev, Y_dev, false, Ky_inv_dev, lambdas_host, sigma_f_host, stream);
+}
+
+extern "C" int gpmpc_pack_build_strided(gpmpc_pack* p, const double* X_dev, const double* Y_dev, const double* Ky_inv_dev,
+                                        size_t ld, size_t gp_stride, const double* lambdas_host, const double* sigma_f_host, void* stream) {
+    if (!Ky_inv_dev || ld == 0) return GPMPC_E_ARG;
+    return pack_build_impl(p, X_dev, Y_dev, false, Ky_inv_dev, lambdas_host, sigma_f_host, stream, ld, gp_stride);
 }
 
 extern "C" int gpmpc_pack_build_beta(gpmpc_pack* p, const double* X_dev, const double* beta_dev, const double* Ky_inv_dev,

@@ -1063,11 +1063,27 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     // Whole-horizon kernel, one workgroup per trajectory (traj_persist.h): large batches of a small training set -- at least about one
     // trajectory per CU, X within the kernel's LDS budget.  r->fused = 3; r->pwaves = waves per workgroup.
     r->pwaves = 0;
-    if (diag && !lowprec && p->da >= 1 && p->da <= 2 && p->Np <= GPMPC_PERSIST_MAXNP_HOST && H * p->da <= 1024 && tn.persist != 0 &&
-        (tn.persist > 0 || (B >= (3 * p->num_cu) / 4 && p->Np <= 640))) {
-        r->fused = 3; r->sb = 0; r->shared = 0; r->tb = 1; r->rgroup = 1; r->colunroll = 1; r->fq = 1;
-        r->pwaves = tn.persist == 8 ? 8 : 16;
-        r->nwork = 0;
+    // Measured against the step-per-launch plan (tools/lib_ab.py, profiles/r04/ab_persist.txt; ms per batch, H = 10, default | 16 waves |
+    // 8 waves): N = 300, ds = 4: B = 128 0.70 | 0.92 | 1.29, B = 192 1.34 | 0.95 | 1.48, B = 256 1.31 | 0.99 | 1.56, B = 384 1.72 | 1.83 | 1.77,
+    // B = 512 2.11 | 1.93 | 1.80; N = 300, ds = 2, B = 256 0.57 | 0.43 | 0.47; N = 200, ds = 2, B = 1024 0.58 | 0.57 | 0.48; N = 400, ds = 3,
+    // da = 2, B = 256 2.11 | 1.68 | 2.54; N = 512, ds = 3, H = 20, B = 256 3.01 | 2.49 | 4.11; N = 640, B = 256 2.75 | 3.03; N = 1024,
+    // H = 20, B = 256 10.9 | 14.4 (every workgroup streams all of M from L2 / Infinity Cache each step: 6.5 TB/s at N = 1024).
+    // One 16-wave workgroup per CU, so the cost goes in generations of num_cu trajectories: taken while the last generation is
+    // at least ~0.7 (one generation) / ~0.9 full; 8-wave workgroups (two per CU) from two full sets on.
+    {
+        const int cu = p->num_cu > 0 ? p->num_cu : 256;
+        const int g16 = (B + cu - 1) / cu, g8 = (B + 2 * cu - 1) / (2 * cu);
+        const double fill16 = (double)B / ((double)g16 * cu), fill8 = (double)B / ((double)g8 * 2 * cu);
+        int pw = 0;
+        if (fill8 >= 0.9) pw = 8;
+        else if (fill16 >= (g16 == 1 ? 0.7 : 0.9)) pw = 16;
+        if (tn.persist == 8 || tn.persist == 16) pw = tn.persist;
+        if (diag && !lowprec && p->da >= 1 && p->da <= 2 && p->Np <= GPMPC_PERSIST_MAXNP_HOST && H * p->da <= 1024 && tn.persist != 0 &&
+            pw && (tn.persist > 0 || p->Np <= 512)) {
+            r->fused = 3; r->sb = 0; r->shared = 0; r->tb = 1; r->rgroup = 1; r->colunroll = 1; r->fq = 1;
+            r->pwaves = pw;
+            r->nwork = 0;
+        }
     }
     if (shape) { r->fused = shape->fused; r->pwaves = shape->pwaves; if (r->fused == 3) { r->sb = 0; r->shared = 0; r->nwork = 0; } }
     r->nm = gpmpc_num_moments(D, diag, grad);
@@ -1742,6 +1758,7 @@ extern "C" int gpmpc_rollout(const gpmpc_pack* p, int B, int H, const double* x0
 // Plan selection that measures: time the candidate plans of ONE call shape on this device and keep the winner
 // ---------------------------------------------------------------------------
 static bool same_shape(const RollPlan& a, const RollPlan& b) {
+    if (a.fused == 3 && b.fused == 3) return a.pwaves == b.pwaves;          // the whole-horizon kernel has no tiling
     return a.tiling == b.tiling && a.tb == b.tb && a.sb == b.sb && a.fused == b.fused && a.fq == b.fq && a.shared == b.shared &&
            a.sh_list == b.sh_list && a.fng == b.fng && a.colunroll == b.colunroll && a.hchunks == b.hchunks && a.pwaves == b.pwaves &&
            a.rgroup == b.rgroup && a.nwork == b.nwork;
@@ -1767,7 +1784,7 @@ extern "C" int gpmpc_pack_autotune(gpmpc_pack* p, int B, int H, unsigned flags, 
         int S = split_count(p, r, B, false, !use_graph, split);
         if (S > 1 && r.fused == 3) S = 1;
         for (int k = 0; k < nc; ++k) if (same_shape(cand[k].r, r) && cand[k].S == S) return;
-        cand[nc].r = r; cand[nc].S = S; cand[nc].ms = -1.0; cand[nc].why = why; ++nc;
+        cand[nc].r = r; cand[nc].S = S; cand[nc].ms = 0.0; cand[nc].why = why; ++nc;
     };
     const gpmpc_tuning base = p->tune;
     add(base, 0, "default");
@@ -1810,7 +1827,9 @@ extern "C" int gpmpc_pack_autotune(gpmpc_pack* p, int B, int H, unsigned flags, 
     const bool was_timing = timing_on();
     if (was_timing) gpmpc_timing_enable(0);                   // per-kernel events cannot be recorded inside the captures below
     // ---- time every candidate: one captured graph (or the plain launches), one warm-up, then replays for >= ~2 ms or 3 times ----
-    for (int k = 0; k < nc && rc == GPMPC_OK; ++k) {
+    for (int pass = 0; pass < 2; ++pass)                          // two passes, the better time of each candidate: the first launches of a
+    for (int k = 0; k < nc && rc == GPMPC_OK; ++k) {              // process (code upload, cold caches) must not be charged to the default plan
+        if (pass == 1 && cand[k].ms < 0.0) continue;              // failed to enqueue in the first pass
         const Cand& c = cand[k];
         auto enqueue = [&](hipStream_t s) {
             return c.S <= 1 ? enqueue_rollout(p, B, H, x0, U, &cost, fl, nullptr, nullptr, oc, og, ws, wsb, s, nullptr, false, &c.r)
@@ -1850,7 +1869,8 @@ extern "C" int gpmpc_pack_autotune(gpmpc_pack* p, int B, int H, unsigned flags, 
             if (best < 0.0 || per < best) best = per;
         }
         if (exec) (void)hipGraphExecDestroy(exec);
-        cand[k].ms = r2 == GPMPC_OK ? best : -1.0;
+        if (r2 != GPMPC_OK) cand[k].ms = -1.0;
+        else if (pass == 0 || best < cand[k].ms) cand[k].ms = best;
     }
     (void)hipStreamSynchronize(st);
     if (was_timing) gpmpc_timing_enable(1);
@@ -1870,8 +1890,8 @@ extern "C" int gpmpc_pack_autotune(gpmpc_pack* p, int B, int H, unsigned flags, 
         size_t off = 0;
         report[0] = 0;
         for (int k = 0; k < nc && off + 96 < report_bytes; ++k)
-            off += snprintf(report + off, report_bytes - off, "%s%s:fused=%d,tiling=%d,sb=%d,tb=%d,shared=%d,pwaves=%d,split=%d:%.5f",
-                            k ? ";" : "", k == win ? "*" : "", cand[k].r.fused, cand[k].r.tiling, cand[k].r.sb, cand[k].r.tb, cand[k].r.shared,
+            off += snprintf(report + off, report_bytes - off, "%s%s%s:fused=%d,tiling=%d,sb=%d,tb=%d,shared=%d,pwaves=%d,split=%d:%.5f",
+                            k ? ";" : "", k == win ? "*" : "", cand[k].why, cand[k].r.fused, cand[k].r.tiling, cand[k].r.sb, cand[k].r.tb, cand[k].r.shared,
                             cand[k].r.pwaves, cand[k].S, cand[k].ms);
     }
     if (ea) (void)hipEventDestroy(ea);

@@ -67,14 +67,16 @@ class Dynamics(object):
                 g.append_train_data(x, y, incremental=incremental)
         else:
             modes = []
-            for g, y in zip(self.gpr_err, ys):
+            # one device copy of the new input rows and one of ALL targets for the ds GPs (they were 2 ds host-to-device copies)
+            shared = {"y_all": torch.tensor(np.asarray(next_state, dtype=np.float64).reshape(-1, self.state_dim)).to(self.device)}
+            for a, (g, y) in enumerate(zip(self.gpr_err, ys)):
                 if not np.isscalar(y) and np.ndim(y) > 0:
                     n_obs, yy = len(y), np.asarray(y)[:, None]
                     xx = x
                 else:
                     n_obs, yy = 1, np.array([y])[:, None]
                     xx = np.reshape(x, (1, g.x_dim))
-                modes.append(g._ingest(xx, yy, n_obs, incremental))
+                modes.append(g._ingest(xx, yy, n_obs, incremental, shared=shared, column=a))
             GaussianProcessRegression.update_many(self.gpr_err, modes)
         self._seen_X = [g.X_train for g in self.gpr_err]
 
@@ -102,7 +104,10 @@ class Dynamics(object):
             if g0.num_train == 0:
                 raise RuntimeError("no training data")
             Y = torch.cat([g.y_train.reshape(-1, 1) for g in self.gpr_err], dim=1)
-            Kinv = torch.stack([g.Ky_inv.detach() for g in self.gpr_err])
+            if all(g.Ky_inv is g0.Ky_inv for g in self.gpr_err):
+                Kinv = g0.Ky_inv.detach()               # GPs with identical hyper-parameters share ONE inverse: read in place, no stack
+            else:
+                Kinv = torch.stack([g.Ky_inv.detach() for g in self.gpr_err])
             lam = np.stack([g.get_lambdas() for g in self.gpr_err])
             sf = np.array([g.get_sigma_f() for g in self.gpr_err])
             # the closed loop appends one observation per step: refill the existing pack while its padded size fits

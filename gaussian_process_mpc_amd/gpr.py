@@ -110,14 +110,31 @@ class GaussianProcessRegression(object):
         else:
             self.build_Ky_inv_mat()
 
-    def _ingest(self, x, y, num_obs, incremental):
-        """Store the new rows (src/gpr.py:109-119) and say how the matrices have to follow: "incremental" or "full"."""
-        x = torch.tensor(np.asarray(x), requires_grad=False).type(torch.float64).to(self.device)
-        y = torch.tensor(y, requires_grad=False).type(torch.float64).to(self.device)
+    def _ingest(self, x, y, num_obs, incremental, shared=None, column=0):
+        """Store the new rows (src/gpr.py:109-119) and say how the matrices have to follow: "incremental" or "full".
+        shared (optional): a dict carried across the GPs of ONE Dynamics.append_train_data call, which feeds every GP the same
+        input rows: the device copy of x, the concatenated X_train and the device copy of all targets (column `column` is this
+        GP's) are then made once instead of once per GP (each was its own host-to-device copy on every environment step)."""
+        if shared is not None and "x" in shared:
+            x = shared["x"]
+        else:
+            x = torch.tensor(np.asarray(x), requires_grad=False).type(torch.float64).to(self.device)
+            if shared is not None:
+                shared["x"] = x
+        if shared is not None and "y_all" in shared:
+            y = shared["y_all"][:, column:column + 1].contiguous()
+        else:
+            y = torch.tensor(y, requires_grad=False).type(torch.float64).to(self.device)
         if self.num_train == 0:
             self.X_train, self.y_train = x, y
         else:
-            self.X_train = torch.cat((self.X_train, x), dim=0)
+            if shared is not None and shared.get("X_old") is self.X_train:
+                self.X_train = shared["X_new"]                     # the same tensor for every GP that held the same one
+            else:
+                X_new = torch.cat((self.X_train, x), dim=0)
+                if shared is not None:
+                    shared["X_old"], shared["X_new"] = self.X_train, X_new
+                self.X_train = X_new
             self.y_train = torch.cat((self.y_train, y), dim=0)
         # The O(N^2) append is only valid on matrices built with the CURRENT hyper-parameters (the setters do not
         # rebuild, src/gpr.py:53; the reference's append always does, so an edit takes effect there), and its round-off
@@ -183,11 +200,54 @@ class GaussianProcessRegression(object):
         Ky2 = torch.cat((torch.cat((Ky, k.t()), dim=1), torch.cat((k, kff + noise), dim=1)), dim=0)
         return Kf2, Ky2, out
 
+    def _append_buffers(self, n1):
+        """Two sets of capacity-padded (cap, cap) buffers for Kf, Ky, Ky_inv: an append reads the current matrices (views of one set, or
+        the packed tensors of a full rebuild) and writes the (n + 1)-point ones into the OTHER set -- no allocation and no
+        concatenation per step, and the n-point tensors stay intact for whoever still holds them (followers of update_many, a pack
+        being built) until the append after next.  Grown in steps of 256 rows."""
+        cap = getattr(self, "_cap", 0)
+        if cap < n1:
+            cap = ((n1 + 64 + 255) // 256) * 256
+            self._cap = cap
+            self._bufs = [[torch.empty((cap, cap), dtype=torch.float64, device=self.device) for _ in range(3)] for _ in range(2)]
+            self._cur = 1                                       # the next write goes to set 0
+            nb = lib().gpmpc_gp_append_workspace_bytes(cap, self.x_dim)
+            self._append_ws = torch.empty(int(nb), dtype=torch.uint8, device=self.device)
+        return cap
+
     def _append_one_incremental(self, x_new):
         """self.X_train / y_train already hold the new row (last) and num_train counts it; Kf, Ky, Ky_inv still have the
-        old size n."""
+        old size n.  One library call (C ABI ``gpmpc_gp_append``: k = K_f(X, x_new), the Schur step on Ky_inv, the new row /
+        column of Kf and Ky) from the current matrices into the other buffer set."""
         n = self.num_train - 1
-        self.Kf, self.Ky, self.Ky_inv = self._schur_append(self.X_train[:n], x_new, self.Kf, self.Ky, self.Ky_inv)
+        cap = self._append_buffers(n + 1)
+        Kf, Ky, Kinv = self.Kf, self.Ky, self.Ky_inv
+        if not (Kf.stride(1) == 1 and Ky.stride(1) == 1 and Kf.stride(0) == Ky.stride(0)):
+            Kf, Ky = Kf.contiguous(), Ky.contiguous()
+        if Kinv.stride(1) != 1:
+            Kinv = Kinv.contiguous()
+        dst = self._bufs[1 - self._cur]
+        # never write over the set the inputs live in (after a rebuild / refresh the inputs are packed tensors: either set is free)
+        base = [t.untyped_storage().data_ptr() for t in (Kf, Ky, Kinv)]
+        if any(d.untyped_storage().data_ptr() in base for d in dst):
+            dst = self._bufs[self._cur]
+            if any(d.untyped_storage().data_ptr() in base for d in dst):
+                raise RuntimeError("incremental append: both buffer sets alias the current matrices")
+            self._cur = 1 - self._cur
+        X_old = self.X_train[:n]
+        if not X_old.is_contiguous():
+            X_old = X_old.contiguous()
+        xn = x_new.reshape(1, self.x_dim).contiguous()
+        _, lp = host_doubles(self.get_lambdas())
+        vp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        with torch.cuda.device(self.device):
+            check(lib().gpmpc_gp_append(n, self.x_dim, ptr(X_old), ptr(xn), lp, self.get_sigma_f(), self._noise_var(),
+                                        vp(Kf), vp(Ky), Kf.stride(0), vp(Kinv), Kinv.stride(0),
+                                        vp(dst[0]), vp(dst[1]), vp(dst[2]), cap,
+                                        ctypes.c_void_p(self._append_ws.data_ptr()), self._append_ws.numel(), stream_ptr(self.device)),
+                  "gpmpc_gp_append")
+        self._cur = 1 - self._cur
+        self.Kf, self.Ky, self.Ky_inv = dst[0][:n + 1, :n + 1], dst[1][:n + 1, :n + 1], dst[2][:n + 1, :n + 1]
         self._beta = None
         self.version += 1
         self._appends_since_rebuild += 1

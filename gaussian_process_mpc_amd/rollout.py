@@ -70,8 +70,19 @@ class GPPack:
         self.N, self.D = self.X.shape
         self.ds = self.Y.shape[1]
         self.da = self.D - self.ds
+        ld = gstride = 0
         if Ky_inv is not None:
-            Ky_inv = _dev(Ky_inv, self.device).reshape(self.ds, self.N, self.N)
+            Kt = Ky_inv if isinstance(Ky_inv, torch.Tensor) else None
+            if (Kt is not None and Kt.is_cuda and Kt.device == self.device and Kt.dtype == torch.float64 and not Kt.is_contiguous()
+                    and Kt.stride(-1) == 1 and Kt.shape[-2:] == (self.N, self.N) and (Kt.dim() == 2 or (Kt.dim() == 3 and Kt.shape[0] == self.ds))):
+                # a view of a capacity-padded buffer (closed loop) and / or ONE matrix shared by all GPs: read in place
+                ld, gstride = Kt.stride(-2), (0 if Kt.dim() == 2 else Kt.stride(0))
+                Ky_inv = Kt
+            elif Kt is not None and Kt.dim() == 2 and self.ds > 1 and tuple(Kt.shape) == (self.N, self.N):
+                Ky_inv = _dev(Kt, self.device)          # one contiguous matrix shared by all GPs
+                ld, gstride = self.N, 0
+            else:
+                Ky_inv = _dev(Ky_inv, self.device).reshape(self.ds, self.N, self.N)
         self.lambdas = np.ascontiguousarray(np.asarray(lambdas, dtype=np.float64).reshape(self.ds, self.D))
         self.sigma_f = np.ascontiguousarray(np.asarray(sigma_f, dtype=np.float64).reshape(self.ds))
         if self._h is None:
@@ -82,8 +93,14 @@ class GPPack:
         _, lp = host_doubles(self.lambdas)
         _, sp = host_doubles(self.sigma_f)
         with torch.cuda.device(self.device):
-            build = lib().gpmpc_pack_build_beta if y_is_beta else lib().gpmpc_pack_build
-            check(build(self._h, ptr(self.X), ptr(self.Y), ptr(Ky_inv), lp, sp, stream_ptr()), "gpmpc_pack_build")
+            if ld and not y_is_beta:
+                check(lib().gpmpc_pack_build_strided(self._h, ptr(self.X), ptr(self.Y), ctypes.c_void_p(Ky_inv.data_ptr()), ld, gstride,
+                                                     lp, sp, stream_ptr()), "gpmpc_pack_build_strided")
+            else:
+                if ld:                                  # (beta given: the strided entry takes targets only)
+                    Ky_inv = Ky_inv.contiguous() if Ky_inv.dim() == 3 else Ky_inv.contiguous().unsqueeze(0).expand(self.ds, -1, -1).contiguous()
+                build = lib().gpmpc_pack_build_beta if y_is_beta else lib().gpmpc_pack_build
+                check(build(self._h, ptr(self.X), ptr(self.Y), ptr(Ky_inv), lp, sp, stream_ptr()), "gpmpc_pack_build")
         n, npad, ds, da = (ctypes.c_int() for _ in range(4))
         lib().gpmpc_pack_dims(self._h, ctypes.byref(n), ctypes.byref(npad), ctypes.byref(ds), ctypes.byref(da))
         self.Np = npad.value

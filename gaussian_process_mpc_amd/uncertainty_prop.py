@@ -86,7 +86,7 @@ def covariance_prop_torch(lambdas1, lambdas2, u, S, X_train, mean1, mean2, beta1
     """Cov[f1, f2] -- src/tools/uncertainty_prop.py:402-465.  The reference's cross term (:446) is
     index-transposed; ``bug_compatible=True`` (default) reproduces it, ``False`` gives the consistent
     form that matches the reference's numpy ``covariance_prop``.  Only the betas enter (rank-one
-    weights), so the pack is built without Ky_inv.  Without a graph mean1 / mean2 are recomputed on the device; when ``u``, ``S``,
+    weights), so the pack is built without Ky_inv.  ``mean1 * mean2`` is subtracted as given (:465).  When ``u``, ``S``,
     ``mean1`` or ``mean2`` requires grad the result carries the reference's graph (``autograd.CrossCovFunction``: analytic
     d/du, d/dS of beta1^T Qt beta2 from the device, minus the product of the caller's means in torch)."""
     l1, l2 = _np(lambdas1), _np(lambdas2)
@@ -103,4 +103,9 @@ def covariance_prop_torch(lambdas1, lambdas2, u, S, X_train, mean1, mean2, beta1
         m1 = torch.as_tensor(mean1).to(dev, torch.float64).reshape(())
         m2 = torch.as_tensor(mean2).to(dev, torch.float64).reshape(())
         return q - m1 * m2
-    return moment_match(pack, u, S, want_cov=True, bug_compatible=bug_compatible)["cov"][0, 0, 1]
+    r = moment_match(pack, u, S, want_cov=True, bug_compatible=bug_compatible)
+    # the reference subtracts the product of the means it is GIVEN (:465): beta1^T Qt beta2 from the device, the caller's means here
+    q = r["cov"][0, 0, 1] + r["mean"][0, 0] * r["mean"][0, 1]
+    m1 = torch.as_tensor(mean1).detach().to(q.device, torch.float64).reshape(())
+    m2 = torch.as_tensor(mean2).detach().to(q.device, torch.float64).reshape(())
+    return q - m1 * m2

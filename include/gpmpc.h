@@ -108,6 +108,13 @@ int gpmpc_pack_build(gpmpc_pack* pack, const double* X_dev, const double* Y_dev,
                      const double* Ky_inv_dev, const double* lambdas_host,
                      const double* sigma_f_host, void* stream);
 
+/* Same for inverses that are NOT packed [ds][N][N]: row stride `ld` (>= N) and the stride `gp_stride` from one GP's matrix to
+ * the next, both in doubles.  gp_stride = 0: ONE matrix for every GP (GPs fed the same inputs under identical hyper-parameters
+ * have identical Ky_inv -- every experiment of the reference, src/experiments/pretrain_uncertainty.py:100-105 -- and a capacity-padded
+ * buffer that grows by one observation per Simulator step, src/simulator.py:55, is read in place instead of being copied). */
+int gpmpc_pack_build_strided(gpmpc_pack* pack, const double* X_dev, const double* Y_dev, const double* Ky_inv_dev,
+                             size_t ld, size_t gp_stride, const double* lambdas_host, const double* sigma_f_host, void* stream);
+
 /* Same, with beta given instead of the targets: beta dev [N][ds] (column a = beta_a), as the callers of
  * variance_prop_torch / covariance_prop_torch hold it (src/tools/uncertainty_prop.py:341, :402).
  * Ky_inv may be NULL: the weight matrices are then zero and only means and cross-covariances
@@ -307,6 +314,18 @@ int gpmpc_predict(int n, int D, const double* X_dev, const double* lambdas_host,
 size_t gpmpc_kinv_append_workspace_bytes(int n);
 int gpmpc_kinv_append(int n, const double* Ky_inv_dev, const double* k_dev, double kappa, double* out_dev,
                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* The whole data update of ONE appended observation for a GP kept in CAPACITY-PADDED buffers (closed loop: src/simulator.py:55 ->
+ * src/gpr.py:90-122 store the row, :159-171 rebuild Kf, Ky and invert): k = K_f(X, x_new) (src/gpr.py:124-135), then Kf, Ky and
+ * Ky_inv of the n + 1 points -- the Schur step of gpmpc_kinv_append -- written into the OUTPUT buffers (row stride ld_out >= n + 1)
+ * from the INPUT buffers (row strides ld_k_in of Kf / Ky and ld_in of Ky_inv, >= n).  Inputs and outputs must not alias: the caller ping-pongs two buffer sets, so the
+ * n-point matrices stay valid for whoever still reads them.  X dev [n][D] (the n OLD rows), x_new dev [D], lambdas host [D].
+ * Four kernel launches, no allocation, no host-side concatenation. */
+size_t gpmpc_gp_append_workspace_bytes(int n, int D);
+int gpmpc_gp_append(int n, int D, const double* X_dev, const double* x_new_dev, const double* lambdas_host, double sigma_f,
+                    double noise_var, const double* Kf_in, const double* Ky_in, size_t ld_k_in, const double* Ky_inv_in, size_t ld_in,
+                    double* Kf_out, double* Ky_out, double* Ky_inv_out, size_t ld_out, void* workspace, size_t workspace_bytes,
+                    void* stream);
 
 /* Gradient of the log marginal likelihood w.r.t. the LOG hyper-parameters in one pass over Ky_inv: replaces the autograd
  * backward through inv / det of update_hyperparams (src/gpr.py:334-338; likelihood src/gpr.py:240-251) and the dense

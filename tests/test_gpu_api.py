@@ -720,3 +720,78 @@ def test_update_Ky_inv_mat_block_inverse(G):
     gp.update_Ky_inv_mat(k)
     assert gp.Ky_inv.shape == (n + 1, n + 1)
     np.testing.assert_allclose(gp.Ky_inv.cpu().numpy() @ full, np.eye(n + 1), rtol=0, atol=1e-9)
+
+
+def test_autotune_measures_and_keeps_the_fastest_plan(G):
+    """gpmpc_pack_autotune: candidates are timed on the device, the winner is remembered for that call shape only, results under the
+    tuned plan agree with the default plan's to rounding and are bit-reproducible; autotune_clear restores the thresholds' choice."""
+    from gaussian_process_mpc_amd.synth import synth_problem
+    from oracle import gpmpc_oracle as O
+    pb = synth_problem(77, 300, 2, 1, 6, 64)
+    kinv = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"]).Ky_inv.numpy()
+    pack = G.GPPack(pb["X"], pb["Y"], kinv, pb["lambdas"], pb["sigma_f"])
+    cost = G.CostParams(-1.0, pb["Q"], pb["R"])
+    before, other_before = pack.plan(64, 6), pack.plan(32, 6)
+    r0 = G.rollout(pack, pb["x0"], pb["U"], cost)
+    res = pack.autotune(64, 6)
+    timed = [c for c in res if c["ms"] > 0]
+    assert len(timed) >= 3 and sum(c["winner"] for c in res) == 1
+    win = next(c for c in res if c["winner"])
+    assert win["ms"] <= min(c["ms"] for c in timed) * 1.0000001 or win is res[0]      # the fastest, or the default within 2 % of it
+    assert res[0]["ms"] > 0 and res[0]["name"] == "default"
+    r1 = G.rollout(pack, pb["x0"], pb["U"], cost)
+    r2 = G.rollout(pack, pb["x0"], pb["U"], cost)
+    for k in r1:
+        assert torch.equal(r1[k], r2[k]), k
+    np.testing.assert_allclose(r1["means"].cpu().numpy(), r0["means"].cpu().numpy(), rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(r1["vars"].cpu().numpy(), r0["vars"].cpu().numpy(), rtol=1e-5)
+    np.testing.assert_allclose(r1["grad"].cpu().numpy(), r0["grad"].cpu().numpy(), rtol=1e-4, atol=1e-8)
+    assert pack.plan(32, 6) == other_before                           # other call shapes keep the thresholds' choice
+    pack.autotune_clear()
+    assert pack.plan(64, 6) == before
+    r3 = G.rollout(pack, pb["x0"], pb["U"], cost)
+    for k in r0:
+        assert torch.equal(r0[k], r3[k]), k
+
+
+def test_gp_append_into_padded_buffers_and_strided_pack_build(G):
+    """C ABI gpmpc_gp_append (one call: k vector, Schur step on Ky_inv, new row / column of Kf and Ky, written into buffers of another
+    leading dimension) against torch on the n + 1 points, and gpmpc_pack_build_strided: a pack built from a strided view / ONE shared
+    inverse equals the pack built from packed copies bit for bit."""
+    import ctypes
+    from gaussian_process_mpc_amd._lib import lib, ptr, stream_ptr, host_doubles, check
+    dev = G.require_gpu()
+    rng = np.random.default_rng(5)
+    n, D, cap = 75, 3, 128
+    X = torch.tensor(rng.uniform(-2, 2, (n + 1, D)), device=dev)
+    lam, sf, noise = np.array([0.7, 1.3, 2.0]), 1.2, 1e-2
+    d2 = ((X[:, None, :] - X[None, :, :]) ** 2 / torch.tensor(lam, device=dev)).sum(-1)
+    Kf_full = sf ** 2 * torch.exp(-0.5 * d2)
+    Ky_full = Kf_full + noise * torch.eye(n + 1, dtype=torch.float64, device=dev)
+    Kf, Ky = Kf_full[:n, :n].contiguous(), Ky_full[:n, :n].contiguous()
+    Kinv = torch.linalg.inv(Ky)
+    out = [torch.full((cap, cap), float("nan"), dtype=torch.float64, device=dev) for _ in range(3)]
+    nb = lib().gpmpc_gp_append_workspace_bytes(n, D)
+    ws = torch.empty(int(nb), dtype=torch.uint8, device=dev)
+    _, lp = host_doubles(lam)
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    check(lib().gpmpc_gp_append(n, D, ptr(X[:n].contiguous()), ptr(X[n:n + 1].contiguous()), lp, sf, noise, vp(Kf), vp(Ky), n, vp(Kinv), n,
+                                vp(out[0]), vp(out[1]), vp(out[2]), cap, ctypes.c_void_p(ws.data_ptr()), ws.numel(), stream_ptr()), "gpmpc_gp_append")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out[0][:n + 1, :n + 1].cpu().numpy(), Kf_full.cpu().numpy(), rtol=1e-14, atol=1e-15)
+    np.testing.assert_allclose(out[1][:n + 1, :n + 1].cpu().numpy(), Ky_full.cpu().numpy(), rtol=1e-14, atol=1e-15)
+    ref = torch.linalg.inv(Ky_full)
+    np.testing.assert_allclose(out[2][:n + 1, :n + 1].cpu().numpy(), ref.cpu().numpy(), rtol=1e-7, atol=1e-9 * float(ref.abs().max()))
+    assert torch.isnan(out[2][n + 1:, :]).all() and torch.isnan(out[2][:, n + 1:]).all()          # nothing beyond the (n + 1) block is touched
+    # argument checks: aliasing and too small a leading dimension
+    assert lib().gpmpc_gp_append(n, D, ptr(X[:n].contiguous()), ptr(X[n:n + 1].contiguous()), lp, sf, noise, vp(Kf), vp(Ky), n, vp(Kinv), n,
+                                 vp(Kf), vp(out[1]), vp(out[2]), cap, ctypes.c_void_p(ws.data_ptr()), ws.numel(), stream_ptr()) == -1
+    assert lib().gpmpc_gp_append(n, D, ptr(X[:n].contiguous()), ptr(X[n:n + 1].contiguous()), lp, sf, noise, vp(Kf), vp(Ky), n, vp(Kinv), n,
+                                 vp(out[0]), vp(out[1]), vp(out[2]), n, ctypes.c_void_p(ws.data_ptr()), ws.numel(), stream_ptr()) == -1
+    # strided pack build: a view of the padded buffer, shared by two GPs, against packed copies
+    Y = torch.tensor(rng.normal(size=(n + 1, 2)), device=dev)
+    lam2 = np.stack((lam, lam))
+    view = out[2][:n + 1, :n + 1]
+    p_view = G.GPPack(X, Y, view, lam2, np.array([sf, sf]))
+    p_copy = G.GPPack(X, Y, torch.stack((view.contiguous(), view.contiguous())), lam2, np.array([sf, sf]))
+    assert torch.equal(p_view.weights(), p_copy.weights()) and torch.equal(p_view.beta(), p_copy.beta())

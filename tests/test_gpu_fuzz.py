@@ -53,6 +53,40 @@ def test_fuzz_diagonal_rollout_vs_cport(G, seed):
         assert cg[0] == r["cost"][0].item() and np.array_equal(cg[1:], r["grad"][0].cpu().numpy().reshape(-1)), tag
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_whole_horizon_form_vs_cport(G, seed):
+    """Batches of about one trajectory per CU and more: the plan is the whole-horizon kernel (csrc/traj_persist.h, one workgroup of 16
+    or 8 waves per trajectory).  Ragged N, every state / action dimension, short and long horizons, all cost regimes, against the C port;
+    bit-reproducible from call to call."""
+    from oracle import cport, gpmpc_oracle as O
+    from gaussian_process_mpc_amd.synth import synth_problem
+    rng = np.random.default_rng(7000 + seed)
+    N = int(rng.choice([40, 64, 65, 130, 200, 300, 449, 512]))
+    ds = int(rng.integers(1, 7))
+    da = int(rng.integers(1, 3))
+    H = int(rng.integers(1, 12))
+    B = int(rng.choice([200, 256, 300, 520, 1030]))
+    gamma = float(rng.choice([-1.0, 1e-5, 0.0, 0.5]))
+    pb = synth_problem(600 + seed, N, ds, da, H, B)
+    kinv = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"]).Ky_inv.numpy()
+    pack = G.GPPack(pb["X"], pb["Y"], kinv, pb["lambdas"], pb["sigma_f"])
+    tag = f"N={N} ds={ds} da={da} H={H} B={B} gamma={gamma}"
+    assert pack.plan(B, H)["form"] == "persist", (tag, pack.plan(B, H))
+    cost = G.CostParams(gamma, pb["Q"], pb["R"])
+    r = G.rollout(pack, pb["x0"], pb["U"], cost)
+    pick = sorted({0, 1, B // 2, B - 1})
+    c = cport.rollout(pb, kinv, gamma, x0=pb["x0"][pick], U=pb["U"][pick], nthreads=8)
+    np.testing.assert_allclose(r["means"][pick].cpu().numpy(), c["means"], rtol=1e-5, atol=1e-9, err_msg=tag)
+    np.testing.assert_allclose(r["vars"][pick].cpu().numpy(), c["vars"], rtol=1e-4, atol=1e-12, err_msg=tag)
+    np.testing.assert_allclose(r["cost"][pick].cpu().numpy(), c["cost"], rtol=1e-6, atol=1e-12, err_msg=tag)
+    np.testing.assert_allclose(r["grad"][pick].cpu().numpy(), c["grad"], rtol=1e-4, atol=1e-7, err_msg=tag)
+    again = G.rollout(pack, pb["x0"], pb["U"], cost)
+    for k in r:
+        assert torch.equal(r[k], again[k]), (tag, k)
+    f = G.rollout(pack, pb["x0"], pb["U"], cost, want_grad=False)
+    np.testing.assert_allclose(f["cost"].cpu().numpy(), r["cost"].cpu().numpy(), rtol=1e-9, err_msg=tag)
+
+
 @pytest.mark.parametrize("seed", range(10))
 def test_fuzz_fullcov_rollout_vs_cport(G, seed):
     from oracle import cport, gpmpc_oracle as O

@@ -2,6 +2,7 @@
 
 The rollout picks its kernel by the amount of work (csrc/step.hip::plan_rollout, csrc/moment.hip::plan_mom):
 
+    whole horizon in one launch (traj_persist.h)          B >= ~0.7 trajectories per CU, N <= 512: one workgroup per trajectory
     one launch per step, 64-row tiles (step_fused.h)      small batches (the staged pair_kernel.h with GPMPC_FUSED=0 / full S)
     one launch per step, 256x64 / 32 / 16 tiles           from ~150 (N >= 512; else ~400) to ~4700 (7000: <= 200 tiles per trajectory)
       (step_fused.h Q = 0 / 32 / 16)                      tile workgroups: scalar-broadcast column loop inside the fused step kernel
@@ -55,14 +56,18 @@ def test_diag_rollout_every_shape_vs_cport(G, ds, da):
     import os
     narrow = {"GPMPC_FUSED_SB": "1", "GPMPC_PAIR_SB": "1"}
     for B, env in ((3, None), (b_mid, None), (b_mid, {"GPMPC_FUSED_SB": "1"}), (5, dict(narrow, GPMPC_TILING="5")),
-                   (4, dict(narrow, GPMPC_TILING="6")), (b_big, None)):
+                   (4, dict(narrow, GPMPC_TILING="6")), (7, {"GPMPC_PERSIST": "16"}), (6, {"GPMPC_PERSIST": "8"}), (b_big, None)):
         # b_mid runs twice: as head kernel + pair_kernel_sb.h on the 256x64 tiles (the plan for a training set of less than one
         # 256-row tile, and for more than ~4700 tile workgroups) and, forced, as one launch per step on the same tiles
         # (step_fused.h, Q = 0: the plan from ~400 to ~4700 tile workgroups of a larger training set); the same form on 256x32 and
-        # 256x16 tiles (Q = 32 / 16: the plan for a handful of trajectories of a large training set) is forced on small batches
+        # 256x16 tiles (Q = 32 / 16: the plan for a handful of trajectories of a large training set) is forced on small batches;
+        # GPMPC_PERSIST forces the whole-horizon kernel (traj_persist.h: one workgroup of 16 / 8 waves per trajectory, the plan for
+        # batches of about one trajectory per CU and more of a training set of up to 512 points)
         try:
             os.environ.update(env or {})
             pack.reload_tuning()
+            if env and "GPMPC_PERSIST" in env:
+                assert pack.plan(B, H)["form"] == "persist"
             r = G.rollout(pack, pb["x0"][:B], pb["U"][:B], cost)
             f = G.rollout(pack, pb["x0"][:B], pb["U"][:B], cost, want_grad=False)       # the GRAD = false instances
         finally:
