@@ -291,14 +291,21 @@ def measured_traffic(config, B, want_grad, kernel_hint):
     """HBM-side bytes per launch of the dominant kernel from the tracked PMC summary of THIS workload
     (profiles/r02/pmc_<config>.json, written by tools/prof_pmc.sh: separate --pmc passes of `bench.py --config <config>`;
     FETCH_SIZE x 2 for the gfx950 wide-read correction + WRITE_SIZE, both in KiB).  None when no summary matches."""
-    d, rnd = None, None
-    for rnd in ("r03", "r02"):
-        try:
-            with open(os.path.join(ROOT, "profiles", rnd, f"pmc_{config}{'_shared' if kernel_hint == 'sbs' else ''}.json")) as f:
-                d = json.load(f)
+    d, rnd, name = None, None, None
+    sh = "_shared" if kernel_hint == "sbs" else ""
+    for rnd in ("r04", "r03", "r02"):
+        for name in (f"pmc_{config}_B{B}{sh}.json", f"pmc_{config}{sh}.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", rnd, name)) as f:
+                    d = json.load(f)
+            except (OSError, ValueError):
+                d = None
+                continue
+            if d.get("batch_per_gpu") == B:
+                break
+            d = None
+        if d is not None:
             break
-        except (OSError, ValueError):
-            continue
     if d is None:
         return None, None
     if d.get("batch_per_gpu") != B or bool(d.get("want_grad", True)) != bool(want_grad) or \
@@ -308,7 +315,7 @@ def measured_traffic(config, B, want_grad, kernel_hint):
     if "FETCH_SIZE" not in k or "WRITE_SIZE" not in k:
         return None, None
     traffic = (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
-    src = (f"profiles/{rnd}/pmc_{config}{'_shared' if kernel_hint == 'sbs' else ''}.json (HEAD {d.get('head', '?')}; `{d.get('command', '?')}`; kernel {k.get('name', '?')}; "
+    src = (f"profiles/{rnd}/{name} (HEAD {d.get('head', '?')}; `{d.get('command', '?')}`; kernel {k.get('name', '?')}; "
            f"2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes; Infinity-Cache hits are included in FETCH_SIZE)")
     return traffic, src
 

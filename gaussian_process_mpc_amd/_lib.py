@@ -59,6 +59,7 @@ SIGNATURES = {
     "gpmpc_pack_resize": (_i, [_vp, _i]),
     "gpmpc_pack_reload_tuning": (_i, [_vp]),
     "gpmpc_pack_graph_captures": (ctypes.c_longlong, [_vp]),
+    "gpmpc_store_host": (_i, [_vp, _vp, _sz, _vp]),
     "gpmpc_build_ky": (_i, [_i, _i, _vp, _dp, _d, _d, _vp, _vp, _vp]),
     "gpmpc_pack_build": (_i, [_vp, _vp, _vp, _vp, _dp, _dp, _vp]),
     "gpmpc_pack_build_strided": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _dp, _dp, _vp]),

@@ -95,6 +95,10 @@ int gpmpc_upload_small(void* dst_dev, const void* src_host, size_t bytes, hipStr
     return GPMPC_OK;
 }
 
+extern "C" int gpmpc_store_host(void* dst_dev, const void* src_host, size_t bytes, void* stream) {
+    return gpmpc_upload_small(dst_dev, src_host, bytes, (hipStream_t)stream);
+}
+
 // Kf = sigma_f^2 exp(-1/2 d2), Ky = Kf + noise_var I   (src/gpr.py:163-170)
 __global__ void k_build_ky(const double* __restrict__ X, int n, int D, const double* __restrict__ lam,
                            double sf2, double noise_var, double* __restrict__ Kf, double* __restrict__ Ky) {

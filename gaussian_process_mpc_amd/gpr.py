@@ -115,6 +115,8 @@ class GaussianProcessRegression(object):
         shared (optional): a dict carried across the GPs of ONE Dynamics.append_train_data call, which feeds every GP the same
         input rows: the device copy of x, the concatenated X_train and the device copy of all targets (column `column` is this
         GP's) are then made once instead of once per GP (each was its own host-to-device copy on every environment step)."""
+        if incremental and num_obs == 1 and self.num_train > 0 and self.x_dim * 8 <= 512:
+            return self._ingest_one_in_place(x, y, shared, column)
         if shared is not None and "x" in shared:
             x = shared["x"]
         else:
@@ -145,6 +147,43 @@ class GaussianProcessRegression(object):
         if not inc:
             self._pending = None                               # a full rebuild supersedes one in flight
         self.num_train += num_obs
+        return "incremental" if inc else "full"
+
+    def _ingest_one_in_place(self, x, y, shared, column):
+        """One new observation on the incremental path: X_train / y_train are views of capacity-padded, APPEND-ONLY device buffers (rows
+        below num_train never change, so earlier views stay valid), and the new row travels as a kernel argument (C ABI
+        ``gpmpc_store_host``) -- no host-to-device copy, no concatenation.  Same values as src/gpr.py:109-119."""
+        n = self.num_train
+        xh = np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(self.x_dim))
+        yh = np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(1))
+        vp = lambda t, off: ctypes.c_void_p(t.data_ptr() + 8 * off)  # noqa: E731
+        with torch.cuda.device(self.device):
+            sp = stream_ptr(self.device)
+            if shared is not None and shared.get("X_old") is self.X_train:
+                self.X_train = shared["X_new"]                     # the leader of this call already appended the row
+            else:
+                buf = getattr(self, "_Xbuf", None)
+                if buf is None or buf.shape[0] < n + 1 or self.X_train.untyped_storage().data_ptr() != buf.untyped_storage().data_ptr():
+                    buf = torch.empty((((n + 1 + 255) // 256) * 256 + 256, self.x_dim), dtype=torch.float64, device=self.device)
+                    buf[:n].copy_(self.X_train)
+                    self._Xbuf = buf
+                check(lib().gpmpc_store_host(vp(buf, n * self.x_dim), xh.ctypes.data_as(ctypes.c_void_p), 8 * self.x_dim, sp), "gpmpc_store_host")
+                X_new = buf[:n + 1]
+                if shared is not None:
+                    shared["X_old"], shared["X_new"] = self.X_train, X_new
+                self.X_train = X_new
+            yb = getattr(self, "_ybuf", None)
+            if yb is None or yb.shape[0] < n + 1 or self.y_train.untyped_storage().data_ptr() != yb.untyped_storage().data_ptr():
+                yb = torch.empty((((n + 1 + 255) // 256) * 256 + 256, 1), dtype=torch.float64, device=self.device)
+                yb[:n].copy_(self.y_train)
+                self._ybuf = yb
+            check(lib().gpmpc_store_host(vp(yb, n), yh.ctypes.data_as(ctypes.c_void_p), 8, sp), "gpmpc_store_host")
+            self.y_train = yb[:n + 1]
+        inc = (self.Ky_inv is not None and self._built_hypers == self._current_hypers()
+               and (self._appends_since_rebuild < self.rebuild_every or self.async_rebuild or self.refresh == "newton"))
+        if not inc:
+            self._pending = None
+        self.num_train += 1
         return "incremental" if inc else "full"
 
     def _adopt(self, other):

@@ -94,6 +94,11 @@ int gpmpc_pack_reload_tuning(gpmpc_pack* pack);
  * kept per pack, least recently used replaced).  Diagnostic; no reference counterpart. */
 long long gpmpc_pack_graph_captures(const gpmpc_pack* pack);
 
+/* A few host values (<= 512 bytes, a multiple of 4) -> device memory, ordered on `stream`, consumed before the call returns (they travel
+ * as kernel arguments: no pageable-memory copy, no synchronisation).  The closed loop appends ONE observation per step
+ * (src/simulator.py:55 -> src/gpr.py:109-119): the new input row and targets go straight into capacity-padded device buffers. */
+int gpmpc_store_host(void* dst_dev, const void* src_host, size_t bytes, void* stream);
+
 /* Build K_f, K_y = K_f + noise_var*I for one GP on the device
  * (GaussianProcessRegression.build_Ky_inv_mat, src/gpr.py:163-170; the inverse at :171 is
  * taken by the caller).  X dev [n][D]; lambdas host [D]; Kf, Ky dev [n][n] (Kf may be NULL).

@@ -65,7 +65,7 @@ def test_fuzz_whole_horizon_form_vs_cport(G, seed):
     ds = int(rng.integers(1, 7))
     da = int(rng.integers(1, 3))
     H = int(rng.integers(1, 12))
-    B = int(rng.choice([200, 256, 300, 520, 1030]))
+    B = int(rng.choice([200, 256, 500, 512, 1024]))      # ~0.7-1 and ~2, 4 trajectories per CU (256 CUs): the sizes the plan takes this form at
     gamma = float(rng.choice([-1.0, 1e-5, 0.0, 0.5]))
     pb = synth_problem(600 + seed, N, ds, da, H, B)
     kinv = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"]).Ky_inv.numpy()

@@ -593,6 +593,7 @@ def test_scalar_broadcast_kernels_match_staged(G, golden, monkeypatch):
     gp = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"])
     pk = G.GPPack(pb["X"], pb["Y"], gp.Ky_inv.numpy(), pb["lambdas"], pb["sigma_f"])
     cost = G.CostParams(-1.0, pb["Q"] + 0.02 * (1 - np.eye(2)), pb["R"])
+    monkeypatch.setenv("GPMPC_PERSIST", "0")                 # (a batch of 700 would otherwise take the whole-horizon kernel either way)
     for fn in (G.rollout, G.rollout_fullcov):
         monkeypatch.setenv("GPMPC_PAIR_SB", "0")
         a = fn(pk.reload_tuning(), pb["x0"], pb["U"], cost)

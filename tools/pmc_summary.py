@@ -25,7 +25,7 @@ acc = defaultdict(lambda: [0.0, 0])
 for f in glob.glob(os.path.join(a.root, "p*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         k = r.get("Kernel_Name", "")
-        if "pair_kernel" not in k:
+        if not any(t in k for t in ("pair_kernel", "k_step_fused", "k_traj_persist")):
             continue
         e = acc[(k.split("(")[0].replace("void ", "").strip(), r["Counter_Name"])]
         e[0] += float(r["Counter_Value"]); e[1] += 1

@@ -1,17 +1,18 @@
 #!/bin/bash
 # PMC passes for the pair kernel on the GPU box (run through gpurun from the repo root):
-#   bash tools/prof_pmc.sh <config> [extra bench args...]
+#   [PMC_BATCH=<B of --batch, for the sidecar> PMC_STEPS=<timed steps>] bash tools/prof_pmc.sh <config> [extra bench args...]
 # Each pass is its own rocprofv3 run (counters only; no tracing domains).  Writes gpurun_out/pmc_<config>/pmc_<config>.txt
 # (per-launch averages) and pmc_<config>.json (the sidecar bench.py reads roofline.traffic from once it is copied to
 # profiles/rNN/).  HEAD comes from tools/.githead (written on the build host before gpurun: the box has no .git).
 set -u
 CFG=$1; shift
-ROOTD=${GRAFT_REPO_ROOT:-$(pwd)}
+ROOTD=$(pwd)      # the tree the job runs in (a staged copy under .stage/ when launched by tools/stage_run.sh)
 OUT=$ROOTD/gpurun_out/pmc_$CFG
 mkdir -p $OUT
 HEAD=$(cat $ROOTD/tools/.githead 2>/dev/null || echo unknown)
-BATCH=$(python3 -c "import sys; sys.path.insert(0,'$ROOTD'); from gaussian_process_mpc_amd.synth import CONFIGS; c=CONFIGS['$CFG']; print(c['B']//8 if '$CFG'=='C4' else c['B'])")
-CMD="python3 bench.py --config $CFG --steps 1 --warmup 1 --no-cpu-baseline --no-extras $*"
+BATCH=${PMC_BATCH:-$(python3 -c "import sys; sys.path.insert(0,'$ROOTD'); from gaussian_process_mpc_amd.synth import CONFIGS; c=CONFIGS['$CFG']; print(c['B']//8 if '$CFG'=='C4' else c['B'])")}
+STEPS=${PMC_STEPS:-1}
+CMD="python3 bench.py --config $CFG --steps $STEPS --warmup 1 --no-cpu-baseline --no-extras $*"
 # the inverse kernel matrices come from an UNPROFILED run: rocprofv3 --pmc segfaults inside rocSOLVER's 4096^2 LU (C4)
 KC=/tmp/kinv_$CFG.pt
 [ -f $KC ] || python3 $ROOTD/bench.py --config $CFG --steps 1 --warmup 0 --no-cpu-baseline --no-extras --kinv-cache $KC > /dev/null 2>&1
@@ -24,7 +25,7 @@ P5="SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INST_CYCLES
 i=0
 for P in "$P1" "$P2" "$P3" "$P4" "$P5"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $P --output-format csv -d $OUT/p$i -- python3 $ROOTD/bench.py --config $CFG --steps 1 --warmup 1 --no-cpu-baseline --no-extras --kinv-cache $KC "$@" > $OUT/p$i.log 2>&1 || echo "pass $i failed (see $OUT/p$i.log)"
+  timeout -k 10 300 rocprofv3 --pmc $P --output-format csv -d $OUT/p$i -- python3 $ROOTD/bench.py --config $CFG --steps $STEPS --warmup 1 --no-cpu-baseline --no-extras --kinv-cache $KC "$@" > $OUT/p$i.log 2>&1 || echo "pass $i failed (see $OUT/p$i.log)"
 done
 { echo "# rocprofv3 --pmc (5 separate passes) of: $CMD"; echo "# HEAD $HEAD"; python3 $ROOTD/tools/pmc_summary.py $OUT --json $OUT/pmc_$CFG.json --config $CFG --batch $BATCH --command "$CMD" --head $HEAD; } > $OUT/pmc_$CFG.txt 2>&1
 grep -E "FETCH_SIZE|WRITE_SIZE|GRBM|SQ_ACTIVE_INST_VALU " $OUT/pmc_$CFG.txt

@@ -3,7 +3,7 @@
 #   bash tools/prof_trace.sh <config>     -> gpurun_out/trace_<config>/kernel_stats_<config>.csv (+ the bench line of the traced run)
 set -u
 CFG=$1; shift
-ROOTD=${GRAFT_REPO_ROOT:-$(pwd)}
+ROOTD=$(pwd)      # the tree the job runs in (a staged copy under .stage/ when launched by tools/stage_run.sh)
 OUT=$ROOTD/gpurun_out/trace_$CFG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
