@@ -971,6 +971,11 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     r->tiling = big ? 0 : (big128 ? 4 : (mid ? 2 : (many ? 3 : 1)));
     if (r->tiling == 2 && narrow_ok && wg2 < 1000)           // 32 columns from ~300 workgroups of 64, 16 below (while the partial sums
         r->tiling = (wg2 >= 300 || p->wl[0][6].nwork > 1300) ? 5 : 6;      // of a trajectory stay within ~1300)
+    // A training set whose LAST row tile is a quarter or half tile (Np = 320, 384: N = 257...384): its 256x64 workgroups carry one or
+    // two waves of four; on 32 columns there are twice as many, half as long -- measured with gpmpc_pack_autotune (round 4,
+    // profiles/r04/autotune_small_n.txt): N = 300, ds = 4, B = 48 / 64 / 96 / 128 / 160 x1.07 / 1.08 / 1.09 / 1.10 / 1.07, ds = 2,
+    // B = 128 / 160 x1.06; N = 400 (Np = 448) and N = 512: level, N = 200 (one row tile): level.
+    if (r->tiling == 2 && fsb_take && p->Np > 256 && p->Np <= 384 && wg2 >= 1000) r->tiling = 5;
     if (tn.pair_sb >= 0) {                                   // 0 = staged kernel, 1 = scalar broadcast
         r->sb = (tn.pair_sb != 0 && sb_ok) ? 1 : 0;
         r->tiling = r->sb ? (big ? 0 : (big128 ? 4 : 2)) : (big ? 0 : (many ? 3 : 1));
@@ -1078,8 +1083,13 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
         if (fill8 >= 0.9) pw = 8;
         else if (fill16 >= (g16 == 1 ? 0.7 : 0.9)) pw = 16;
         if (tn.persist == 8 || tn.persist == 16) pw = tn.persist;
+        // With ONE lambda for all GPs the step-per-launch forms share exponent and exp across the GPs of a pair, this kernel does not
+        // (yet): from three GPs on they are ahead of it (shared packs, ms per batch, step-per-launch | 16 waves | 8 waves: N = 300, ds = 4,
+        // B = 256 0.87 | 0.99 | 1.56, B = 512 1.42 | 1.93 | 1.81; N = 512, ds = 3, B = 256 1.97 | 2.49; with two GPs the whole-horizon
+        // kernel still wins: N = 300, ds = 2, B = 256 0.49 | 0.43, N = 200, B = 1024 0.70 | 0.56 | 0.47 -- profiles/r04/ab_persist_shared.txt)
+        const bool shared_ahead = shared_on && p->ds >= 3;
         if (diag && !lowprec && p->da >= 1 && p->da <= 2 && p->Np <= GPMPC_PERSIST_MAXNP_HOST && H * p->da <= 1024 && tn.persist != 0 &&
-            pw && (tn.persist > 0 || p->Np <= 512)) {
+            pw && (tn.persist > 0 || (p->Np <= 512 && !shared_ahead))) {
             r->fused = 3; r->sb = 0; r->shared = 0; r->tb = 1; r->rgroup = 1; r->colunroll = 1; r->fq = 1;
             r->pwaves = pw;
             r->nwork = 0;
@@ -1139,7 +1149,11 @@ static int split_count(const gpmpc_pack* p, const RollPlan& r, int B, bool lowpr
     if (r.fused == 2) {
         // one launch per step: two branches are ahead everywhere (tools/env_ab.py --var GPMPC_SPLIT, N = 1024, B = 8 / 16 / 24: one branch
         // x1.03 / 0.86 / 0.94, two x1.11 / 1.01 / 1.06, four x1.02 / 0.95 / 1.01 of the two-kernel rule's choice)
-        S = B >= 4 ? 2 : 1;
+        // ... but only from ~800 tile workgroups per launch on (gpmpc_pack_autotune, round 4: N = 200, ds = 2, B = 64 and ds = 4, B = 32
+        // -- 512 tile workgroups -- run x1.21 faster unsplit; N = 200, ds = 4, B = 64 and everything larger keeps two), and a pair of
+        // trajectories of a large training set splits too (N = 2048, B = 2: x1.04)
+        const long wgs = (long)B * r.nwork;
+        S = ((B >= 4 && wgs >= 800) || (B >= 2 && wgs >= 1000 && wgs <= 2500)) ? 2 : 1;
     } else if (mid && B >= 4) {
         S = B / 2 < GPMPC_MAX_SPLIT ? B / 2 : GPMPC_MAX_SPLIT;
         while (S > 1 && (long)(B / S) * r.nwork >= 4096 && B / S < 8) --S;

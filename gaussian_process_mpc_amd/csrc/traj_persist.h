@@ -38,8 +38,23 @@ static __device__ unsigned long long g_persist_stamps[64];
 #define GPMPC_PST(slot) do { } while (0)
 #define GPMPC_PSTW(slot) do { } while (0)
 #endif
+#ifndef GPMPC_PERSIST_MG
+#define GPMPC_PERSIST_MG 0        // 0: by D (below)
+#endif
 #ifndef GPMPC_PERSIST_ILP
-#define GPMPC_PERSIST_ILP 2        // columns whose dependency chains the scheduler may interleave
+#define GPMPC_PERSIST_ILP 0       // 0: by D (below)
+#endif
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's GLOBAL memory operations (s_waitcnt vmcnt(0)): in
+// this kernel that put the write latency of the step's Jacobian rows -- read by nobody before the kernel ends -- and of the weight /
+// beta prefetches in front of every barrier (6.7 us of an 84 us step in the in-kernel timeline).  Where waves exchange data through
+// GLOBAL memory (the column rows) the drain is explicit.
+#ifdef GPMPC_PERSIST_SYNCTHREADS
+#define GPMPC_LDS_BARRIER() __syncthreads()
+#else
+#define GPMPC_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+#endif
+#ifndef GPMPC_PERSIST_PRIO_SHIFT
+#define GPMPC_PERSIST_PRIO_SHIFT 5  // the issue priority rotates every 2^shift columns
 #endif
 #ifndef GPMPC_PERSIST_ROTPRIO
 #define GPMPC_PERSIST_ROTPRIO 1
@@ -52,7 +67,13 @@ template <int D, int NS2, bool GRAD>
 __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
     constexpr int DS = NS2, DA = D - NS2, NM = GRAD ? 1 + 2 * D : 1, NA = GRAD ? 1 + D + NS2 : 1, NV = 1 + 2 * D;
     constexpr int GW = (D + 1 + NS2 + 1) & ~1;     // doubles per G row, as PairSbTraits
-    constexpr int MG = 4;                          // weight columns per group (two groups in flight)
+    // weight columns per group (two groups in flight) and columns whose dependency chains may interleave: 4 and 2 up to D = 6; from D = 7
+    // the accumulators alone (2 (1 + D + ds) + 2 (1 + 2 D) registers) leave room for 2 and 1 (D = 7: 68 -> 6 VGPR spills, D = 8: 94 -> 18).
+    // Not only speed: the D = 8, ds = 7 instance with 94 VGPR + 80 SGPR spills returned means with the low mantissa word of some
+    // double lost (1e-6 relative, deterministic, the objective-only instance and every lighter one exact) -- a spill-path miscompile;
+    // tests/test_gpu_instances.py holds every (ds, da) instance to the C port.
+    constexpr int MG = GPMPC_PERSIST_MG ? GPMPC_PERSIST_MG : (D >= 7 ? 2 : 4);
+    constexpr int ILPW = GPMPC_PERSIST_ILP ? GPMPC_PERSIST_ILP : (D >= 7 ? 1 : 2);
     extern __shared__ double s_dyn[];              // X: [D][Np]
     __shared__ double s_tab[GPMPC_EXP_N];
     __shared__ double s_part[16 * 2 * 4 * NM];     // [wave][first | second GP of the wave's range][row of 16 lanes][moment]
@@ -94,34 +115,46 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
     const int lane8 = lane * 8;
 
     for (int t = 1; t <= A.H; ++t) {
+        // Everything below that depends only on the thread index (row / GP of a thread in each phase, addresses, an integer division) is
+        // loop-invariant over t: hoisted out of the step loop it was ~60 VGPRs of live state, spilled to scratch and reloaded in every
+        // phase of every step.  A zero the compiler cannot prove (t >> 30) makes the index step-dependent: recomputed (a few integer
+        // instructions) instead.  (An inline-asm-laundered zero did the same but MISCOMPILED the ds = 7 instance -- means off by 1e-3 from
+        // the first step on, the NO_TZ build of the same source exact --: kept out.)
+#ifndef GPMPC_PERSIST_NO_TZ
+        const int tz = t >> 30;                                    // 0 (1 <= t <= H < 2^30), but not provably
+#else
+        const int tz = 0;
+#endif
+        const int tiz = tid + tz;
         GPMPC_PST(0);
         // ---- 1: input moments of the action dimensions, then the per-(GP, dimension) scalars ------------------------------------
         if (DA > 0 && tid >= DS && tid < D) { s_uin[tid] = s_U[(t - 1) * DA + (tid - DS)]; s_sin[tid] = GPMPC_ACTION_VAR; }
-        __syncthreads();
-        if (tid < DS * D) {
-            const int a = tid / D, k = tid - a * D;
+        GPMPC_LDS_BARRIER();
+        if (tiz < DS * D) {
+            const int a = tiz / D, k = tiz - a * D;
             const double lam = lam_mine, sk = s_sin[k], uk = s_uin[k];
-            s_B[tid] = 1.0 / (sk + lam);
-            s_Ak[tid] = 1.0 / (0.5 * lam + sk);
+            s_B[tiz] = 1.0 / (sk + lam);
+            s_Ak[tiz] = 1.0 / (0.5 * lam + sk);
             const double sc = rsqrt(8.0 * (0.5 * lam + sk));       // the pair transform h = sc (u - x), as step_fused.h
-            s_sc[tid] = sc;
-            s_cv[tid] = sc * uk;
-            s_r1[tid] = sk / lam + 1.0;
-            s_r2[tid] = 2.0 * sk / lam + 1.0;
+            s_sc[tiz] = sc;
+            s_cv[tiz] = sc * uk;
+            s_r1[tiz] = sk / lam + 1.0;
+            s_r2[tiz] = 2.0 * sk / lam + 1.0;
         }
-        __syncthreads();
+        GPMPC_LDS_BARRIER();
         GPMPC_PST(1);
         // weights of this thread's points in the mean sums of GP am: requested now, used in 2b
         constexpr int PT = 4;
         double bpre[PT];
+        const int tgz = tg + tz;
 #pragma unroll
         for (int q = 0; q < PT; ++q) {
-            const int i = tg + q * 64 * wpg;
+            const int i = tgz + q * 64 * wpg;
             const double bv = A.beta[(size_t)(am < DS ? am : 0) * Np + (i < Np ? i : 0)];
             bpre[q] = (am < DS && i < Np) ? bv : 0.0;
         }
         // ---- 2a: column rows of every (GP, point) -> scratch (stores in flight while the mean sums run) --------------------------
-        for (int e = tid; e < DS * Np; e += nthr) {
+        for (int e = tiz; e < DS * Np; e += nthr) {
             const int a = e / Np, j = e - a * Np;
             double g[GW], qh = 0.0;
 #pragma unroll
@@ -149,7 +182,7 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
 #pragma unroll
                 for (int k = 0; k < D; ++k) { u[k] = s_uin[k]; Bk[k] = s_B[am * D + k]; }
                 int it = 0;
-                for (int i = tg; i < Np; i += 64 * wpg, ++it) {
+                for (int i = tgz; i < Np; i += 64 * wpg, ++it) {
                     double d[D], q = 0.0;
 #pragma unroll
                     for (int k = 0; k < D; ++k) { d[k] = u[k] - s_X[k * Np + i]; q = fma(Bk[k] * d[k], d[k], q); }
@@ -173,18 +206,18 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
         GPMPC_PST(3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's G rows are in L2
         GPMPC_PST(4);
-        __syncthreads();
+        GPMPC_LDS_BARRIER();
         GPMPC_PST(5);
         __builtin_amdgcn_s_dcache_inv();                           // the scalar cache may hold the previous step's rows
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (tid < DS * NV) {                                       // combine the mean sums: waves of the GP's group, rows in fixed order
-            const int a = tid / NV, m = tid - a * NV;
+        if (tiz < DS * NV) {                                       // combine the mean sums: waves of the GP's group, rows in fixed order
+            const int a = tiz / NV, m = tiz - a * NV;
             double sum = 0.0;
             for (int ww = a * wpg; ww < (a + 1) * wpg; ++ww) {
                 const double* r4 = &s_mred[ww * 4 * NV + m];
                 sum += (r4[0] + r4[NV]) + (r4[2 * NV] + r4[3 * NV]);
             }
-            s_ms[tid] = sum;
+            s_ms[tiz] = sum;
         }
         GPMPC_PST(6);
         GPMPC_PSTW(16);
@@ -256,7 +289,7 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
                     // The four waves a SIMD holds of this workgroup are arbitrated by age: left alone the oldest runs ahead and the
                     // youngest finishes 40 % later, the SIMD half empty at the end (stamps: wave 2 109 k cycles, wave 15 165 k for
                     // equal ranges).  Rotating the issue priority every few iterations lets them advance together.
-                    switch (((jc >> 5) + (w >> 2)) & 3) {
+                    switch (((jc >> GPMPC_PERSIST_PRIO_SHIFT) + (w >> 2)) & 3) {
                         case 0: __builtin_amdgcn_s_setprio(0); break;
                         case 1: __builtin_amdgcn_s_setprio(1); break;
                         case 2: __builtin_amdgcn_s_setprio(2); break;
@@ -268,7 +301,7 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
                         mgb[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, (jc + MG + q) * Np * 8, 0));
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int q = 0; q < MG; ++q) { column(jc + q, mga[q]); if (q % GPMPC_PERSIST_ILP == GPMPC_PERSIST_ILP - 1) __builtin_amdgcn_sched_barrier(0); }
+                    for (int q = 0; q < MG; ++q) { column(jc + q, mga[q]); if (q % ILPW == ILPW - 1) __builtin_amdgcn_sched_barrier(0); }
                     {   // unconditional (the last iteration re-requests its own first group, unused): under a branch the compiler's
                         // wait counts merge both paths and every wait below becomes "all loads done"
                         const int jn = jc + 2 * MG < n ? jc + 2 * MG : jc;
@@ -278,7 +311,7 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int q = 0; q < MG; ++q) { column(jc + MG + q, mgb[q]); if (q % GPMPC_PERSIST_ILP == GPMPC_PERSIST_ILP - 1) __builtin_amdgcn_sched_barrier(0); }
+                    for (int q = 0; q < MG; ++q) { column(jc + MG + q, mgb[q]); if (q % ILPW == ILPW - 1) __builtin_amdgcn_sched_barrier(0); }
                 }
                 // per-lane combination into the m-moments of this row block (pair_kernel_sb.h), summed over the row blocks of the GP
                 {
@@ -303,18 +336,18 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
             GPMPC_PSTW(48);
         }
         GPMPC_PST(7);
-        __syncthreads();
+        GPMPC_LDS_BARRIER();
         GPMPC_PST(8);
         // ---- 4: combine, outputs and Jacobian rows of step t, input moments of step t + 1 ------------------------------------
-        if (tid >= 64 && tid < 64 + DS) {                          // c_m, c of the step (wave 1, beside the combine of wave 0)
-            const int a = tid - 64;
+        if (tiz >= 64 && tiz < 64 + DS) {                          // c_m, c of the step (wave 1, beside the combine of wave 0)
+            const int a = tiz - 64;
             double detm = 1.0, detv = 1.0;
             for (int l = 0; l < D; ++l) { detm *= s_r1[a * D + l]; detv *= s_r2[a * D + l]; }
             const double sf = A.sf[a], sf2 = sf * sf;
             s_sf2[a] = sf2; s_cm[a] = sf2 / sqrt(detm); s_c[a] = 1.0 / sqrt(detv);
         }
-        if (tid < DS * NM) {
-            const int a = tid / NM, m = tid - a * NM;
+        if (tiz < DS * NM) {
+            const int a = tiz / NM, m = tiz - a * NM;
             double sum = 0.0;
             for (int ww = 0; ww < NW; ++ww) {                      // fixed order: waves, their (at most two) GPs, rows as (0 + 1) + (2 + 3)
                 const int lo = s_rng[ww], hi = s_rng[ww + 1];
@@ -324,11 +357,11 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
                 const double* r4 = &s_part[((ww * 2 + (a - a0)) * 4) * NM + m];
                 sum += (r4[0] + r4[NM]) + (r4[2 * NM] + r4[3 * NM]);
             }
-            s_z[tid] = sum;
+            s_z[tiz] = sum;
         }
-        __syncthreads();
-        if (tid < DS * D) {
-            const int a = tid / D, k = tid - a * D, nc = 2 * DS + DA;
+        GPMPC_LDS_BARRIER();
+        if (tiz < DS * D) {
+            const int a = tiz / D, k = tiz - a * D, nc = 2 * DS + DA;
             const double c = s_c[a], cm = s_cm[a], sf2 = s_sf2[a];
             const double mu = cm * s_ms[a * NV];
             const double Tt = c * s_z[a * NM];
@@ -338,7 +371,7 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
                 A.vars[((size_t)b * (A.H + 1) + t) * DS + a] = var;
             }
             if (GRAD) {
-                const double Bq = s_B[tid], Ak = s_Ak[tid], sc = s_sc[tid];
+                const double Bq = s_B[tiz], Ak = s_Ak[tiz], sc = s_sc[tiz];
                 const double dmu_du = -Bq * cm * s_ms[a * NV + 1 + k];
                 const double dmu_ds = -0.5 * mu * Bq + 0.5 * Bq * Bq * cm * s_ms[a * NV + 1 + D + k];
                 const double dT_du = -4.0 * sc * c * s_z[a * NM + (GRAD ? 1 + k : 0)];
@@ -357,7 +390,7 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
             }
         }
         GPMPC_PST(9);
-        __syncthreads();                                           // every reader of s_uin / s_sin of step t is done
+        GPMPC_LDS_BARRIER();                                           // every reader of s_uin / s_sin of step t is done
         GPMPC_PST(10);
         if (tid < DS) {
             const double mu = s_cm[tid] * s_ms[tid * NV];

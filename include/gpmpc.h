@@ -18,7 +18,12 @@
  *    returns GPMPC_E_DEVICE if the calling thread's current device differs (it never switches devices itself).
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).
  *    All work is enqueued asynchronously on it; nothing synchronises the
- *    device.  Calls are re-entrant across streams as long as workspaces differ.
+ *    device.  Calls are re-entrant across streams and host threads as long as workspaces differ: a pack is only read by a
+ *    rollout, and what a pack OWNS -- its private streams / events (graph replay, the concurrent sub-batches of a mid-size
+ *    batch), the captured graphs and the staging buffers of gpmpc_objective_gradient -- is guarded by a per-pack host lock
+ *    (lazy creation, a stream capture from begin to end, a fork / join of a split launch, the callback entry are each one
+ *    critical section).  Functions that MODIFY a pack (build, resize, enable_fullcov, reload_tuning, autotune, destroy) must
+ *    not run concurrently with anything else on that pack.
  *    HOST arrays (hyper-parameters, cost parameters) are consumed before the call
  *    returns -- they travel as kernel arguments --: the caller may free or overwrite
  *    them at once, whatever `stream` is waiting for.  DEVICE buffers must stay valid
