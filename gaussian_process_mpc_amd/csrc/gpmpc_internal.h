@@ -189,7 +189,7 @@ struct PersistArgs {
     double* gscr;                                  // [B][ds][Np][GW] column rows, one slot per workgroup
     int total;                                     // columns of the flattened (GP, row block, column) space: ds * 64 * T (T + 1) / 2
 };
-template <int D> int gpmpc_launch_persist_D(bool grad, int ns2, int waves, const PersistArgs& a, hipStream_t s);
+template <int D> int gpmpc_launch_persist_D(bool grad, int ns2, int waves, int ng, const PersistArgs& a, hipStream_t s);
 
 
 // Implemented in pair_d*.hip (one translation unit per D so the build parallelises).

@@ -4,7 +4,7 @@
 #ifndef GPMPC_PAIR_D
 #error "compile with -DGPMPC_PAIR_D=<D>"
 #endif
-template int gpmpc_launch_persist_D<GPMPC_PAIR_D>(bool, int, int, const PersistArgs&, hipStream_t);
+template int gpmpc_launch_persist_D<GPMPC_PAIR_D>(bool, int, int, int, const PersistArgs&, hipStream_t);
 
 #if defined(GPMPC_PERSIST_STAMPS) && GPMPC_PAIR_D == GPMPC_STAMP_D
 #ifndef GPMPC_STAMP_D

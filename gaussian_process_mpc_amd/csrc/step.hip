@@ -878,7 +878,7 @@ int gpmpc_timed_pair_sbf(int D, bool grad, int ns2, int waves, const PairSbfArgs
 }
 
 #define GPMPC_PERSIST_MAXNP_HOST 1024
-struct RollPlan { int tiling, tb, waves, nwork, nm, pps, sps, sb, gw, rgroup, fused, fq, hchunks, hrows, shared, sh_list, colunroll /* columns per iteration of the sb kernel */, fng /* GPs per tile workgroup of the one-launch form with one lambda */, pwaves /* waves per workgroup of the whole-horizon kernel (fused = 3) */; size_t off_mpart; size_t off_G; size_t off_pp, off_sp, off_part, off_partz, off_jac, off_means, off_vars, total; };
+struct RollPlan { int tiling, tb, waves, nwork, nm, pps, sps, sb, gw, rgroup, fused, fq, hchunks, hrows, shared, sh_list, colunroll /* columns per iteration of the sb kernel */, fng /* GPs per tile workgroup of the one-launch form with one lambda */, pwaves /* waves per workgroup of the whole-horizon kernel (fused = 3) */, png /* GPs per unit there: 1, or 2 with one lambda for all GPs */; size_t off_mpart; size_t off_G; size_t off_pp, off_sp, off_part, off_partz, off_jac, off_means, off_vars, total; };
 
 // shape (optional): take every SHAPE decision (tiling, kernel, trajectories per wave, row chunks ...) from this plan of a larger
 // batch and only size the buffers for B: the sub-batches of a split call then run exactly the launches the whole batch would,
@@ -1087,15 +1087,25 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
         // (yet): from three GPs on they are ahead of it (shared packs, ms per batch, step-per-launch | 16 waves | 8 waves: N = 300, ds = 4,
         // B = 256 0.87 | 0.99 | 1.56, B = 512 1.42 | 1.93 | 1.81; N = 512, ds = 3, B = 256 1.97 | 2.49; with two GPs the whole-horizon
         // kernel still wins: N = 300, ds = 2, B = 256 0.49 | 0.43, N = 200, B = 1024 0.70 | 0.56 | 0.47 -- profiles/r04/ab_persist_shared.txt)
-        const bool shared_ahead = shared_on && p->ds >= 3;
+        // ... so with one lambda this kernel runs over units of TWO GPs (traj_persist.h, NG = 2; instantiated up to D = 6), and packs it
+        // cannot serve that way (D >= 7) keep the step-per-launch forms from three GPs on.  Shared packs, step-per-launch | units of two
+        // GPs, 16 waves | 8 waves (profiles/r04/ab_persist_shared_ng2.txt): N = 300, ds = 4, B = 256 0.86 | 0.68 | 0.78, B = 512 1.41 | 1.27 | 1.10;
+        // ds = 2, B = 256 0.49 | 0.33; ds = 5, B = 256 1.34 | 1.03; N = 200, ds = 2, B = 1024 0.69 | 0.43 | 0.33; N = 400, ds = 3, da = 2 1.44 | 1.39;
+        // N = 512, ds = 3, H = 20 1.94 | 2.06 (not taken: up to Np = 448 with one lambda).  D = 7 loses with distinct lambdas too
+        // (N = 300, ds = 6: 2.19 | 2.32; ds = 5, da = 2: 1.69 | 1.98 -- the accumulators leave the column loop one chain and two loads in
+        // flight): taken up to D = 6.
+        const bool pshared = shared_on && p->ds >= 2 && D >= 3 && D <= 6;
+        const bool shared_ahead = shared_on && !pshared && p->ds >= 3;
+        r->png = 1;
         if (diag && !lowprec && p->da >= 1 && p->da <= 2 && p->Np <= GPMPC_PERSIST_MAXNP_HOST && H * p->da <= 1024 && tn.persist != 0 &&
-            pw && (tn.persist > 0 || (p->Np <= 512 && !shared_ahead))) {
+            pw && (tn.persist > 0 || (p->Np <= (pshared ? 448 : 512) && D <= 6 && !shared_ahead))) {
             r->fused = 3; r->sb = 0; r->shared = 0; r->tb = 1; r->rgroup = 1; r->colunroll = 1; r->fq = 1;
             r->pwaves = pw;
+            r->png = pshared ? 2 : 1;
             r->nwork = 0;
         }
     }
-    if (shape) { r->fused = shape->fused; r->pwaves = shape->pwaves; if (r->fused == 3) { r->sb = 0; r->shared = 0; r->nwork = 0; } }
+    if (shape) { r->fused = shape->fused; r->pwaves = shape->pwaves; r->png = shape->png; if (r->fused == 3) { r->sb = 0; r->shared = 0; r->nwork = 0; } }
     r->nm = gpmpc_num_moments(D, diag, grad);
     r->pps = D + D * D;
     r->sps = sps_of(D);
@@ -1212,7 +1222,7 @@ extern "C" int gpmpc_plan_describe(const gpmpc_pack* p, int B, int H, unsigned f
     long wgs;
     if (r.fused == 3) {
         form = "persist";
-        snprintf(kern, sizeof(kern), "k_traj_persist<%d,%d,%s>x%dwaves", D, ds, grad ? "true" : "false", r.pwaves);
+        snprintf(kern, sizeof(kern), "k_traj_persist<%d,%d,%s,%d>x%dwaves", D, ds, grad ? "true" : "false", r.png, r.pwaves);
         wgs = B;
     } else if (r.fused == 2) {
         const int q = r.tiling == 2 ? 0 : cfg[r.tiling][1], ng = r.shared ? r.fng : 1;
@@ -1245,15 +1255,15 @@ extern "C" int gpmpc_plan_describe(const gpmpc_pack* p, int B, int H, unsigned f
     return GPMPC_OK;
 }
 
-static int launch_persist(int D, bool grad, int ns2, int waves, const PersistArgs& a, hipStream_t s) {
+static int launch_persist(int D, bool grad, int ns2, int waves, int ng, const PersistArgs& a, hipStream_t s) {
     switch (D) {
-        case 2: return gpmpc_launch_persist_D<2>(grad, ns2, waves, a, s);
-        case 3: return gpmpc_launch_persist_D<3>(grad, ns2, waves, a, s);
-        case 4: return gpmpc_launch_persist_D<4>(grad, ns2, waves, a, s);
-        case 5: return gpmpc_launch_persist_D<5>(grad, ns2, waves, a, s);
-        case 6: return gpmpc_launch_persist_D<6>(grad, ns2, waves, a, s);
-        case 7: return gpmpc_launch_persist_D<7>(grad, ns2, waves, a, s);
-        case 8: return gpmpc_launch_persist_D<8>(grad, ns2, waves, a, s);
+        case 2: return gpmpc_launch_persist_D<2>(grad, ns2, waves, ng, a, s);
+        case 3: return gpmpc_launch_persist_D<3>(grad, ns2, waves, ng, a, s);
+        case 4: return gpmpc_launch_persist_D<4>(grad, ns2, waves, ng, a, s);
+        case 5: return gpmpc_launch_persist_D<5>(grad, ns2, waves, ng, a, s);
+        case 6: return gpmpc_launch_persist_D<6>(grad, ns2, waves, ng, a, s);
+        case 7: return gpmpc_launch_persist_D<7>(grad, ns2, waves, ng, a, s);
+        case 8: return gpmpc_launch_persist_D<8>(grad, ns2, waves, ng, a, s);
     }
     return GPMPC_E_ARG;
 }
@@ -1328,8 +1338,8 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
         Q.means = A.means; Q.vars = A.vars; Q.jac = A.jac;
         Q.gscr = (double*)(ws + r.off_G);
         const int T = p->Np / 64;
-        Q.total = p->ds * 32 * T * (T + 1);
-        const int rc = timed_launch(GPMPC_TIME_FUSED, s, [&] { return launch_persist(p->D, grad, p->ds, r.pwaves, Q, s); });
+        Q.total = ((p->ds + r.png - 1) / r.png) * 32 * T * (T + 1);
+        const int rc = timed_launch(GPMPC_TIME_FUSED, s, [&] { return launch_persist(p->D, grad, p->ds, r.pwaves, r.png, Q, s); });
         if (rc != GPMPC_OK) return rc;
         A.finished = 1;
     } else
@@ -1772,7 +1782,7 @@ extern "C" int gpmpc_rollout(const gpmpc_pack* p, int B, int H, const double* x0
 // Plan selection that measures: time the candidate plans of ONE call shape on this device and keep the winner
 // ---------------------------------------------------------------------------
 static bool same_shape(const RollPlan& a, const RollPlan& b) {
-    if (a.fused == 3 && b.fused == 3) return a.pwaves == b.pwaves;          // the whole-horizon kernel has no tiling
+    if (a.fused == 3 && b.fused == 3) return a.pwaves == b.pwaves && a.png == b.png;      // the whole-horizon kernel has no tiling
     return a.tiling == b.tiling && a.tb == b.tb && a.sb == b.sb && a.fused == b.fused && a.fq == b.fq && a.shared == b.shared &&
            a.sh_list == b.sh_list && a.fng == b.fng && a.colunroll == b.colunroll && a.hchunks == b.hchunks && a.pwaves == b.pwaves &&
            a.rgroup == b.rgroup && a.nwork == b.nwork;

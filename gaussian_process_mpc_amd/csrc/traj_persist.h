@@ -63,8 +63,14 @@ static __device__ unsigned long long g_persist_stamps[64];
 #define GPMPC_PERSIST_MAXNP 1024                   // X in LDS: Np * D doubles (57 KB at D = 7)
 #endif
 
-template <int D, int NS2, bool GRAD>
+// NG > 1: every GP has the SAME length-scales (pair_kernel_sbs.h: the setting of all the reference's experiments).  The transformed
+// points, the exponent and its exp are then common to the GPs of a (trajectory, step): a wave's range runs over UNITS of NG GPs, one
+// set of column rows per trajectory, one exponent and one table exp per pair applied to NG weight loads -- (1 + D + 7) / NG + 2 + D + ds
+// fp64-rate instructions per pair and GP (17.5 at D = 5, ds = 4, NG = 2, against 24).  A partial last unit (odd ds) re-reads the last GP;
+// its results are not combined.
+template <int D, int NS2, bool GRAD, int NG = 1>
 __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
+    constexpr bool SH = NG > 1;
     constexpr int DS = NS2, DA = D - NS2, NM = GRAD ? 1 + 2 * D : 1, NA = GRAD ? 1 + D + NS2 : 1, NV = 1 + 2 * D;
     constexpr int GW = (D + 1 + NS2 + 1) & ~1;     // doubles per G row, as PairSbTraits
     // weight columns per group (two groups in flight) and columns whose dependency chains may interleave: 4 and 2 up to D = 6; from D = 7
@@ -76,7 +82,7 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
     constexpr int ILPW = GPMPC_PERSIST_ILP ? GPMPC_PERSIST_ILP : (D >= 7 ? 1 : 2);
     extern __shared__ double s_dyn[];              // X: [D][Np]
     __shared__ double s_tab[GPMPC_EXP_N];
-    __shared__ double s_part[16 * 2 * 4 * NM];     // [wave][first | second GP of the wave's range][row of 16 lanes][moment]
+    __shared__ double s_part[16 * 2 * NG * 4 * NM];    // [wave][first | second unit of the wave's range][GP of the unit][row of 16 lanes][moment]
     __shared__ double s_mred[16 * 4 * NV];         // mean sums: [wave][row of 16 lanes][value]
     __shared__ double s_z[DS * NM], s_ms[DS * NV];
     __shared__ double s_uin[D], s_sin[D];
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
     }
     // this wave's range of the flattened column space
     const int r_lo = (int)(((long)A.total * w / NW + 4) & ~7L), r_hi = w == NW - 1 ? A.total : (int)(((long)A.total * (w + 1) / NW + 4) & ~7L);
-    const int gp_first = r_lo < A.total ? r_lo / per_gp : DS;     // the GP the range starts in (slot 0 of s_part; slot 1 = the next)
+    const int gp_first = r_lo < A.total ? r_lo / per_gp : DS;     // the unit (GP, or group of NG GPs) the range starts in (slot 0 of s_part; slot 1 = the next)
     // mean sums: a group of wpg waves per GP
     const int wpg = NW / DS > 0 ? NW / DS : 1;
     const int am = w / wpg, tg = (w - am * wpg) * 64 + lane;       // GP of this wave in phase 2, index of the thread within the group
@@ -154,8 +160,8 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
             bpre[q] = (am < DS && i < Np) ? bv : 0.0;
         }
         // ---- 2a: column rows of every (GP, point) -> scratch (stores in flight while the mean sums run) --------------------------
-        for (int e = tiz; e < DS * Np; e += nthr) {
-            const int a = e / Np, j = e - a * Np;
+        for (int e = tiz; e < (SH ? 1 : DS) * Np; e += nthr) {      // one set of rows per trajectory when the GPs share lambda
+            const int a = SH ? 0 : e / Np, j = e - a * Np;
             double g[GW], qh = 0.0;
 #pragma unroll
             for (int k = 0; k < GW; ++k) g[k] = 0.0;
@@ -221,6 +227,120 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
         }
         GPMPC_PST(6);
         GPMPC_PSTW(16);
+        // ---- 3 (one lambda for all GPs): this wave's range over units of NG GPs ----------------------------------------------------
+        if constexpr (SH) {
+            double zsum[NG][NM];
+#pragma unroll
+            for (int q = 0; q < NG; ++q)
+#pragma unroll
+                for (int m = 0; m < NM; ++m) zsum[q][m] = 0.0;
+            int pos = r_lo, slot = 0, u_cur = gp_first;
+            const double* Gl = Gs;
+            asm volatile("" : "+s"(Gl) :: "memory");
+            typedef const double __attribute__((address_space(4))) gpmpc_cdouble;
+            auto flush = [&](int sl) {
+#pragma unroll
+                for (int q = 0; q < NG; ++q)
+#pragma unroll
+                    for (int m = 0; m < NM; ++m) {
+                        const double sr = wave_row_sum(zsum[q][m]);
+                        if ((lane & 15) == 0) s_part[(((w * 2 + sl) * NG + q) * 4 + (lane >> 4)) * NM + m] = sr;
+                        zsum[q][m] = 0.0;
+                    }
+            };
+            while (pos < r_hi) {
+                const int u = pos / per_gp, rem = pos - u * per_gp;
+                if (u != u_cur) { flush(slot); slot = 1; u_cur = u; }
+                int r = 0;
+                while (r + 1 < T && 64 * ((r + 1) * T - (r + 1) * r / 2) <= rem) ++r;
+                const int bstart = 64 * (r * T - r * (r - 1) / 2);
+                const int j0 = 64 * r + (rem - bstart);
+                const int blen = Np - 64 * r;
+                int n = bstart + blen - rem;
+                if (n > r_hi - pos) n = r_hi - pos;
+                const int i0 = 64 * r;
+                __amdgpu_buffer_rsrc_t Mrs[NG];
+#pragma unroll
+                for (int q = 0; q < NG; ++q) {
+                    const int a = u * NG + q < DS ? u * NG + q : DS - 1;
+                    Mrs[q] = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(A.M + ((size_t)a * Np + j0) * Np + i0), 0, 0x7fffffff, 0x00020000);
+                }
+                double hi2[D], qi;
+                {
+                    double q = 0.0;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) {
+                        const double h = fma(-s_sc[k], s_X[k * Np + i0 + lane], s_cv[k]);      // the transform of GP 0 = of every GP
+                        hi2[k] = (2.0 * GPMPC_EXP_NEG_INV_C) * h;
+                        q = fma(h, h, q);
+                    }
+                    qi = GPMPC_EXP_NEG_INV_C * q;
+                }
+                double acc[NG][NA];
+#pragma unroll
+                for (int q = 0; q < NG; ++q)
+#pragma unroll
+                    for (int m = 0; m < NA; ++m) acc[q][m] = 0.0;
+                const double* Ga = Gl + (size_t)j0 * GW;
+                constexpr int CS = 2;                                  // columns per iteration
+                for (int jc = 0; jc < n; jc += CS) {                   // n is a multiple of 8
+#if GPMPC_PERSIST_ROTPRIO
+                    switch (((jc >> GPMPC_PERSIST_PRIO_SHIFT) + (w >> 2)) & 3) {
+                        case 0: __builtin_amdgcn_s_setprio(0); break;
+                        case 1: __builtin_amdgcn_s_setprio(1); break;
+                        case 2: __builtin_amdgcn_s_setprio(2); break;
+                        default: __builtin_amdgcn_s_setprio(3); break;
+                    }
+#endif
+                    double mij[CS][NG];
+#pragma unroll
+                    for (int c = 0; c < CS; ++c)
+#pragma unroll
+                        for (int q = 0; q < NG; ++q)
+                            mij[c][q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs[q], lane8, (jc + c) * Np * 8, 0));
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int c = 0; c < CS; ++c) {
+                        const gpmpc_cdouble* __restrict__ g = (const gpmpc_cdouble*)(Ga + (size_t)(jc + c) * GW);
+                        double sx = qi + g[D];
+#pragma unroll
+                        for (int k = 0; k < D; ++k) sx = fma(hi2[k], g[k], sx);
+                        const double e = gpmpc_exp_neg_scaled(sx, s_tab);
+#pragma unroll
+                        for (int q = 0; q < NG; ++q) {
+                            const double P = mij[c][q] * e;
+                            acc[q][0] += P;
+                            if (GRAD) {
+#pragma unroll
+                                for (int k = 0; k < D; ++k) acc[q][GRAD ? 1 + k : 0] = fma(P, g[k], acc[q][GRAD ? 1 + k : 0]);
+#pragma unroll
+                                for (int k = 0; k < NS2; ++k) acc[q][GRAD ? 1 + D + k : 0] = fma(P, g[D + 1 + k], acc[q][GRAD ? 1 + D + k : 0]);
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < NG; ++q) {
+                    const double rs = acc[q][0];
+                    zsum[q][0] += rs;
+                    if (GRAD) {
+#pragma unroll
+                        for (int k = 0; k < D; ++k) {
+                            const double h = (0.5 / GPMPC_EXP_NEG_INV_C) * hi2[k], v = acc[q][GRAD ? 1 + k : 0];
+                            zsum[q][GRAD ? 1 + k : 0] += fma(h, rs, v);
+                            if (k < NS2) zsum[q][GRAD ? 1 + D + k : 0] += fma(h * h, rs, fma(2.0 * h, v, acc[q][GRAD ? 1 + D + (k < NS2 ? k : 0) : 0]));
+                        }
+                    }
+                }
+                pos += n;
+            }
+            GPMPC_PSTW(32);
+#if GPMPC_PERSIST_ROTPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
+            if (r_lo < r_hi) flush(slot);
+            GPMPC_PSTW(48);
+        } else
         // ---- 3: this wave's range of the N^2 sum ------------------------------------------------------------------------------
         {
             double zsum[NM];
@@ -352,9 +472,10 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
             for (int ww = 0; ww < NW; ++ww) {                      // fixed order: waves, their (at most two) GPs, rows as (0 + 1) + (2 + 3)
                 const int lo = s_rng[ww], hi = s_rng[ww + 1];
                 if (lo >= hi) continue;
-                const int a0 = s_ga[ww];                           // the range ends in GP a0 or a0 + 1: hi <= (a0 + 2) per_gp
-                if (a != a0 && !(a == a0 + 1 && hi > (a0 + 1) * per_gp)) continue;
-                const double* r4 = &s_part[((ww * 2 + (a - a0)) * 4) * NM + m];
+                const int a0 = s_ga[ww];                           // the range ends in unit a0 or a0 + 1: hi <= (a0 + 2) per_gp
+                const int un = a / NG, qn = a - un * NG;           // unit of GP a and its place in it
+                if (un != a0 && !(un == a0 + 1 && hi > (a0 + 1) * per_gp)) continue;
+                const double* r4 = &s_part[(((ww * 2 + (un - a0)) * NG + qn) * 4) * NM + m];
                 sum += (r4[0] + r4[NM]) + (r4[2 * NM] + r4[3 * NM]);
             }
             s_z[tiz] = sum;
@@ -400,27 +521,37 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
     }
 }
 
-template <int D, int NS2, bool GRAD>
+template <int D, int NS2, bool GRAD, int NG = 1>
 static int launch_persist_one(const PersistArgs& a, int waves, hipStream_t s) {
     const size_t lds = sizeof(double) * ((size_t)D * a.Np + (size_t)a.H * (D - NS2));
     if (a.Np > GPMPC_PERSIST_MAXNP || a.Np % 64 != 0 || (waves != 8 && waves != 16) || a.H * (D - NS2) > 2 * 512) return GPMPC_E_ARG;
     if (lds > 32 * 1024) {                         // static + dynamic LDS beyond the default 64 KB of a launch: opt in (160 KB per CU on gfx950)
         static bool raised = false;                 // (per instance; a benign race: the attribute is idempotent)
         if (!raised) {
-            if (hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_traj_persist<D, NS2, GRAD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * (D * GPMPC_PERSIST_MAXNP + 2 * 512)));
+            if (hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_traj_persist<D, NS2, GRAD, NG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * (D * GPMPC_PERSIST_MAXNP + 2 * 512)));
                 ea != hipSuccess) { gpmpc_set_error("trajectory-persistent kernel: LDS attribute", ea); return GPMPC_E_LAUNCH; }
             raised = true;
         }
     }
-    hipLaunchKernelGGL((k_traj_persist<D, NS2, GRAD>), dim3(a.B), dim3(64 * waves), lds, s, a);
+    hipLaunchKernelGGL((k_traj_persist<D, NS2, GRAD, NG>), dim3(a.B), dim3(64 * waves), lds, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { gpmpc_set_error("trajectory-persistent rollout kernel launch", e); return GPMPC_E_LAUNCH; }
     return GPMPC_OK;
 }
 
-// ns2 = state_dim (D - ns2 in {1, 2} action dimensions); waves per workgroup 16 | 8
+// ns2 = state_dim (D - ns2 in {1, 2} action dimensions); waves per workgroup 16 | 8; ng = 1, or 2: units of two GPs with one lambda
+// (instantiated up to D = 6: beyond, two GPs' accumulators and lane sums do not fit the 128 registers of four waves per SIMD)
 template <int D>
-int gpmpc_launch_persist_D(bool grad, int ns2, int waves, const PersistArgs& a, hipStream_t s) {
+int gpmpc_launch_persist_D(bool grad, int ns2, int waves, int ng, const PersistArgs& a, hipStream_t s) {
+    if (ng != 1 && ng != 2) return GPMPC_E_ARG;
+    if constexpr (D >= 3 && D <= 6) {
+        if (ng == 2 && ns2 >= 2) {
+            if (ns2 == D - 1) return grad ? launch_persist_one<D, D - 1, true, 2>(a, waves, s) : launch_persist_one<D, D - 1, false, 2>(a, waves, s);
+            if constexpr (D >= 4) { if (ns2 == D - 2) return grad ? launch_persist_one<D, D - 2, true, 2>(a, waves, s) : launch_persist_one<D, D - 2, false, 2>(a, waves, s); }
+            return GPMPC_E_ARG;
+        }
+    }
+    if (ng != 1) return GPMPC_E_ARG;
     if constexpr (D >= 2) {
         if (ns2 == D - 1) return grad ? launch_persist_one<D, (D >= 2 ? D - 1 : 1), true>(a, waves, s) : launch_persist_one<D, (D >= 2 ? D - 1 : 1), false>(a, waves, s);
     }

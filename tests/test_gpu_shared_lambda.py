@@ -86,6 +86,23 @@ def test_every_shape_vs_cport_and_vs_distinct_kernels(G, ds, da, monkeypatch):
     np.testing.assert_allclose(of["cost"].cpu().numpy(), o["cost"].cpu().numpy(), rtol=1e-9)
     monkeypatch.delenv("GPMPC_FUSED_SB")
     pack.reload_tuning()
+    # the whole-horizon kernel over units of TWO GPs (traj_persist.h, NG = 2: the plan for ~one trajectory per CU and more of a training
+    # set of up to 512 points; instantiated up to D = 6 -- beyond, and for a single GP, the distinct-lambda instance runs), forced onto a
+    # small batch, 16 and 8 waves per workgroup: against the C port and, tightly, against the step-per-launch result
+    for pw in ("16", "8"):
+        monkeypatch.setenv("GPMPC_PERSIST", pw)
+        pack.reload_tuning()
+        pl = pack.plan(9, H)
+        assert pl["form"] == "persist" and (("," + ("2" if 3 <= ds + da <= 6 else "1") + ">") in pl["kernel"]), pl
+        w = G.rollout(pack, pb["x0"][:9], pb["U"][:9], cost)
+        _check_vs_cport(w, pb, kinv, [0, 4, 8], f"whole-horizon form ds={ds} da={da} waves={pw}")
+        np.testing.assert_allclose(w["means"].cpu().numpy(), res[b_mid]["means"][:9].cpu().numpy(), rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(w["vars"].cpu().numpy(), res[b_mid]["vars"][:9].cpu().numpy(), rtol=1e-6, atol=1e-14)
+        np.testing.assert_allclose(w["grad"].cpu().numpy(), res[b_mid]["grad"][:9].cpu().numpy(), rtol=1e-5, atol=1e-9)
+        wf = G.rollout(pack, pb["x0"][:9], pb["U"][:9], cost, want_grad=False)
+        np.testing.assert_allclose(wf["cost"].cpu().numpy(), w["cost"].cpu().numpy(), rtol=1e-9)
+    monkeypatch.delenv("GPMPC_PERSIST")
+    pack.reload_tuning()
     # the distinct-lambda kernels on the same pack: the same sums, the exponent rounded the same way -> agreement far inside
     # the tolerance (the tilings and the summation order of the partial sums are the same)
     monkeypatch.setenv("GPMPC_SHARED", "0")
