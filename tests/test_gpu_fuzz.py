@@ -64,6 +64,7 @@ def test_fuzz_whole_horizon_form_vs_cport(G, seed):
     N = int(rng.choice([40, 64, 65, 130, 200, 300, 449, 512]))
     ds = int(rng.integers(1, 7))
     da = int(rng.integers(1, 3))
+    ds = min(ds, 6 - da)                                  # the plan takes this form up to D = 6 (D = 7, 8: forced in test_gpu_instances.py)
     H = int(rng.integers(1, 12))
     B = int(rng.choice([200, 256, 500, 512, 1024]))      # ~0.7-1 and ~2, 4 trajectories per CU (256 CUs): the sizes the plan takes this form at
     gamma = float(rng.choice([-1.0, 1e-5, 0.0, 0.5]))
