@@ -10,7 +10,9 @@
 // ds variance units and the ds(ds-1)/2 cross units), the Jacobians of all steps are kept, and k_fc_tail evaluates the
 // risk-sensitive cost with full Sigma (src/mpc.py:179-198) and runs the reverse sweep.
 #include "gpmpc_internal.h"
+#include "moment_dev.h"
 
+int gpmpc_timed_pair_sbf(int D, bool grad, int ns2, int waves, const PairSbfArgs& a, hipStream_t s);
 int gpmpc_moment_match_ex(const gpmpc_pack* p, int nq, const double* u, const double* S, unsigned flags,
                           double* out_mean, double* out_var, double* out_cov, double* out_l, double* dmean_du,
                           double* dmean_dS, double* dvar_du, double* dvar_dS, double* dcov_du, double* dcov_dS,
@@ -195,6 +197,182 @@ __global__ __launch_bounds__(64) void k_fc_tail(FcArgs A) {
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Small batches: TWO launches per horizon step (round 4).  The step-per-four-launches form above (assemble, prep, pair kernel,
+// finish) leaves the chip to ~10 workgroups for three of the four launches and runs the pair kernel on 256x256 tiles (N = 2048,
+// B = 1: 528 workgroups, two waves per SIMD, each a chain of 256 dependent column round trips: 140 us of a 209 us step).  Here
+//   k_fc_head(t)  one workgroup per (trajectory, unit): closes step t-1 -- the Z0 sums of EVERY unit (each workgroup needs the whole
+//                 covariance to assemble S_t; bit-identical in all workgroups of a trajectory: same code, same order), the full
+//                 moment sums and the Jacobians of its OWN unit only (one thread of wave 3, concurrent with the set-up chains of
+//                 waves 0 / 1) --, assembles (u_t, S_t) in LDS and runs the prep phase of its unit (moment_dev.h);
+//   pair kernel   pair_kernel_sbf.h on 256x128 or 256x64 tiles (4 - 8 waves per SIMD at B = 1).
+// The set-up records (sp) are double-buffered by step parity: the workgroup of a cross unit reads the records of its two
+// variance units of the step being closed while their workgroups write this step's.
+// ---------------------------------------------------------------------------
+struct FcHeadArgs {
+    MomArgs M;                    // M.sp: records of THIS step; Jacobian pointers: slice of the step being closed
+    const double* sp_prev;        // records of the step being closed
+    const double* x0; const double* U;
+    int B, H, da;
+    double* out_means; double* out_covs;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void k_fc_head(FcHeadArgs A, int t) {
+    constexpr int NMX = 1 + D + D * (D + 1) / 2;
+    constexpr bool STAGE = MomPrepLds<D>::STAGE;
+    __shared__ MomPrepLds<D> sh;
+    __shared__ double s_small[STAGE ? 1 : 256];
+    __shared__ double s_z[NMX], s_z0[GPMPC_MAX_DS + GPMPC_MAX_PAIRS], s_mu[GPMPC_MAX_DS], s_cv[GPMPC_MAX_DS * GPMPC_MAX_DS];
+    const MomArgs& M = A.M;
+    const int q = blockIdx.x, unit = blockIdx.y, tid = threadIdx.x, ds = M.ds, nunits = M.nunits, nm = M.nm, H = A.H;
+    if (t >= 2) {
+        double* red = STAGE ? sh.g : s_small;             // 256 doubles; the staging buffer of the prep phase is free until then
+        const double* __restrict__ part = M.part + (size_t)q * M.nwork * nm;
+        int L = 1;
+        while (2 * L * nunits <= 256 && L < 64) L *= 2;
+        {   // Z0 of every unit: L lanes per unit, two independent sums per lane, then the L partial sums in order
+            const int u = tid / L, l = tid - u * L;
+            if (u < nunits) {
+                const int w0 = M.ustart[u], w1 = M.ustart[u + 1];
+                double s0 = 0.0, s1 = 0.0;
+                int wi = w0 + l;
+                for (; wi + L < w1; wi += 2 * L) { s0 += part[(size_t)wi * nm]; s1 += part[(size_t)(wi + L) * nm]; }
+                if (wi < w1) s0 += part[(size_t)wi * nm];
+                red[tid] = s0 + s1;
+            }
+        }
+        __syncthreads();
+        if (tid < nunits) {
+            double s = 0.0;
+            for (int l = 0; l < L; ++l) s += red[tid * L + l];
+            s_z0[tid] = s;
+        }
+        __syncthreads();
+        if (nm > 1) {   // the other moments of this workgroup's unit: 256 / nm lanes per moment
+            const int G = 256 / nm, g = tid / nm, m = tid - g * nm;
+            if (g < G) {
+                const int w0 = M.ustart[unit], w1 = M.ustart[unit + 1];
+                double s0 = 0.0, s1 = 0.0;
+                int wi = w0 + g;
+                for (; wi + G < w1; wi += 2 * G) { s0 += part[(size_t)wi * nm + m]; s1 += part[(size_t)(wi + G) * nm + m]; }
+                if (wi < w1) s0 += part[(size_t)wi * nm + m];
+                red[tid] = s0 + s1;
+            }
+            __syncthreads();
+            if (tid < nm) {
+                double s = 0.0;
+                for (int gg = 0; gg < G; ++gg) s += red[gg * nm + tid];
+                s_z[tid] = tid == 0 ? s_z0[unit] : s;
+            }
+        } else if (tid == 0) s_z[0] = s_z0[unit];
+        // moments of step t-1 (k_mom_finish's formulas)
+        if (tid < nunits) {
+            const double* sp = A.sp_prev + ((size_t)q * nunits + tid) * M.sps;
+            const double c = sp[0];
+            if (tid < ds) {
+                const double mu = sp[1], sf2 = sp[2];
+                const double T = c * s_z0[tid];
+                s_mu[tid] = mu;
+                s_cv[tid * ds + tid] = sf2 - T - mu * mu;
+            } else {
+                const int pr = tid - ds, a = M.pair_ab[2 * pr], b = M.pair_ab[2 * pr + 1];
+                const double mua = A.sp_prev[((size_t)q * nunits + a) * M.sps + 1], mub = A.sp_prev[((size_t)q * nunits + b) * M.sps + 1];
+                const double F = c * s_z0[tid];
+                const double cov = F - mua * mub;
+                s_cv[a * ds + b] = cov; s_cv[b * ds + a] = cov;
+            }
+        }
+        __syncthreads();
+    }
+    // record the state of step t-1 (the workgroup of unit 0) and assemble the input distribution of step t (k_fc_assemble)
+    if (tid < ds) {
+        const double m = (t == 1) ? A.x0[(size_t)q * ds + tid] : s_mu[tid];
+        sh.u[tid] = m;
+        if (unit == 0) A.out_means[((size_t)q * (H + 1) + (t - 1)) * ds + tid] = m;
+    } else if (tid < D && t <= H) sh.u[tid] = A.U[((size_t)q * H + (t - 1)) * A.da + (tid - ds)];
+    if (tid < D * D) {
+        const int k = tid / D, l = tid - k * D;
+        double c = 0.0;
+        if (k < ds && l < ds) {
+            c = (t == 1) ? (k == l ? GPMPC_INIT_VAR : 0.0) : s_cv[k * ds + l];
+            if (unit == 0) A.out_covs[(((size_t)q * (H + 1) + (t - 1)) * ds + k) * ds + l] = c;
+        } else if (k >= ds && l >= ds) c = (k == l) ? GPMPC_ACTION_VAR : 0.0;
+        sh.S[tid] = c;
+    }
+    if (t > H) {                                            // final call: closes step H only
+        if (M.grad && tid == 0) mom_finish_unit<D>(M, A.sp_prev, q, unit, s_z, false);
+        return;
+    }
+    __syncthreads();
+    if (t >= 2 && M.grad && tid == 192) mom_finish_unit<D>(M, A.sp_prev, q, unit, s_z, false);
+    mom_prep_body<D>(M, q, unit, sh);
+}
+
+struct FcPlan2 { int tiling, waves, nwork, nunits, nm, pps, sps, gw; size_t off_pp, off_sp0, off_sp1, off_part, off_G, off_dmu, off_dmS, off_dcu, off_dcS, total; };
+
+// 1: the two-launch form applies and is taken (GPMPC_FC_FORM = 0 / 1 forces)
+static int plan_fc2(const gpmpc_pack* p, int B, int H, bool grad, FcPlan2* r) {
+    if (p->npairs == 0 || !p->fullcov || p->D - p->ds > 2 || p->tune.pair_sb == 0 || p->tune.fc_form == 0) return 0;
+    const long w256 = (long)B * p->wl[1][0].nwork;
+    if (p->tune.fc_form != 1 && w256 >= 4096) return 0;             // the chip is full on the large tiles
+    r->tiling = ((long)B * p->wl[1][4].nwork >= 1024) ? 4 : 2;
+    if (p->tune.fc_tiling == 0 || p->tune.fc_tiling == 2 || p->tune.fc_tiling == 4) r->tiling = p->tune.fc_tiling;
+    const gpmpc_worklist& w = p->wl[1][r->tiling];
+    const size_t ds = p->ds, D = p->D, HB = (size_t)(grad ? H : 0) * B;
+    r->waves = w.waves; r->nwork = w.nwork; r->nunits = w.nunits;
+    r->nm = gpmpc_num_moments(p->D, false, grad);
+    r->pps = 2 * (p->D + p->D * p->D); r->sps = msps_of(p->D); r->gw = gpmpc_sbf_gw(p->D, p->ds);
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += (n * sizeof(double) + 255) & ~(size_t)255; return o; };
+    r->off_pp = take((size_t)B * r->nunits * r->pps);
+    r->off_sp0 = take((size_t)B * r->nunits * r->sps); r->off_sp1 = take((size_t)B * r->nunits * r->sps);
+    r->off_part = take((size_t)B * r->nwork * r->nm);
+    r->off_G = take((size_t)B * r->nunits * p->Np * r->gw);
+    r->off_dmu = take(HB * ds * D); r->off_dmS = take(HB * ds * D * D);
+    r->off_dcu = take(HB * ds * ds * D); r->off_dcS = take(HB * ds * ds * D * D);
+    r->total = off;
+    return 1;
+}
+
+template <int D>
+static int run_fc2(const gpmpc_pack* p, const FcPlan2& r, FcArgs& T, bool grad, char* ws, hipStream_t s) {
+    const int B = T.B, H = T.H;
+    const size_t ds = p->ds, Dz = p->D;
+    FcHeadArgs A;
+    memset(&A, 0, sizeof(A));
+    MomArgs& M = A.M;
+    M.XT = p->XT; M.beta = p->beta; M.lam = p->lam; M.sf = p->sf;
+    M.N = p->N; M.Np = p->Np; M.ds = p->ds; M.D = p->D; M.nq = B;
+    M.pp = (double*)(ws + r.off_pp); M.part = (double*)(ws + r.off_part);
+    M.pps = r.pps; M.sps = r.sps; M.nwork = r.nwork; M.nunits = r.nunits; M.nm = r.nm; M.grad = grad ? 1 : 0;
+    M.ustart = p->wl[1][r.tiling].ustart_dev;
+    M.pair_ab = p->pair_ab_dev; M.npairs = p->npairs;
+    M.G = (double*)(ws + r.off_G); M.gw = r.gw; M.ns2 = p->ds;
+    A.x0 = T.x0; A.U = T.U; A.B = B; A.H = H; A.da = p->da;
+    A.out_means = T.out_means; A.out_covs = T.out_covs;
+    double* sp[2] = {(double*)(ws + r.off_sp0), (double*)(ws + r.off_sp1)};
+    T.dmean_du = (double*)(ws + r.off_dmu); T.dmean_dS = (double*)(ws + r.off_dmS);
+    T.dcov_du = (double*)(ws + r.off_dcu); T.dcov_dS = (double*)(ws + r.off_dcS);
+    PairSbfArgs Q;
+    Q.M = p->M; Q.XT = p->XT; Q.pp = M.pp; Q.G = M.G; Q.part = M.part; Q.work = p->wl[1][r.tiling].work_dev;
+    Q.Np = p->Np; Q.B = B; Q.nunits = r.nunits; Q.nwork = r.nwork; Q.pps = r.pps; Q.nm = r.nm; Q.ntri = p->ds;
+    for (int t = 1; t <= H + 1; ++t) {
+        M.sp = sp[t & 1]; A.sp_prev = sp[(t - 1) & 1];
+        if (grad && t >= 2) {
+            const size_t sl = (size_t)(t - 2) * B;
+            M.dmean_du = T.dmean_du + sl * ds * Dz; M.dmean_dS = T.dmean_dS + sl * ds * Dz * Dz;
+            M.dcov_du = T.dcov_du + sl * ds * ds * Dz; M.dcov_dS = T.dcov_dS + sl * ds * ds * Dz * Dz;
+        }
+        hipLaunchKernelGGL(k_fc_head<D>, dim3(B, r.nunits), dim3(256), 0, s, A, t);
+        if (t > H) break;
+        if (int rc = gpmpc_timed_pair_sbf(p->D, grad, p->ds, r.waves, Q, s)) return rc;
+    }
+    GPMPC_HIP(hipGetLastError());
+    return GPMPC_OK;
+}
+
 struct FcPlan { size_t off_u, off_S, off_mean, off_cov, off_var, off_dvu, off_dvS, off_dmu, off_dmS, off_dcu, off_dcS, off_mm, mm_bytes, total; };
 
 static void plan_fc(const gpmpc_pack* p, int B, int H, bool grad, FcPlan* r) {
@@ -215,6 +393,8 @@ extern "C" size_t gpmpc_rollout_fullcov_workspace_bytes(const gpmpc_pack* p, int
     if (!p || B < 1 || H < 1) return 0;
     FcPlan r;
     plan_fc(p, B, H, (flags & GPMPC_WANT_GRAD) != 0, &r);
+    FcPlan2 r2;
+    if (plan_fc2(p, B, H, (flags & GPMPC_WANT_GRAD) != 0, &r2) && r2.total > r.total) return r2.total;
     return r.total;
 }
 
@@ -230,7 +410,9 @@ extern "C" int gpmpc_rollout_fullcov(const gpmpc_pack* p, int B, int H, const do
     if (grad && !out_grad) return GPMPC_E_ARG;
     FcPlan r;
     plan_fc(p, B, H, grad, &r);
-    if (workspace_bytes < r.total) return GPMPC_E_WORKSPACE;
+    FcPlan2 r2;
+    const bool two = plan_fc2(p, B, H, grad, &r2) != 0;
+    if (workspace_bytes < (two ? r2.total : r.total)) return GPMPC_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace;
     const size_t ds = p->ds, D = p->D;
@@ -238,6 +420,26 @@ extern "C" int gpmpc_rollout_fullcov(const gpmpc_pack* p, int B, int H, const do
     memset(&A, 0, sizeof(A));
     A.B = B; A.H = H; A.ds = p->ds; A.da = p->da; A.D = p->D; A.grad = grad ? 1 : 0;
     A.x0 = x0; A.U = U;
+    const size_t nz = ds + ds * ds;
+    const size_t lds = sizeof(double) * ((size_t)GPMPC_FC_WORKERS * ds * 2 * ds + (H + 1) + (size_t)(H + 1) * nz + 2 * nz + D + D * D);
+    if (lds > 60 * 1024) return GPMPC_E_ARG;
+    if (two) {
+        A.out_means = out_means; A.out_covs = out_covs; A.out_cost = out_cost; A.out_grad = out_grad; A.cost = *cost;
+        int rc = GPMPC_E_ARG;
+        switch (p->D) {
+            case 2: rc = run_fc2<2>(p, r2, A, grad, ws, s); break;
+            case 3: rc = run_fc2<3>(p, r2, A, grad, ws, s); break;
+            case 4: rc = run_fc2<4>(p, r2, A, grad, ws, s); break;
+            case 5: rc = run_fc2<5>(p, r2, A, grad, ws, s); break;
+            case 6: rc = run_fc2<6>(p, r2, A, grad, ws, s); break;
+            case 7: rc = run_fc2<7>(p, r2, A, grad, ws, s); break;
+            case 8: rc = run_fc2<8>(p, r2, A, grad, ws, s); break;
+        }
+        if (rc != GPMPC_OK) return rc;
+        hipLaunchKernelGGL(k_fc_tail, dim3(B), dim3(64), lds, s, A);
+        GPMPC_HIP(hipGetLastError());
+        return GPMPC_OK;
+    }
     A.u = (double*)(ws + r.off_u); A.S = (double*)(ws + r.off_S);
     A.mean = (double*)(ws + r.off_mean); A.cov = (double*)(ws + r.off_cov);
     A.out_means = out_means; A.out_covs = out_covs;
@@ -258,9 +460,6 @@ extern "C" int gpmpc_rollout_fullcov(const gpmpc_pack* p, int B, int H, const do
         if (rc != GPMPC_OK) return rc;
     }
     hipLaunchKernelGGL(k_fc_assemble, gb, tb, 0, s, A, H + 1);      // records step H
-    const size_t nz = ds + ds * ds;
-    const size_t lds = sizeof(double) * ((size_t)GPMPC_FC_WORKERS * ds * 2 * ds + (H + 1) + (size_t)(H + 1) * nz + 2 * nz + D + D * D);
-    if (lds > 60 * 1024) return GPMPC_E_ARG;
     hipLaunchKernelGGL(k_fc_tail, dim3(B), dim3(64), lds, s, A);
     GPMPC_HIP(hipGetLastError());
     return GPMPC_OK;

@@ -47,6 +47,8 @@ struct gpmpc_tuning {
     int fused_sb;    // GPMPC_FUSED_SB    one launch per horizon step for mid-size batches (step_fused.h, Q = 0): 0 off | 1 on | -1 unset
     int split;       // GPMPC_SPLIT       sub-batches (parallel graph branches) of a graph-replayed rollout: 1 none | 2..4 | -1 unset (2 for mid-size batches)
     int shared;      // GPMPC_SHARED      0: never use the shared-lambda kernel (pair_kernel_sbs.h) | -1 unset (used when lambdas are shared)
+    int fc_form;     // GPMPC_FC_FORM     full-covariance rollout: 0 four launches per step | 1 two (fullcov.hip::k_fc_head) | -1 unset (by the size of the launch)
+    int fc_tiling;   // GPMPC_FC_TILING   pair-kernel tiles of the two-launch form: 0 256x256 | 2 256x64 | 4 256x128 | -1 unset
     int persist;     // GPMPC_PERSIST     whole-horizon kernel, one workgroup per trajectory (traj_persist.h): 0 off | 8 / 16 on with that many waves | -1 unset
 };
 void gpmpc_read_tuning(gpmpc_tuning* t);

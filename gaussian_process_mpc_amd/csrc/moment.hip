@@ -15,280 +15,25 @@
 int gpmpc_timed_pair(int D, bool diag, bool grad, int tb, int waves, const PairArgs& a, hipStream_t s);
 int gpmpc_timed_pair_sbf(int D, bool grad, int ns2, int waves, const PairSbfArgs& a, hipStream_t s);
 
-struct MomArgs {
-    const double* XT; const double* beta; const double* lam; const double* sf;
-    int N, Np, ds, D;
-    const double* u; const double* S; int nq;
-    double* pp; double* sp; double* part;
-    int pps, sps, nwork, nunits, nm, grad;
-    const int* ustart;            // work items of unit u: [ustart[u], ustart[u+1])
-    const int* pair_ab; int npairs;   // cross units evaluated by the pair kernel (0: none)
-    double* G; int gw, ns2;           // column rows of the scalar-broadcast kernel (pair_kernel_sbf.h), or null
-    double* out_mean; double* out_var; double* out_cov; double* out_l;
-    double* dmean_du; double* dmean_dS; double* dvar_du; double* dvar_dS; double* dcov_du; double* dcov_dS;
-    unsigned flags;
-};
-
-// sp layout, variance unit a: 0 c | 1 mu | 2 sf2 | 3 Am[D*D] | 3+DD Cm[D*D] | 3+2DD dmu_du[D] | 3+2DD+D dmu_dS[D*D]
-//            cross unit (a,b): 0 c_ab | 1,2 unused | 3 Bab[D*D] | 3+DD Cm[D*D]
-// pp layout per unit: rows [cvec(D) | T(D*D)], columns the same D + D*D doubles further
-__host__ __device__ static inline int msps_of(int D) { return 3 + 3 * D * D + D; }
-
-// In-place inverse and determinant of a small general matrix (Gauss-Jordan, partial pivoting).
-__device__ static double small_inverse(int n, double* a /*[n][n]*/, double* inv /*[n][n]*/) {
-    for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) inv[r * n + c] = (r == c) ? 1.0 : 0.0;
-    double det = 1.0;
-    for (int k = 0; k < n; ++k) {
-        int piv = k; double best = fabs(a[k * n + k]);
-        for (int r = k + 1; r < n; ++r) { const double v = fabs(a[r * n + k]); if (v > best) { best = v; piv = r; } }
-        if (piv != k) {
-            for (int c = 0; c < n; ++c) {
-                double t = a[k * n + c]; a[k * n + c] = a[piv * n + c]; a[piv * n + c] = t;
-                t = inv[k * n + c]; inv[k * n + c] = inv[piv * n + c]; inv[piv * n + c] = t;
-            }
-            det = -det;
-        }
-        const double pv = a[k * n + k];
-        det *= pv;
-        const double ip = 1.0 / pv;
-        for (int c = 0; c < n; ++c) { a[k * n + c] *= ip; inv[k * n + c] *= ip; }
-        for (int r = 0; r < n; ++r) {
-            if (r == k) continue;
-            const double f = a[r * n + k];
-            for (int c = 0; c < n; ++c) { a[r * n + c] = fma(-f, a[k * n + c], a[r * n + c]); inv[r * n + c] = fma(-f, inv[k * n + c], inv[r * n + c]); }
-        }
-    }
-    return det;
-}
+#include "moment_dev.h"
 
 template <int D>
 __global__ __launch_bounds__(256) void k_mom_prep(MomArgs A) {
-    constexpr int NS2 = D * (D + 1) / 2, NV = 1 + D + NS2;
-    __shared__ double s_u[D], s_S[D * D], s_B[D * D];
-    __shared__ double s_scr[16 * NV], s_out[NV];
-    __shared__ double s_tmp[2 * D * D], s_tmpA[D * D], s_Cm[D * D], s_L[D * D], s_cm;
-    constexpr int GWT = (D + 1 + D * (D + 1) / 2 + 1) & ~1;          // widest G row at this D
-    constexpr bool STAGE = GWT <= 28;                               // 256 rows of it within the 64 KB of static LDS
-    __shared__ double s_g[STAGE ? 256 * GWT : 1];
+    __shared__ MomPrepLds<D> sh;
     // one workgroup per (query, unit): the per-unit set-up (D x D inverse, Cholesky factor, D^2 products) is the work of ONE
     // thread, and looping over the units inside a workgroup put ds of those latencies in a row (C5: 400 us per launch)
-    const int q = blockIdx.x, ds = A.ds, unit = blockIdx.y;
-    if (threadIdx.x < D) s_u[threadIdx.x] = A.u[(size_t)q * D + threadIdx.x];
-    if (threadIdx.x < D * D) s_S[threadIdx.x] = A.S[(size_t)q * D * D + threadIdx.x];
+    const int q = blockIdx.x, unit = blockIdx.y;
+    if (threadIdx.x < D) sh.u[threadIdx.x] = A.u[(size_t)q * D + threadIdx.x];
+    if (threadIdx.x < D * D) sh.S[threadIdx.x] = A.S[(size_t)q * D * D + threadIdx.x];
     __syncthreads();
-    if (unit < ds) {
-        const int a = unit;
-        double* sp = A.sp + ((size_t)q * A.nunits + a) * A.sps;
-        double* pp = A.pp + ((size_t)q * A.nunits + a) * A.pps;
-        // Set-up of the unit: the mean side (B = (S + Lambda)^-1) and the variance side (A = (Lambda/2 + S)^-1, its Cholesky
-        // factor) are independent chains of D x D algebra: one lane each, in different waves, on LDS copies; the results go
-        // to global memory afterwards, one element per thread (the chains used to read their own global stores back).
-        if (threadIdx.x == 0) {
-            const double* lam = A.lam + a * D;
-            double detlam = 1.0;
-            for (int k = 0; k < D; ++k) detlam *= lam[k];
-            // B = (S + Lambda)^-1, det(Lambda^-1 S + I) = det(S + Lambda) / det(Lambda)
-            for (int r = 0; r < D; ++r) for (int c = 0; c < D; ++c) s_tmpA[r * D + c] = 0.5 * (s_S[r * D + c] + s_S[c * D + r]) + (r == c ? lam[r] : 0.0);
-            const double detm = small_inverse(D, s_tmpA, s_B) / detlam;
-            const double sf = A.sf[a];
-            s_cm = sf * sf / sqrt(detm);
-        } else if (threadIdx.x == 64) {
-            const double* lam = A.lam + a * D;
-            // A = (Lambda/2 + S)^-1, det(2 Lambda^-1 S + I) = det(S + Lambda/2) / det(Lambda/2)
-            double dethalf = 1.0;
-            for (int k = 0; k < D; ++k) dethalf *= 0.5 * lam[k];
-            for (int r = 0; r < D; ++r) for (int c = 0; c < D; ++c) s_tmp[r * D + c] = 0.5 * (s_S[r * D + c] + s_S[c * D + r]) + (r == c ? 0.5 * lam[r] : 0.0);
-            const double detv = small_inverse(D, s_tmp, s_tmp + D * D) / dethalf;
-            const double* Am = s_tmp + D * D;
-            // Cholesky A/8 = L L^T, Cm = L^T (upper); L in LDS (one lane's D^2 doubles would be 2 D^2 registers of every lane)
-            double* L = s_L;
-            for (int e = 0; e < D * D; ++e) L[e] = 0.0;
-            for (int r = 0; r < D; ++r)
-                for (int c = 0; c <= r; ++c) {
-                    double s = 0.125 * 0.5 * (Am[r * D + c] + Am[c * D + r]);
-                    for (int l = 0; l < c; ++l) s -= L[r * D + l] * L[c * D + l];
-                    L[r * D + c] = (r == c) ? sqrt(s) : s / L[c * D + c];
-                }
-            for (int r = 0; r < D; ++r) for (int c = 0; c < D; ++c) s_Cm[r * D + c] = (c >= r) ? L[c * D + r] : 0.0;
-            const double sf = A.sf[a];
-            sp[0] = 1.0 / sqrt(detv);
-            sp[2] = sf * sf;
-        }
-        __syncthreads();
-        if (threadIdx.x < D * D) {
-            const int e = threadIdx.x;
-            sp[3 + e] = s_tmp[D * D + e];                       // Am
-            sp[3 + D * D + e] = s_Cm[e];
-            pp[D + e] = s_Cm[e]; pp[D + D * D + D + e] = s_Cm[e];
-        }
-        if (threadIdx.x >= 64 && threadIdx.x < 64 + D) {
-            const int k = threadIdx.x - 64;
-            double s = 0.0;
-            for (int l = k; l < D; ++l) s += s_Cm[k * D + l] * s_u[l];
-            pp[k] = s; pp[D + D * D + k] = s;
-        }
-        __syncthreads();
-        double u[D];
-        const double* Bm = s_B;      // read from LDS in the loop (wave-uniform addresses: broadcast reads): 2 D^2 registers less
-#pragma unroll
-        for (int k = 0; k < D; ++k) u[k] = s_u[k];
-        double v[NV];
-#pragma unroll
-        for (int m = 0; m < NV; ++m) v[m] = 0.0;
-        for (int i = threadIdx.x; i < A.Np; i += blockDim.x) {
-            double d[D], qf = 0.0;
-            int boff = 0;
-            asm volatile("" : "+v"(boff));      // opaque offset: keeps the D^2 reads of B in the loop instead of 2 D^2 hoisted registers
-#pragma unroll
-            for (int k = 0; k < D; ++k) d[k] = u[k] - A.XT[(size_t)k * A.Np + i];
-#pragma unroll
-            for (int k = 0; k < D; ++k) {
-                double bd = 0.0;
-#pragma unroll
-                for (int l = 0; l < D; ++l) bd = fma(Bm[boff + k * D + l], d[l], bd);
-                qf = fma(bd, d[k], qf);
-            }
-            const double ex = exp(-0.5 * qf);
-            const double p = A.beta[(size_t)a * A.Np + i] * ex;
-            if (A.out_l && i < A.N) A.out_l[((size_t)q * ds + a) * A.N + i] = s_cm * ex;
-            v[0] += p;
-            int o = 1 + D;
-#pragma unroll
-            for (int k = 0; k < D; ++k) {
-                const double pd = p * d[k];
-                v[1 + k] += pd;
-#pragma unroll
-                for (int l = k; l < D; ++l) { v[o] = fma(pd, d[l], v[o]); ++o; }
-            }
-        }
-        const double cm = s_cm;
-        block_sum<NV>(v, s_scr, s_out);
-        if (threadIdx.x == 0) {
-            const double mu = cm * s_out[0];
-            sp[1] = mu;
-            double* dmu_du = sp + 3 + 2 * D * D;
-            double* dmu_dS = dmu_du + D;
-            double* S2 = s_tmp;                 // LDS scratch of the set-up phase, free by now
-            int o = 1 + D;
-            for (int k = 0; k < D; ++k) for (int l = k; l < D; ++l) { S2[k * D + l] = S2[l * D + k] = s_out[o]; ++o; }
-            for (int k = 0; k < D; ++k) {
-                double s = 0.0;
-                for (int l = 0; l < D; ++l) s += s_B[k * D + l] * s_out[1 + l];
-                dmu_du[k] = -cm * s;
-            }
-            // B S2 B
-            double* BS = s_tmp + D * D;
-            for (int r = 0; r < D; ++r) for (int c = 0; c < D; ++c) { double s = 0.0; for (int l = 0; l < D; ++l) s += s_B[r * D + l] * S2[l * D + c]; BS[r * D + c] = s; }
-            for (int r = 0; r < D; ++r) for (int c = 0; c < D; ++c) {
-                double s = 0.0;
-                for (int l = 0; l < D; ++l) s += BS[r * D + l] * s_B[l * D + c];
-                dmu_dS[r * D + c] = -0.5 * mu * s_B[r * D + c] + 0.5 * cm * s;
-            }
-        }
-        __syncthreads();
-    }
-    // cross-covariance units (a < b): Gaussian-product form of covariance_prop_torch (:402-465)
-    //   Lab = (La^-1 + Lb^-1)^-1, w_a = Lab La^-1, w_b = Lab Lb^-1, Bab = (S + Lab)^-1, c = det(Lab^-1 S + I)^-1/2,
-    //   Cm^T Cm = Bab / 2, rows p_i = Cm (w_a o (u - x_i)), columns q_j = Cm (w_b o (u - x_j)).
-    if (unit >= ds && threadIdx.x == 0) {
-        const int pr = unit - ds;
-        const int a = A.pair_ab[2 * pr], b = A.pair_ab[2 * pr + 1];
-        const double* la = A.lam + a * D; const double* lb = A.lam + b * D;
-        double* sp = A.sp + ((size_t)q * A.nunits + ds + pr) * A.sps;
-        double* pp = A.pp + ((size_t)q * A.nunits + ds + pr) * A.pps;
-        // the matrices live in LDS (free in a cross-unit workgroup): as per-thread arrays indexed by runtime loop counters
-        // they were private (scratch) memory, a global-memory round trip per access
-        double* Mt = s_tmp; double* Bab = s_tmp + D * D; double* L = s_tmpA;
-        double wa[D], wb[D];
-        double detlab = 1.0;
-        for (int k = 0; k < D; ++k) {
-            const double lab = la[k] * lb[k] / (la[k] + lb[k]);
-            wa[k] = lb[k] / (la[k] + lb[k]); wb[k] = la[k] / (la[k] + lb[k]);
-            detlab *= lab;
-            for (int c = 0; c < D; ++c) Mt[k * D + c] = 0.5 * (s_S[k * D + c] + s_S[c * D + k]) + (k == c ? lab : 0.0);
-        }
-        const double det = small_inverse(D, Mt, Bab);
-        sp[0] = sqrt(detlab / det);
-        sp[1] = 0.0; sp[2] = 0.0;
-        for (int e = 0; e < D * D; ++e) { sp[3 + e] = Bab[e]; L[e] = 0.0; }
-        for (int r = 0; r < D; ++r)
-            for (int c = 0; c <= r; ++c) {
-                double s = 0.25 * (Bab[r * D + c] + Bab[c * D + r]);
-                for (int l = 0; l < c; ++l) s -= L[r * D + l] * L[c * D + l];
-                L[r * D + c] = (r == c) ? sqrt(s) : s / L[c * D + c];
-            }
-        double* Cm = s_Cm;
-        for (int r = 0; r < D; ++r) for (int c = 0; c < D; ++c) { Cm[r * D + c] = (c >= r) ? L[c * D + r] : 0.0; sp[3 + D * D + r * D + c] = Cm[r * D + c]; }
-        double* pr_r = pp; double* pr_c = pp + D + D * D;
-        for (int k = 0; k < D; ++k) {
-            double sr = 0.0, sc = 0.0;
-            for (int l = 0; l < D; ++l) {
-                const double tr_ = Cm[k * D + l] * wa[l], tc_ = Cm[k * D + l] * wb[l];
-                pr_r[D + k * D + l] = tr_; pr_c[D + k * D + l] = tc_;
-                sr += tr_ * s_u[l]; sc += tc_ * s_u[l];
-            }
-            pr_r[k] = sr; pr_c[k] = sc;
-        }
-    }
-    if (!A.G) return;
-    // Column rows of every unit for the scalar-broadcast pair kernel: [q_j (D) | |q_j|^2 | q_jk q_jl (k <= l < ns2) | pad]
-    // with q_j = cvec_c - T_c x_j, the unit's COLUMN-side transform written above by this workgroup.
-    __syncthreads();
-    {
-        const int u = unit;
-        const double* prc = A.pp + ((size_t)q * A.nunits + u) * A.pps + D + D * D;
-        double* Gu = A.G + ((size_t)q * A.nunits + u) * A.Np * A.gw;
-        double cv[D];
-        double* T = s_tmp;           // the column-side transform, read from LDS in the loop like B above
-#pragma unroll
-        for (int k = 0; k < D; ++k) cv[k] = prc[k];
-        if (threadIdx.x < D * D) T[threadIdx.x] = prc[D + threadIdx.x];
-        __syncthreads();
-        // The rows of 256 consecutive points are contiguous in G: staged through LDS and written lane-contiguously (a lane
-        // writing its own 8 gw-byte row stores 8 bytes into 64 different cache lines per instruction: C5 376 us per launch
-        // for 671 MB).  D >= 7 (rows of up to 46 doubles) keeps the direct stores: the staging buffer would not fit.
-        for (int i0 = 0; i0 < A.Np; i0 += blockDim.x) {
-            const int i = i0 + threadIdx.x;
-            if (i < A.Np) {
-                double x[D], qv[D], qq = 0.0;
-                int toff = 0;
-                asm volatile("" : "+v"(toff));      // as for B above: T stays in LDS
-#pragma unroll
-                for (int k = 0; k < D; ++k) x[k] = A.XT[(size_t)k * A.Np + i];
-                double* g = STAGE ? s_g + (size_t)threadIdx.x * A.gw : Gu + (size_t)i * A.gw;
-#pragma unroll
-                for (int k = 0; k < D; ++k) {
-                    double sacc = cv[k];
-#pragma unroll
-                    for (int l = k; l < D; ++l) sacc = fma(-T[toff + k * D + l], x[l], sacc);
-                    qv[k] = sacc; g[k] = sacc;
-                    qq = fma(sacc, sacc, qq);
-                }
-                g[D] = GPMPC_EXP_NEG_INV_C * qq;                  // pre-scaled for gpmpc_exp_neg_scaled (fast_exp.h)
-                int o = D + 1;
-#pragma unroll
-                for (int k = 0; k < D; ++k)
-#pragma unroll
-                    for (int l = k; l < D; ++l)
-                        if (k < A.ns2 && l < A.ns2) { g[o] = qv[k] * qv[l]; ++o; }
-                for (; o < A.gw; ++o) g[o] = 0.0;
-            }
-            if (STAGE) {
-                __syncthreads();
-                const int rows = (A.Np - i0 < (int)blockDim.x) ? A.Np - i0 : (int)blockDim.x;
-                double* dst = Gu + (size_t)i0 * A.gw;
-                for (int e = threadIdx.x; e < rows * A.gw; e += blockDim.x) dst[e] = s_g[e];
-                __syncthreads();
-            }
-        }
-    }
+    mom_prep_body<D>(A, q, unit, sh);
 }
 
 template <int D>
 __global__ __launch_bounds__(256) void k_mom_finish(MomArgs A) {
     constexpr int NMX = 1 + D + D * (D + 1) / 2;
     __shared__ double s_z[(GPMPC_MAX_DS + GPMPC_MAX_PAIRS) * NMX];
-    const int q = blockIdx.x, ds = A.ds, nm = A.nm, nunits = A.nunits;
+    const int q = blockIdx.x, nm = A.nm, nunits = A.nunits;
     for (int idx = threadIdx.x; idx < nunits * nm; idx += blockDim.x) {
         const int u = idx / nm, m = idx - u * nm;
         const double* p = A.part + (size_t)q * A.nwork * nm + m;
@@ -306,73 +51,9 @@ __global__ __launch_bounds__(256) void k_mom_finish(MomArgs A) {
     __syncthreads();
     const int u = threadIdx.x;
     if (u >= nunits) return;
-    const double* sp = A.sp + ((size_t)q * nunits + u) * A.sps;
-    const double* z = s_z + u * nm;
-    const double c = sp[0];
-    const double* Bm = sp + 3;                 // Am (variance unit) or Bab (cross unit)
-    const double* Cm = sp + 3 + D * D;
-    double Z2[D * D], CtZ1[D], CZC[D * D];
-    if (A.grad) {
-        int o = 1 + D;
-        for (int k = 0; k < D; ++k) for (int l = k; l < D; ++l) { Z2[k * D + l] = Z2[l * D + k] = z[o]; ++o; }
-        for (int k = 0; k < D; ++k) {
-            double s = 0.0;                                   // (Cm^T Z1)_k
-            for (int l = 0; l <= k; ++l) s += Cm[l * D + k] * z[1 + l];
-            CtZ1[k] = s;
-        }
-        double ZC[D * D];                                     // Z2 Cm
-        for (int r = 0; r < D; ++r) for (int cc = 0; cc < D; ++cc) { double s = 0.0; for (int l = 0; l <= cc; ++l) s += Z2[r * D + l] * Cm[l * D + cc]; ZC[r * D + cc] = s; }
-        for (int r = 0; r < D; ++r) for (int cc = 0; cc < D; ++cc) { double s = 0.0; for (int l = 0; l <= r; ++l) s += Cm[l * D + r] * ZC[l * D + cc]; CZC[r * D + cc] = s; }
-    }
-    if (u < ds) {                                             // variance unit
-        const int a = u;
-        const double mu = sp[1], sf2 = sp[2];
-        const double T = c * z[0];
-        const double var = sf2 - T - mu * mu;
-        A.out_mean[(size_t)q * ds + a] = mu;
-        A.out_var[(size_t)q * ds + a] = var;
-        if (A.out_cov) A.out_cov[((size_t)q * ds + a) * ds + a] = var;
-        if (!A.grad) return;
-        const double* dmu_du = sp + 3 + 2 * D * D;
-        const double* dmu_dS = dmu_du + D;
-        for (int k = 0; k < D; ++k) {
-            const double dT_du = -4.0 * c * CtZ1[k];
-            const double dv = -dT_du - 2.0 * mu * dmu_du[k];
-            A.dmean_du[((size_t)q * ds + a) * D + k] = dmu_du[k];
-            A.dvar_du[((size_t)q * ds + a) * D + k] = dv;
-            if (A.dcov_du) A.dcov_du[(((size_t)q * ds + a) * ds + a) * D + k] = dv;
-        }
-        for (int e = 0; e < D * D; ++e) {
-            const double dT_dS = -0.5 * T * Bm[e] + 8.0 * c * CZC[e];
-            const double dv = -dT_dS - 2.0 * mu * dmu_dS[e];
-            A.dmean_dS[((size_t)q * ds + a) * D * D + e] = dmu_dS[e];
-            A.dvar_dS[((size_t)q * ds + a) * D * D + e] = dv;
-            if (A.dcov_dS) A.dcov_dS[(((size_t)q * ds + a) * ds + a) * D * D + e] = dv;
-        }
-    } else {                                                  // cross unit (a, b): F = c Z0, Cov = F - mu_a mu_b
-        const int pr = u - ds, a = A.pair_ab[2 * pr], b = A.pair_ab[2 * pr + 1];
-        const double* spa = A.sp + ((size_t)q * nunits + a) * A.sps;
-        const double* spb = A.sp + ((size_t)q * nunits + b) * A.sps;
-        const double mua = spa[1], mub = spb[1];
-        const double F = c * z[0];
-        const double cov = F - mua * mub;
-        A.out_cov[((size_t)q * ds + a) * ds + b] = cov;
-        A.out_cov[((size_t)q * ds + b) * ds + a] = cov;
-        if (!A.grad || !A.dcov_du) return;
-        const double* da_du = spa + 3 + 2 * D * D; const double* da_dS = da_du + D;
-        const double* db_du = spb + 3 + 2 * D * D; const double* db_dS = db_du + D;
-        for (int k = 0; k < D; ++k) {
-            const double d = -2.0 * c * CtZ1[k] - mub * da_du[k] - mua * db_du[k];
-            A.dcov_du[(((size_t)q * ds + a) * ds + b) * D + k] = d;
-            A.dcov_du[(((size_t)q * ds + b) * ds + a) * D + k] = d;
-        }
-        for (int e = 0; e < D * D; ++e) {
-            const double d = -0.5 * F * Bm[e] + 2.0 * c * CZC[e] - mub * da_dS[e] - mua * db_dS[e];
-            A.dcov_dS[(((size_t)q * ds + a) * ds + b) * D * D + e] = d;
-            A.dcov_dS[(((size_t)q * ds + b) * ds + a) * D * D + e] = d;
-        }
-    }
+    mom_finish_unit<D>(A, A.sp, q, u, s_z + u * nm, true);
 }
+
 
 // ---------------------------------------------------------------------------
 // Cross-covariance Cov[f_a, f_b] for a != b  (src/tools/uncertainty_prop.py:402-465):

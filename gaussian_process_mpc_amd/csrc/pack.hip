@@ -223,6 +223,8 @@ void gpmpc_read_tuning(gpmpc_tuning* t) {
     t->split = geti("GPMPC_SPLIT", -1);
     t->fused_sb = geti("GPMPC_FUSED_SB", -1);
     t->persist = geti("GPMPC_PERSIST", -1);
+    t->fc_form = geti("GPMPC_FC_FORM", -1);
+    t->fc_tiling = geti("GPMPC_FC_TILING", -1);
 }
 
 extern "C" int gpmpc_pack_reload_tuning(gpmpc_pack* p) {
@@ -278,7 +280,7 @@ extern "C" int gpmpc_pack_create(gpmpc_pack** out, int n_train, int state_dim, i
     if (const char* ev = getenv("GPMPC_JT0")) { const int v = atoi(ev); if (v >= 64 && v % 64 == 0) cfg[0][1] = v; }   // A/B: column extent of the large tiles
     for (int mode = 0; mode < 2 && ok; ++mode)
         for (int k = 0; k < 7 && ok; ++k) {
-            if (mode == 1 && k >= 2) continue;
+            if (mode == 1 && k >= 2 && k != 2 && k != 4) continue;      // full-covariance units: 256x256, 64x64, and 256x64 / 256x128 for small batches (fullcov.hip)
             ok = build_worklist(p->Np, cfg[k][0], cfg[k][1], state_dim, mode ? p->npairs : 0,
                                 mode == 0 && (k == 0 || k == 4) && !p->tune.no_xcd_sort, &p->wl[mode][k]) == 0;
         }

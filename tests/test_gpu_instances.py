@@ -100,7 +100,7 @@ def test_diag_rollout_every_shape_vs_cport(G, ds, da):
 
 
 @pytest.mark.parametrize("ds,da", [(2, 1), (2, 2), (3, 1), (3, 2), (4, 1), (4, 2), (5, 1), (5, 2)])
-def test_fullcov_rollout_every_shape_vs_cport(G, ds, da):
+def test_fullcov_rollout_every_shape_vs_cport(G, ds, da, monkeypatch):
     """Full-covariance rollout (config 5 semantics): the staged kernel (small batch) and pair_kernel_sbf.h (large batch)
     at every input dimension up to 7, against the C port: means, covariances, cost, and the analytic gradient held to
     complex-step directional derivatives of the C port."""
@@ -113,9 +113,29 @@ def test_fullcov_rollout_every_shape_vs_cport(G, ds, da):
     pack = G.GPPack(pb["X"], pb["Y"], kinv, pb["lambdas"], pb["sigma_f"])
     cost = G.CostParams(-1.0, pb["Q"], pb["R"])
     rng = np.random.default_rng(ds * 10 + da)
-    for B in (3, b_big):
+    # (B, overrides): the default plan at a small and a large batch (two launches per step on 256x64 tiles | four on 256x256 tiles +
+    # pair_kernel_sbf.h), the two-launch form forced on each of its tilings, and the four-launch form forced at the small batch
+    cases = [(3, None), (b_big, None)]
+    if da <= 2:
+        cases += [(3, {"GPMPC_FC_FORM": "1", "GPMPC_FC_TILING": "4"}), (2, {"GPMPC_FC_FORM": "1", "GPMPC_FC_TILING": "0"}),
+                  (1, {"GPMPC_FC_FORM": "1", "GPMPC_FC_TILING": "2"}), (3, {"GPMPC_FC_FORM": "0"}), (b_big, {"GPMPC_FC_FORM": "0"})]
+    ref3 = None
+    for B, env in cases:
+        for k, v in (env or {}).items():
+            monkeypatch.setenv(k, v)
+        pack.reload_tuning()
         r = G.rollout_fullcov(pack, pb["x0"][:B], pb["U"][:B], cost)
+        for k in (env or {}):
+            monkeypatch.delenv(k)
+        pack.reload_tuning()
         assert all(torch.isfinite(v).all() for v in r.values())
+        if B == 3:                                  # the forms agree with each other far inside the tolerance against the C port
+            if ref3 is None:
+                ref3 = r
+            else:
+                for key in ("means", "covs", "cost", "grad"):
+                    np.testing.assert_allclose(r[key].cpu().numpy(), ref3[key].cpu().numpy(), rtol=1e-5,          # (the covariances are
+                                               atol=1e-8 * float(ref3[key].abs().max()), err_msg=f"{key} {env}")   # cancelling sums, cut differently)
         pick = [0, B - 1]
         dirs = rng.normal(size=(2, 2, H, da))
         c = cport.rollout_fullcov(pb, kinv, -1.0, x0=pb["x0"][pick], U=pb["U"][pick], dirs=dirs, nthreads=8)
@@ -128,7 +148,13 @@ def test_fullcov_rollout_every_shape_vs_cport(G, ds, da):
             for d in range(2):
                 np.testing.assert_allclose(float((g[k] * dirs[k, d]).sum()), c["ddir"][k, d], rtol=1e-4, atol=1e-7,
                                            err_msg=f"B={B} trajectory {pick[k]} direction {d}")
+        for k, v in (env or {}).items():
+            monkeypatch.setenv(k, v)
+        pack.reload_tuning()
         f = G.rollout_fullcov(pack, pb["x0"][:B], pb["U"][:B], cost, want_grad=False)
+        for k in (env or {}):
+            monkeypatch.delenv(k)
+        pack.reload_tuning()
         np.testing.assert_allclose(f["cost"].cpu().numpy(), r["cost"].cpu().numpy(), rtol=1e-9)
 
 

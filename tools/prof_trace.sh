@@ -7,7 +7,7 @@ ROOTD=$(pwd)      # the tree the job runs in (a staged copy under .stage/ when l
 OUT=$ROOTD/gpurun_out/trace_$CFG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $ROOTD/bench.py --config $CFG --steps 3 --warmup 1 --no-cpu-baseline --no-extras "$@" > $OUT/bench_traced_$CFG.json 2> $OUT/trace.log || { echo "trace failed"; tail -5 $OUT/trace.log; exit 1; }
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $ROOTD/bench.py --config $CFG --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-legs "$@" > $OUT/bench_traced_$CFG.json 2> $OUT/trace.log || { echo "trace failed"; tail -5 $OUT/trace.log; exit 1; }
 find $OUT/kt -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_$CFG.csv \;
 rm -rf $OUT/kt
 head -4 $OUT/kernel_stats_$CFG.csv | cut -c1-160
