@@ -138,11 +138,16 @@ __device__ static double fc_input_cost(int H, int da, const gpmpc_cost_params& C
 }
 
 #define GPMPC_FC_WORKERS 32
-// One workgroup (64 threads) per trajectory.  dynamic LDS:
-//   [WORKERS][ds*2ds] LU scratch | [H+1] cost terms | [H+1][ds + ds*ds] local derivatives | adjoint (2 x (ds + ds*ds)) | g (D + D*D)
-__global__ __launch_bounds__(64) void k_fc_tail(FcArgs A) {
+#define GPMPC_FC_TAIL_TERMS ((GPMPC_MAX_DS + GPMPC_MAX_DS * GPMPC_MAX_DS + 3) / 4)
+// One workgroup (256 threads) per trajectory.  dynamic LDS:
+//   [WORKERS][ds*2ds] LU scratch | [H+1] cost terms | [H+1][ds + ds*ds] local derivatives | adjoint (2 x (ds + ds*ds)) | g (D + ds*ds)
+// Reverse sweep (round 4): the adjoint of (mu_t, Sigma_t) is pulled through step t's Jacobians by FOUR lanes per needed input entry
+// (the D entries of u, the ds x ds state block of S; the action block of S is constant), each lane with its quarter of the
+// ds + ds^2 terms, the Jacobian values of step t-1 loaded while step t is summed: the sweep used to be 64 lanes x 30 entries x 20
+// dependent global round trips (230 us at H = 20, a tenth of a B = 1 rollout).
+__global__ __launch_bounds__(256) void k_fc_tail(FcArgs A) {
     extern __shared__ double s_dyn[];
-    const int b = blockIdx.x, ds = A.ds, da = A.da, D = A.D, H = A.H, nz = ds + ds * ds;
+    const int b = blockIdx.x, ds = A.ds, da = A.da, D = A.D, H = A.H, nz = ds + ds * ds, tid = threadIdx.x;
     double* s_lu = s_dyn;
     double* s_ct = s_lu + GPMPC_FC_WORKERS * ds * 2 * ds;
     double* s_dl = s_ct + (H + 1);
@@ -150,13 +155,36 @@ __global__ __launch_bounds__(64) void k_fc_tail(FcArgs A) {
     double* s_g = s_adj + 2 * nz;
     const double* mu = A.out_means + (size_t)b * (H + 1) * ds;
     const double* Sg = A.out_covs + (size_t)b * (H + 1) * ds * ds;
-    for (int i = threadIdx.x; i <= H && threadIdx.x < GPMPC_FC_WORKERS; i += GPMPC_FC_WORKERS)
-        s_ct[i] = fc_state_cost(ds, A.cost, mu + i * ds, Sg + i * ds * ds, s_lu + threadIdx.x * ds * 2 * ds,
+    for (int i = tid; i <= H && tid < GPMPC_FC_WORKERS; i += GPMPC_FC_WORKERS)
+        s_ct[i] = fc_state_cost(ds, A.cost, mu + i * ds, Sg + i * ds * ds, s_lu + tid * ds * 2 * ds,
                                 A.grad ? s_dl + (size_t)i * nz : nullptr, A.grad ? s_dl + (size_t)i * nz + ds : nullptr);
+    // the entry / term assignment of the sweep and the first prefetch (independent of the cost terms)
+    const int n = tid >> 2, c4 = tid & 3, ne = D + ds * ds;
+    const bool on = A.grad && n < ne;
+    const int eu = n, kl = n >= D ? ((n - D) / ds) * D + (n - D) % ds : 0;
+    const size_t B = A.B;
+    double pf[GPMPC_FC_TAIL_TERMS];
+    auto fetch = [&](int t) {
+        const double* dm_du = A.dmean_du + ((size_t)(t - 1) * B + b) * ds * D;
+        const double* dm_dS = A.dmean_dS + ((size_t)(t - 1) * B + b) * ds * D * D;
+        const double* dc_du = A.dcov_du + ((size_t)(t - 1) * B + b) * ds * ds * D;
+        const double* dc_dS = A.dcov_dS + ((size_t)(t - 1) * B + b) * ds * ds * D * D;
+#pragma unroll
+        for (int k = 0; k < GPMPC_FC_TAIL_TERMS; ++k) {
+            const int j = c4 + 4 * k;
+            double v = 0.0;
+            if (on && j < nz) {
+                if (n < D) v = j < ds ? dm_du[j * D + eu] : dc_du[(j - ds) * D + eu];
+                else v = j < ds ? dm_dS[j * D * D + kl] : dc_dS[(size_t)(j - ds) * D * D + kl];
+            }
+            pf[k] = v;
+        }
+    };
+    if (A.grad) fetch(H);
     __syncthreads();
     const double* U = A.U + (size_t)b * H * da;
     double* gU = A.grad ? A.out_grad + (size_t)b * H * da : nullptr;
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         if (gU) for (int q = 0; q < H * da; ++q) gU[q] = 0.0;
         double total = 0.0;
         for (int i = 0; i <= H; ++i) total += s_ct[i];
@@ -165,38 +193,33 @@ __global__ __launch_bounds__(64) void k_fc_tail(FcArgs A) {
     }
     if (!A.grad) return;
     double* adj = s_adj; double* nxt = s_adj + nz;
-    for (int r = threadIdx.x; r < nz; r += blockDim.x) adj[r] = s_dl[(size_t)H * nz + r];
+    for (int r = tid; r < nz; r += blockDim.x) adj[r] = s_dl[(size_t)H * nz + r];
     __syncthreads();
-    const size_t B = A.B;
     for (int t = H; t >= 1; --t) {
-        const double* dm_du = A.dmean_du + ((size_t)(t - 1) * B + b) * ds * D;
-        const double* dm_dS = A.dmean_dS + ((size_t)(t - 1) * B + b) * ds * D * D;
-        const double* dc_du = A.dcov_du + ((size_t)(t - 1) * B + b) * ds * ds * D;
-        const double* dc_dS = A.dcov_dS + ((size_t)(t - 1) * B + b) * ds * ds * D * D;
-        // g[k] (k < D): d/du_k ; g[D + k*D + l]: d/dS_kl
-        for (int e = threadIdx.x; e < D + D * D; e += blockDim.x) {
-            double s = 0.0;
-            if (e < D) {
-                for (int a = 0; a < ds; ++a) s = fma(adj[a], dm_du[a * D + e], s);
-                for (int ab = 0; ab < ds * ds; ++ab) s = fma(adj[ds + ab], dc_du[ab * D + e], s);
-            } else {
-                const int kl = e - D;
-                for (int a = 0; a < ds; ++a) s = fma(adj[a], dm_dS[a * D * D + kl], s);
-                for (int ab = 0; ab < ds * ds; ++ab) s = fma(adj[ds + ab], dc_dS[ab * D * D + kl], s);
-            }
-            s_g[e] = s;
+        double cur[GPMPC_FC_TAIL_TERMS];
+#pragma unroll
+        for (int k = 0; k < GPMPC_FC_TAIL_TERMS; ++k) cur[k] = pf[k];
+        if (t > 1) fetch(t - 1);
+        // s_g[n]: n < D: d/du_n;  n >= D: d/dS_kl of the state block, (k, l) = ((n - D) / ds, (n - D) % ds)
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < GPMPC_FC_TAIL_TERMS; ++k) {
+            const int j = c4 + 4 * k;
+            if (j < nz) s = fma(adj[j], cur[k], s);
         }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        if (on && c4 == 0) s_g[n] = s;
         __syncthreads();
-        for (int r = threadIdx.x; r < nz + da; r += blockDim.x) {
+        for (int r = tid; r < nz + da; r += blockDim.x) {
             if (r < ds) nxt[r] = s_dl[(size_t)(t - 1) * nz + r] + s_g[r];
-            else if (r < nz) { const int k = (r - ds) / ds, l = (r - ds) - k * ds; nxt[r] = s_dl[(size_t)(t - 1) * nz + r] + s_g[D + k * D + l]; }
+            else if (r < nz) nxt[r] = s_dl[(size_t)(t - 1) * nz + r] + s_g[D + (r - ds)];
             else gU[(t - 1) * da + (r - nz)] += s_g[ds + (r - nz)];
         }
         __syncthreads();
         double* tmp = adj; adj = nxt; nxt = tmp;
     }
 }
-
 
 // ---------------------------------------------------------------------------
 // Small batches: TWO launches per horizon step (round 4).  The step-per-four-launches form above (assemble, prep, pair kernel,
@@ -227,6 +250,13 @@ __global__ __launch_bounds__(256) void k_fc_head(FcHeadArgs A, int t) {
     __shared__ double s_z[NMX], s_z0[GPMPC_MAX_DS + GPMPC_MAX_PAIRS], s_mu[GPMPC_MAX_DS], s_cv[GPMPC_MAX_DS * GPMPC_MAX_DS];
     const MomArgs& M = A.M;
     const int q = blockIdx.x, unit = blockIdx.y, tid = threadIdx.x, ds = M.ds, nunits = M.nunits, nm = M.nm, H = A.H;
+    const int rs = blockIdx.z, RS = gridDim.z;              // workgroups per unit: the first does everything, each its share of the column rows
+    const bool lead = rs == 0;
+#if defined(GPMPC_FC_STAMPS)
+    if (tid == 0) sh.stamp = (t == 3 && q == 0 && rs == 0 && (unit == 0 || unit == nunits - 1)) ? (unit == 0 ? 0 : 32) : -1;
+    __syncthreads();
+#endif
+    GPMPC_FST(0);
     if (t >= 2) {
         double* red = STAGE ? sh.g : s_small;             // 256 doubles; the staging buffer of the prep phase is free until then
         const double* __restrict__ part = M.part + (size_t)q * M.nwork * nm;
@@ -238,24 +268,28 @@ __global__ __launch_bounds__(256) void k_fc_head(FcHeadArgs A, int t) {
                 const int w0 = M.ustart[u], w1 = M.ustart[u + 1];
                 double s0 = 0.0, s1 = 0.0;
                 int wi = w0 + l;
+#pragma unroll 4
                 for (; wi + L < w1; wi += 2 * L) { s0 += part[(size_t)wi * nm]; s1 += part[(size_t)(wi + L) * nm]; }
                 if (wi < w1) s0 += part[(size_t)wi * nm];
                 red[tid] = s0 + s1;
             }
         }
         __syncthreads();
+        GPMPC_FST(1);
         if (tid < nunits) {
             double s = 0.0;
             for (int l = 0; l < L; ++l) s += red[tid * L + l];
             s_z0[tid] = s;
         }
         __syncthreads();
-        if (nm > 1) {   // the other moments of this workgroup's unit: 256 / nm lanes per moment
+        GPMPC_FST(2);
+        if (nm > 1 && lead) {   // the other moments of this workgroup's unit: 256 / nm lanes per moment
             const int G = 256 / nm, g = tid / nm, m = tid - g * nm;
             if (g < G) {
                 const int w0 = M.ustart[unit], w1 = M.ustart[unit + 1];
                 double s0 = 0.0, s1 = 0.0;
                 int wi = w0 + g;
+#pragma unroll 4
                 for (; wi + G < w1; wi += 2 * G) { s0 += part[(size_t)wi * nm + m]; s1 += part[(size_t)(wi + G) * nm + m]; }
                 if (wi < w1) s0 += part[(size_t)wi * nm + m];
                 red[tid] = s0 + s1;
@@ -267,6 +301,7 @@ __global__ __launch_bounds__(256) void k_fc_head(FcHeadArgs A, int t) {
                 s_z[tid] = tid == 0 ? s_z0[unit] : s;
             }
         } else if (tid == 0) s_z[0] = s_z0[unit];
+        GPMPC_FST(3);
         // moments of step t-1 (k_mom_finish's formulas)
         if (tid < nunits) {
             const double* sp = A.sp_prev + ((size_t)q * nunits + tid) * M.sps;
@@ -290,27 +325,32 @@ __global__ __launch_bounds__(256) void k_fc_head(FcHeadArgs A, int t) {
     if (tid < ds) {
         const double m = (t == 1) ? A.x0[(size_t)q * ds + tid] : s_mu[tid];
         sh.u[tid] = m;
-        if (unit == 0) A.out_means[((size_t)q * (H + 1) + (t - 1)) * ds + tid] = m;
+        if (unit == 0 && lead) A.out_means[((size_t)q * (H + 1) + (t - 1)) * ds + tid] = m;
     } else if (tid < D && t <= H) sh.u[tid] = A.U[((size_t)q * H + (t - 1)) * A.da + (tid - ds)];
     if (tid < D * D) {
         const int k = tid / D, l = tid - k * D;
         double c = 0.0;
         if (k < ds && l < ds) {
             c = (t == 1) ? (k == l ? GPMPC_INIT_VAR : 0.0) : s_cv[k * ds + l];
-            if (unit == 0) A.out_covs[(((size_t)q * (H + 1) + (t - 1)) * ds + k) * ds + l] = c;
+            if (unit == 0 && lead) A.out_covs[(((size_t)q * (H + 1) + (t - 1)) * ds + k) * ds + l] = c;
         } else if (k >= ds && l >= ds) c = (k == l) ? GPMPC_ACTION_VAR : 0.0;
         sh.S[tid] = c;
     }
-    if (t > H) {                                            // final call: closes step H only
-        if (M.grad && tid == 0) mom_finish_unit<D>(M, A.sp_prev, q, unit, s_z, false);
-        return;
-    }
     __syncthreads();
-    if (t >= 2 && M.grad && tid == 192) mom_finish_unit<D>(M, A.sp_prev, q, unit, s_z, false);
-    mom_prep_body<D>(M, q, unit, sh);
+    GPMPC_FST(4);
+    if (t >= 2 && M.grad && lead) mom_finish_unit_wg<D>(M, A.sp_prev, q, unit, s_z, sh);      // Jacobians of step t-1, this unit
+    GPMPC_FST(5);
+    if (t > H) return;                                      // final call: closes step H only
+    mom_prep_body<D>(M, q, unit, sh, rs, RS);
 }
 
-struct FcPlan2 { int tiling, waves, nwork, nunits, nm, pps, sps, gw; size_t off_pp, off_sp0, off_sp1, off_part, off_G, off_dmu, off_dmS, off_dcu, off_dcS, total; };
+#if defined(GPMPC_FC_STAMPS)
+extern "C" int gpmpc_debug_fc_stamps(unsigned long long* host_out) {      // [64]
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_fc_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -3;
+}
+#endif
+
+struct FcPlan2 { int tiling, waves, nwork, nunits, nm, pps, sps, gw, rsplit; size_t off_pp, off_sp0, off_sp1, off_part, off_G, off_dmu, off_dmS, off_dcu, off_dcS, total; };
 
 // 1: the two-launch form applies and is taken (GPMPC_FC_FORM = 0 / 1 forces)
 static int plan_fc2(const gpmpc_pack* p, int B, int H, bool grad, FcPlan2* r) {
@@ -323,6 +363,13 @@ static int plan_fc2(const gpmpc_pack* p, int B, int H, bool grad, FcPlan2* r) {
     const size_t ds = p->ds, D = p->D, HB = (size_t)(grad ? H : 0) * B;
     r->waves = w.waves; r->nwork = w.nwork; r->nunits = w.nunits;
     r->nm = gpmpc_num_moments(p->D, false, grad);
+    // workgroups per (trajectory, unit) of the head kernel: one per 256 rows of column rows while the launch stays within ~4 per CU
+    {
+        const int blocks = (p->Np + 255) / 256, room = (int)(1024 / ((long)B * r->nunits));
+        r->rsplit = blocks < room ? blocks : (room > 1 ? room : 1);
+        if (r->rsplit > 16) r->rsplit = 16;
+        if (p->tune.fc_rsplit > 0) r->rsplit = p->tune.fc_rsplit > blocks ? blocks : p->tune.fc_rsplit;
+    }
     r->pps = 2 * (p->D + p->D * p->D); r->sps = msps_of(p->D); r->gw = gpmpc_sbf_gw(p->D, p->ds);
     size_t off = 0;
     auto take = [&](size_t n) { size_t o = off; off += (n * sizeof(double) + 255) & ~(size_t)255; return o; };
@@ -358,6 +405,14 @@ static int run_fc2(const gpmpc_pack* p, const FcPlan2& r, FcArgs& T, bool grad, 
     PairSbfArgs Q;
     Q.M = p->M; Q.XT = p->XT; Q.pp = M.pp; Q.G = M.G; Q.part = M.part; Q.work = p->wl[1][r.tiling].work_dev;
     Q.Np = p->Np; Q.B = B; Q.nunits = r.nunits; Q.nwork = r.nwork; Q.pps = r.pps; Q.nm = r.nm; Q.ntri = p->ds;
+    // columns per iteration of the pair kernel: 4 for launches a wave's column chain bounds -- fewer than 4 waves per SIMD on a
+    // training set of some size, or ONE trajectory streaming more weights than the Infinity Cache holds (N = 2048, ds = 4: 268 MB per
+    // step, 2.13 -> 1.79 ms per rollout) --, else 1: the 20 more registers cost two waves per SIMD (profiles/r04/fullcov_small_batch_ab.txt)
+    {
+        const double mbytes = 8.0 * p->Np * (double)p->Np * (p->npairs + 0.5 * p->ds);
+        Q.cu = (((long)B * r.nwork < 1024 && p->Np >= 512 && p->Np < 1024) || (B == 1 && mbytes > 200e6)) ? 4 : 1;
+        if (p->tune.fc_cu == 1 || p->tune.fc_cu == 2 || p->tune.fc_cu == 4) Q.cu = p->tune.fc_cu;
+    }
     for (int t = 1; t <= H + 1; ++t) {
         M.sp = sp[t & 1]; A.sp_prev = sp[(t - 1) & 1];
         if (grad && t >= 2) {
@@ -365,7 +420,7 @@ static int run_fc2(const gpmpc_pack* p, const FcPlan2& r, FcArgs& T, bool grad, 
             M.dmean_du = T.dmean_du + sl * ds * Dz; M.dmean_dS = T.dmean_dS + sl * ds * Dz * Dz;
             M.dcov_du = T.dcov_du + sl * ds * ds * Dz; M.dcov_dS = T.dcov_dS + sl * ds * ds * Dz * Dz;
         }
-        hipLaunchKernelGGL(k_fc_head<D>, dim3(B, r.nunits), dim3(256), 0, s, A, t);
+        hipLaunchKernelGGL(k_fc_head<D>, dim3(B, r.nunits, t > H ? 1 : r.rsplit), dim3(256), 0, s, A, t);
         if (t > H) break;
         if (int rc = gpmpc_timed_pair_sbf(p->D, grad, p->ds, r.waves, Q, s)) return rc;
     }
@@ -436,7 +491,7 @@ extern "C" int gpmpc_rollout_fullcov(const gpmpc_pack* p, int B, int H, const do
             case 8: rc = run_fc2<8>(p, r2, A, grad, ws, s); break;
         }
         if (rc != GPMPC_OK) return rc;
-        hipLaunchKernelGGL(k_fc_tail, dim3(B), dim3(64), lds, s, A);
+        hipLaunchKernelGGL(k_fc_tail, dim3(B), dim3(256), lds, s, A);
         GPMPC_HIP(hipGetLastError());
         return GPMPC_OK;
     }
@@ -460,7 +515,7 @@ extern "C" int gpmpc_rollout_fullcov(const gpmpc_pack* p, int B, int H, const do
         if (rc != GPMPC_OK) return rc;
     }
     hipLaunchKernelGGL(k_fc_assemble, gb, tb, 0, s, A, H + 1);      // records step H
-    hipLaunchKernelGGL(k_fc_tail, dim3(B), dim3(64), lds, s, A);
+    hipLaunchKernelGGL(k_fc_tail, dim3(B), dim3(256), lds, s, A);
     GPMPC_HIP(hipGetLastError());
     return GPMPC_OK;
 }

@@ -48,6 +48,8 @@ struct gpmpc_tuning {
     int split;       // GPMPC_SPLIT       sub-batches (parallel graph branches) of a graph-replayed rollout: 1 none | 2..4 | -1 unset (2 for mid-size batches)
     int shared;      // GPMPC_SHARED      0: never use the shared-lambda kernel (pair_kernel_sbs.h) | -1 unset (used when lambdas are shared)
     int fc_form;     // GPMPC_FC_FORM     full-covariance rollout: 0 four launches per step | 1 two (fullcov.hip::k_fc_head) | -1 unset (by the size of the launch)
+    int fc_rsplit;   // GPMPC_FC_RSPLIT   workgroups per (trajectory, unit) of the head kernel of the two-launch form | 0 unset
+    int fc_cu;       // GPMPC_FC_CU       columns per iteration of the pair kernel there: 1 | 2 | 4 | 0 unset
     int fc_tiling;   // GPMPC_FC_TILING   pair-kernel tiles of the two-launch form: 0 256x256 | 2 256x64 | 4 256x128 | -1 unset
     int persist;     // GPMPC_PERSIST     whole-horizon kernel, one workgroup per trajectory (traj_persist.h): 0 off | 8 / 16 on with that many waves | -1 unset
 };
@@ -133,6 +135,7 @@ struct PairSbfArgs {
     double* part;         // [B][nwork][nm]
     const int* work;      // [nwork][4] = {unit, i0, j0, j1}
     int Np, B, nunits, nwork, pps, nm, ntri;
+    int cu;               // columns per loop iteration: 1 | 2 | 4 (pair_kernel_sbf.h)
 };
 static inline int gpmpc_sbf_gw(int D, int ns2) { return (D + 1 + ns2 * (ns2 + 1) / 2 + 1) & ~1; }
 int gpmpc_launch_pair_sbf(int D, bool grad, int ns2, int waves, const PairSbfArgs& a, hipStream_t s);

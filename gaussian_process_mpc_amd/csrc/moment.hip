@@ -23,6 +23,9 @@ __global__ __launch_bounds__(256) void k_mom_prep(MomArgs A) {
     // one workgroup per (query, unit): the per-unit set-up (D x D inverse, Cholesky factor, D^2 products) is the work of ONE
     // thread, and looping over the units inside a workgroup put ds of those latencies in a row (C5: 400 us per launch)
     const int q = blockIdx.x, unit = blockIdx.y;
+#if defined(GPMPC_FC_STAMPS)
+    if (threadIdx.x == 0) sh.stamp = -1;
+#endif
     if (threadIdx.x < D) sh.u[threadIdx.x] = A.u[(size_t)q * D + threadIdx.x];
     if (threadIdx.x < D * D) sh.S[threadIdx.x] = A.S[(size_t)q * D * D + threadIdx.x];
     __syncthreads();
@@ -312,7 +315,7 @@ static int run_mom(const gpmpc_pack* p, MomArgs& A, const MomPlan& r, bool grad,
     if (r.sbf) {
         PairSbfArgs Q;
         Q.M = p->M; Q.XT = p->XT; Q.pp = A.pp; Q.G = A.G; Q.part = A.part; Q.work = P.work;
-        Q.Np = p->Np; Q.B = A.nq; Q.nunits = r.nunits; Q.nwork = r.nwork; Q.pps = r.pps; Q.nm = r.nm; Q.ntri = p->ds;
+        Q.Np = p->Np; Q.B = A.nq; Q.nunits = r.nunits; Q.nwork = r.nwork; Q.pps = r.pps; Q.nm = r.nm; Q.ntri = p->ds; Q.cu = 1;
         rc = gpmpc_timed_pair_sbf(D, grad, A.ns2, r.waves, Q, s);
     } else {
         rc = gpmpc_timed_pair(D, false, grad, r.tb, P.colsplit ? 4 : r.waves, P, s);

@@ -105,6 +105,15 @@ __device__ __forceinline__ void lds_cholesky_upper(const double* Am, const doubl
     __syncthreads();
 }
 
+// Diagnostic build (-DGPMPC_FC_STAMPS): s_memtime stamps of thread 0 of two workgroups of k_fc_head (fullcov.hip) at horizon step 3,
+// trajectory 0: the first variance unit (slots 0..) and the last cross unit (slots 32..); tools/fc_stamps.py.
+#if defined(GPMPC_FC_STAMPS)
+static __device__ unsigned long long g_fc_stamps[64];
+#define GPMPC_FST(slot) do { if (sh.stamp >= 0 && threadIdx.x == 0) g_fc_stamps[sh.stamp + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GPMPC_FST(slot) do { } while (0)
+#endif
+
 // LDS of one (query, unit) workgroup of the prep phase
 template <int D>
 struct MomPrepLds {
@@ -113,19 +122,24 @@ struct MomPrepLds {
     static constexpr bool STAGE = GWT <= 28;                          // 256 rows of it within the 64 KB of static LDS
     double u[D], S[D * D], B[D * D];
     double scr[16 * NV], out[NV];
-    double tmp[2 * D * D], tmpA[D * D], Cm[D * D], L[D * D], cm, det[2];
+    double tmp[2 * D * D], tmpA[D * D], Cm[D * D], L[D * D], cm, det[2], cv[D];
     double g[STAGE ? 256 * GWT : 1];
+    int stamp;          // diagnostic builds: first stamp slot of this workgroup, or -1
 };
 
 // Everything of k_mom_prep after the input distribution (sh.u, sh.S) is in LDS: one workgroup of 256 threads per (query q, unit).
 template <int D>
-__device__ __forceinline__ void mom_prep_body(const MomArgs& A, const int q, const int unit, MomPrepLds<D>& sh) {
+// rs, RS: this workgroup is number rs of the RS that share the unit: all of them run the (cheap, bit-identical) set-up, the
+// first alone the mean sums and every store but the column rows, each the column rows of its own 1 / RS of the training set.
+__device__ __forceinline__ void mom_prep_body(const MomArgs& A, const int q, const int unit, MomPrepLds<D>& sh, const int rs = 0, const int RS = 1) {
+    const bool lead = rs == 0;
     constexpr int NV = MomPrepLds<D>::NV;
     constexpr bool STAGE = MomPrepLds<D>::STAGE;
     double* const s_u = sh.u; double* const s_S = sh.S; double* const s_B = sh.B; double* const s_scr = sh.scr; double* const s_out = sh.out;
     double* const s_tmp = sh.tmp; double* const s_tmpA = sh.tmpA; double* const s_Cm = sh.Cm; double* const s_L = sh.L; double& s_cm = sh.cm;
     double* const s_g = sh.g;
     const int ds = A.ds;
+    GPMPC_FST(8);
     if (unit < ds) {
         const int a = unit;
         double* sp = A.sp + ((size_t)q * A.nunits + a) * A.sps;
@@ -150,12 +164,13 @@ __device__ __forceinline__ void mom_prep_body(const MomArgs& A, const int q, con
                 const double detm = sh.det[0] / detlam, detv = sh.det[1] / dethalf;
                 const double sf = A.sf[a];
                 s_cm = sf * sf / sqrt(detm);
-                sp[0] = 1.0 / sqrt(detv);
-                sp[2] = sf * sf;
+                if (lead) { sp[0] = 1.0 / sqrt(detv); sp[2] = sf * sf; }
             }
+            GPMPC_FST(9);
             lds_cholesky_upper<D>(s_tmp + D * D, 0.125, s_L, s_Cm);        // Cholesky A/8 = L L^T, Cm = L^T (upper)
+            GPMPC_FST(10);
         }
-        if (threadIdx.x < D * D) {
+        if (lead && threadIdx.x < D * D) {
             const int e = threadIdx.x;
             sp[3 + e] = s_tmp[D * D + e];                       // Am
             sp[3 + D * D + e] = s_Cm[e];
@@ -165,9 +180,11 @@ __device__ __forceinline__ void mom_prep_body(const MomArgs& A, const int q, con
             const int k = threadIdx.x - 64;
             double s = 0.0;
             for (int l = k; l < D; ++l) s += s_Cm[k * D + l] * s_u[l];
-            pp[k] = s; pp[D + D * D + k] = s;
+            sh.cv[k] = s;
+            if (lead) { pp[k] = s; pp[D + D * D + k] = s; }
         }
         __syncthreads();
+        if (lead) {
         double u[D];
         const double* Bm = s_B;      // read from LDS in the loop (wave-uniform addresses: broadcast reads): 2 D^2 registers less
 #pragma unroll
@@ -175,12 +192,25 @@ __device__ __forceinline__ void mom_prep_body(const MomArgs& A, const int q, con
         double v[NV];
 #pragma unroll
         for (int m = 0; m < NV; ++m) v[m] = 0.0;
+        // (the loads of the next row are issued ahead of the arithmetic of this one: with one workgroup per unit nothing else hides them)
+        double xn[D], bn = 0.0;
+        if ((int)threadIdx.x < A.Np) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) xn[k] = A.XT[(size_t)k * A.Np + threadIdx.x];
+            bn = A.beta[(size_t)a * A.Np + threadIdx.x];
+        }
         for (int i = threadIdx.x; i < A.Np; i += blockDim.x) {
             double d[D], qf = 0.0;
             int boff = 0;
             asm volatile("" : "+v"(boff));      // opaque offset: keeps the D^2 reads of B in the loop instead of 2 D^2 hoisted registers
 #pragma unroll
-            for (int k = 0; k < D; ++k) d[k] = u[k] - A.XT[(size_t)k * A.Np + i];
+            for (int k = 0; k < D; ++k) d[k] = u[k] - xn[k];
+            const double bi = bn;
+            if (i + (int)blockDim.x < A.Np) {
+#pragma unroll
+                for (int k = 0; k < D; ++k) xn[k] = A.XT[(size_t)k * A.Np + i + blockDim.x];
+                bn = A.beta[(size_t)a * A.Np + i + blockDim.x];
+            }
 #pragma unroll
             for (int k = 0; k < D; ++k) {
                 double bd = 0.0;
@@ -189,7 +219,7 @@ __device__ __forceinline__ void mom_prep_body(const MomArgs& A, const int q, con
                 qf = fma(bd, d[k], qf);
             }
             const double ex = exp(-0.5 * qf);
-            const double p = A.beta[(size_t)a * A.Np + i] * ex;
+            const double p = bi * ex;
             if (A.out_l && i < A.N) A.out_l[((size_t)q * ds + a) * A.N + i] = s_cm * ex;
             v[0] += p;
             int o = 1 + D;
@@ -202,7 +232,9 @@ __device__ __forceinline__ void mom_prep_body(const MomArgs& A, const int q, con
             }
         }
         const double cm = s_cm;
-        block_sum<NV>(v, s_scr, s_out);
+        GPMPC_FST(11);
+        block_sum4_rows<NV>(v, s_scr, s_out);
+        GPMPC_FST(12);
         {   // mean and its Jacobians: dmu/du = -cm B S1, dmu/dS = -1/2 mu B + 1/2 cm B S2 B -- one element per thread
             const double mu = cm * s_out[0];
             double* dmu_du = sp + 3 + 2 * D * D;
@@ -230,6 +262,7 @@ __device__ __forceinline__ void mom_prep_body(const MomArgs& A, const int q, con
                 dmu_dS[e] = -0.5 * mu * s_B[e] + 0.5 * cm * s;
             }
         }
+        }       // lead
         __syncthreads();
     }
     // cross-covariance units (a < b): Gaussian-product form of covariance_prop_torch (:402-465)
@@ -249,55 +282,55 @@ __device__ __forceinline__ void mom_prep_body(const MomArgs& A, const int q, con
         }
         __syncthreads();
         lds_inverse_pair<D>(Mt, Bab, nullptr, nullptr, sh.det, false);
-        if (e == 0) {
+        if (lead && e == 0) {
             double detlab = 1.0;
             for (int k = 0; k < D; ++k) detlab *= la[k] * lb[k] / (la[k] + lb[k]);
             sp[0] = sqrt(detlab / sh.det[0]);
             sp[1] = 0.0; sp[2] = 0.0;
         }
-        if (e < D * D) sp[3 + e] = Bab[e];
+        if (lead && e < D * D) sp[3 + e] = Bab[e];
         lds_cholesky_upper<D>(Bab, 0.5, s_tmpA, Cm);            // Cm^T Cm = Bab / 2
         double* pr_r = pp; double* pr_c = pp + D + D * D;
         double* Tr = Mt; double* Tc = s_tmpA;                    // (free by now)
         if (e < D * D) {
             const double wa = lb[c] / (la[c] + lb[c]), wb = la[c] / (la[c] + lb[c]);
             const double tr_ = Cm[e] * wa, tc_ = Cm[e] * wb;
-            sp[3 + D * D + e] = Cm[e];
-            pr_r[D + e] = tr_; pr_c[D + e] = tc_;
+            if (lead) { sp[3 + D * D + e] = Cm[e]; pr_r[D + e] = tr_; pr_c[D + e] = tc_; }
             Tr[e] = tr_; Tc[e] = tc_;
         }
         __syncthreads();
         if (e < D) {
             double sr = 0.0;
             for (int l = 0; l < D; ++l) sr += Tr[e * D + l] * s_u[l];
-            pr_r[e] = sr;
+            if (lead) pr_r[e] = sr;
         } else if (e >= 64 && e < 64 + D) {
             const int k = e - 64;
             double sc = 0.0;
             for (int l = 0; l < D; ++l) sc += Tc[k * D + l] * s_u[l];
-            pr_c[k] = sc;
+            sh.cv[k] = sc;
+            if (lead) pr_c[k] = sc;
         }
     }
+    GPMPC_FST(13);
     if (!A.G) return;
     // Column rows of every unit for the scalar-broadcast pair kernel: [q_j (D) | |q_j|^2 | q_jk q_jl (k <= l < ns2) | pad]
     // with q_j = cvec_c - T_c x_j, the unit's COLUMN-side transform written above by this workgroup.
     __syncthreads();
     {
         const int u = unit;
-        const double* prc = A.pp + ((size_t)q * A.nunits + u) * A.pps + D + D * D;
         double* Gu = A.G + ((size_t)q * A.nunits + u) * A.Np * A.gw;
         double cv[D];
-        double* T = s_tmp;           // the column-side transform, read from LDS in the loop like B above
+        const double* T = unit < ds ? s_Cm : s_tmpA;    // the column-side transform (LDS copies of what went to pp), read from LDS in the loop like B above
 #pragma unroll
-        for (int k = 0; k < D; ++k) cv[k] = prc[k];
-        if (threadIdx.x < D * D) T[threadIdx.x] = prc[D + threadIdx.x];
-        __syncthreads();
+        for (int k = 0; k < D; ++k) cv[k] = sh.cv[k];
+        const int rchunk = (((A.Np + 255) / 256 + RS - 1) / RS) * 256;      // rows of this workgroup: [rs * rchunk, + rchunk)
+        const int row0 = rs * rchunk, row1 = row0 + rchunk < A.Np ? row0 + rchunk : A.Np;
         // The rows of 256 consecutive points are contiguous in G: staged through LDS and written lane-contiguously (a lane
         // writing its own 8 gw-byte row stores 8 bytes into 64 different cache lines per instruction: C5 376 us per launch
         // for 671 MB).  D >= 7 (rows of up to 46 doubles) keeps the direct stores: the staging buffer would not fit.
-        for (int i0 = 0; i0 < A.Np; i0 += blockDim.x) {
+        for (int i0 = row0; i0 < row1; i0 += blockDim.x) {
             const int i = i0 + threadIdx.x;
-            if (i < A.Np) {
+            if (i < row1) {
                 double x[D], qv[D], qq = 0.0;
                 int toff = 0;
                 asm volatile("" : "+v"(toff));      // as for B above: T stays in LDS
@@ -323,13 +356,15 @@ __device__ __forceinline__ void mom_prep_body(const MomArgs& A, const int q, con
             }
             if (STAGE) {
                 __syncthreads();
-                const int rows = (A.Np - i0 < (int)blockDim.x) ? A.Np - i0 : (int)blockDim.x;
+                const int rows = (row1 - i0 < (int)blockDim.x) ? row1 - i0 : (int)blockDim.x;
                 double* dst = Gu + (size_t)i0 * A.gw;
+#pragma unroll 4
                 for (int e = threadIdx.x; e < rows * A.gw; e += blockDim.x) dst[e] = s_g[e];
                 __syncthreads();
             }
         }
     }
+    GPMPC_FST(14);
 }
 
 // Closing algebra of ONE unit u of query q (one thread): z = the unit's nm moment sums, spbase = the set-up record array
@@ -407,4 +442,72 @@ __device__ __forceinline__ void mom_finish_unit(const MomArgs& A, const double* 
             A.dcov_dS[(((size_t)q * ds + b) * ds + a) * D * D + e] = d;
         }
     }
+}
+
+// The same by the whole workgroup for ONE unit (k_fc_head): the D x D products one element per thread, LDS scratch from the prep
+// phase's (sh.tmp, sh.tmpA, sh.L: free until mom_prep_body).  Jacobians only (A.grad set); every thread of the workgroup calls it.
+template <int D>
+__device__ __forceinline__ void mom_finish_unit_wg(const MomArgs& A, const double* __restrict__ spbase, const int q, const int u,
+                                                   const double* z, MomPrepLds<D>& sh) {
+    const int ds = A.ds, nunits = A.nunits, e = threadIdx.x, r = e / D, cc = e - r * D;
+    const double* sp = spbase + ((size_t)q * nunits + u) * A.sps;
+    const double* Bm = sp + 3;
+    double* CmL = sh.tmp; double* Z2 = sh.tmp + D * D; double* ZC = sh.tmpA; double* CtZ1 = sh.L;
+    double bme = 0.0;
+    if (e < D * D) {
+        CmL[e] = sp[3 + D * D + e];
+        bme = Bm[e];
+        const int k = r < cc ? r : cc, l = r < cc ? cc : r;
+        Z2[e] = z[1 + D + k * D - k * (k - 1) / 2 + (l - k)];
+    }
+    const double c = sp[0];
+    __syncthreads();
+    if (e < D * D) { double s = 0.0; for (int l = 0; l <= cc; ++l) s += Z2[r * D + l] * CmL[l * D + cc]; ZC[e] = s; }      // Z2 Cm
+    if (e >= 64 && e < 64 + D) {
+        const int k = e - 64;
+        double s = 0.0;                                       // (Cm^T Z1)_k
+        for (int l = 0; l <= k; ++l) s += CmL[l * D + k] * z[1 + l];
+        CtZ1[k] = s;
+    }
+    __syncthreads();
+    double czc = 0.0;
+    if (e < D * D) for (int l = 0; l <= r; ++l) czc += CmL[l * D + r] * ZC[l * D + cc];                                        // Cm^T Z2 Cm
+    if (u < ds) {
+        const int a = u;
+        const double mu = sp[1];
+        const double T = c * z[0];
+        const double* dmu_du = sp + 3 + 2 * D * D;
+        const double* dmu_dS = dmu_du + D;
+        if (e < D) {
+            const double dT_du = -4.0 * c * CtZ1[e];
+            const double dv = -dT_du - 2.0 * mu * dmu_du[e];
+            A.dmean_du[((size_t)q * ds + a) * D + e] = dmu_du[e];
+            if (A.dcov_du) A.dcov_du[(((size_t)q * ds + a) * ds + a) * D + e] = dv;
+        }
+        if (e < D * D) {
+            const double dT_dS = -0.5 * T * bme + 8.0 * c * czc;
+            const double dv = -dT_dS - 2.0 * mu * dmu_dS[e];
+            A.dmean_dS[((size_t)q * ds + a) * D * D + e] = dmu_dS[e];
+            if (A.dcov_dS) A.dcov_dS[(((size_t)q * ds + a) * ds + a) * D * D + e] = dv;
+        }
+    } else if (A.dcov_du) {
+        const int pr = u - ds, a = A.pair_ab[2 * pr], b = A.pair_ab[2 * pr + 1];
+        const double* spa = spbase + ((size_t)q * nunits + a) * A.sps;
+        const double* spb = spbase + ((size_t)q * nunits + b) * A.sps;
+        const double mua = spa[1], mub = spb[1];
+        const double F = c * z[0];
+        const double* da_du = spa + 3 + 2 * D * D; const double* da_dS = da_du + D;
+        const double* db_du = spb + 3 + 2 * D * D; const double* db_dS = db_du + D;
+        if (e < D) {
+            const double d = -2.0 * c * CtZ1[e] - mub * da_du[e] - mua * db_du[e];
+            A.dcov_du[(((size_t)q * ds + a) * ds + b) * D + e] = d;
+            A.dcov_du[(((size_t)q * ds + b) * ds + a) * D + e] = d;
+        }
+        if (e < D * D) {
+            const double d = -0.5 * F * bme + 2.0 * c * czc - mub * da_dS[e] - mua * db_dS[e];
+            A.dcov_dS[(((size_t)q * ds + a) * ds + b) * D * D + e] = d;
+            A.dcov_dS[(((size_t)q * ds + b) * ds + a) * D * D + e] = d;
+        }
+    }
+    __syncthreads();                 // the scratch goes back to the prep phase
 }

@@ -225,6 +225,8 @@ void gpmpc_read_tuning(gpmpc_tuning* t) {
     t->persist = geti("GPMPC_PERSIST", -1);
     t->fc_form = geti("GPMPC_FC_FORM", -1);
     t->fc_tiling = geti("GPMPC_FC_TILING", -1);
+    t->fc_rsplit = geti("GPMPC_FC_RSPLIT", 0);
+    t->fc_cu = geti("GPMPC_FC_CU", 0);
 }
 
 extern "C" int gpmpc_pack_reload_tuning(gpmpc_pack* p) {

@@ -13,7 +13,10 @@
 #include "gpmpc_internal.h"
 #include "fast_exp.h"
 
-template <int D, int NS2, bool GRAD>
+// CU: columns per loop iteration (their M_ij loads issued together at the top).  1 for launches that fill the chip (C5: the other
+// waves of the SIMD hide a column's round trips); 2 / 4 for the small batches of the two-launch rollout form (fullcov.hip), where a
+// wave's column chain -- scalar loads of the G row, the M_ij load, the dependent exponent -- IS the run time of the launch.
+template <int D, int NS2, bool GRAD, int CU = 1>
 __global__ __launch_bounds__(256) void gpmpc_pair_kernel_sbf(PairSbfArgs A) {
     constexpr int NW = NS2 * (NS2 + 1) / 2;
     constexpr int GW = (D + 1 + NW + 1) & ~1;
@@ -68,19 +71,46 @@ __global__ __launch_bounds__(256) void gpmpc_pair_kernel_sbf(PairSbfArgs A) {
         const __amdgpu_buffer_rsrc_t Mrs =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Ma + (size_t)jstart * Np + iw0), 0, 0x7fffffff, 0x00020000);
         const int lane8 = lane * 8;
-        for (int jc = jstart; jc < j1; ++jc) {           // one column per iteration: see GPMPC_SB_CU in pair_kernel_sb.h
-            const double mij = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, (jc - jstart) * Np * 8, 0));
-            const double* __restrict__ g = G + (size_t)jc * GW;              // wave-uniform address -> SGPRs
-            double s = qi + g[D];
+        if (CU == 1) {
+            for (int jc = jstart; jc < j1; ++jc) {           // one column per iteration: see GPMPC_SB_CU in pair_kernel_sb.h
+                const double mij = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, (jc - jstart) * Np * 8, 0));
+                const double* __restrict__ g = G + (size_t)jc * GW;              // wave-uniform address -> SGPRs
+                double s = qi + g[D];
 #pragma unroll
-            for (int k = 0; k < D; ++k) s = fma(p2[k], g[k], s);
-            const double P = mij * gpmpc_exp_neg_scaled(s, s_tab);
-            acc[0] += P;
-            if (GRAD) {
+                for (int k = 0; k < D; ++k) s = fma(p2[k], g[k], s);
+                const double P = mij * gpmpc_exp_neg_scaled(s, s_tab);
+                acc[0] += P;
+                if (GRAD) {
 #pragma unroll
-                for (int k = 0; k < D; ++k) acc[1 + k] = fma(P, g[k], acc[1 + k]);
+                    for (int k = 0; k < D; ++k) acc[1 + k] = fma(P, g[k], acc[1 + k]);
 #pragma unroll
-                for (int k = 0; k < NW; ++k) acc[1 + D + k] = fma(P, g[D + 1 + k], acc[1 + D + k]);
+                    for (int k = 0; k < NW; ++k) acc[1 + D + k] = fma(P, g[D + 1 + k], acc[1 + D + k]);
+                }
+            }
+        } else {
+            // (column ranges of the work lists are multiples of 64 long, and so is jstart - j0)
+            for (int jc = jstart; jc < j1; jc += CU) {
+                double mij[CU];
+#pragma unroll
+                for (int q = 0; q < CU; ++q)
+                    mij[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, (jc - jstart + q) * Np * 8, 0));
+                __builtin_amdgcn_sched_barrier(0);               // the loads stay at the top of the iteration (pair_kernel_sb.h)
+#pragma unroll
+                for (int q = 0; q < CU; ++q) {
+                    typedef const double __attribute__((address_space(4))) gpmpc_cdouble;       // scalar loads whatever the compiler can prove (pair_kernel_sb.h)
+                    const gpmpc_cdouble* __restrict__ g = (const gpmpc_cdouble*)(G + (size_t)(jc + q) * GW);
+                    double s = qi + g[D];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) s = fma(p2[k], g[k], s);
+                    const double P = mij[q] * gpmpc_exp_neg_scaled(s, s_tab);
+                    acc[0] += P;
+                    if (GRAD) {
+#pragma unroll
+                        for (int k = 0; k < D; ++k) acc[1 + k] = fma(P, g[k], acc[1 + k]);
+#pragma unroll
+                        for (int k = 0; k < NW; ++k) acc[1 + D + k] = fma(P, g[D + 1 + k], acc[1 + D + k]);
+                    }
+                }
             }
         }
     }
@@ -128,6 +158,10 @@ __global__ __launch_bounds__(256) void gpmpc_pair_kernel_sbf(PairSbfArgs A) {
 template <int D, int NS2, bool GRAD>
 static int launch_pair_sbf_one(int waves, const PairSbfArgs& a, hipStream_t s) {
     dim3 grid(a.B * a.nwork), block(64 * waves);
+    // the multi-column instances exist for the rollout's shapes (NS2 = state_dim = D - 1, D - 2)
+    if (a.cu == 2 && NS2 < D) hipLaunchKernelGGL((gpmpc_pair_kernel_sbf<D, NS2, GRAD, (NS2 < D ? 2 : 1)>), grid, block, 0, s, a);
+    else if (a.cu == 4 && NS2 < D) hipLaunchKernelGGL((gpmpc_pair_kernel_sbf<D, NS2, GRAD, (NS2 < D ? 4 : 1)>), grid, block, 0, s, a);
+    else
     hipLaunchKernelGGL((gpmpc_pair_kernel_sbf<D, NS2, GRAD>), grid, block, 0, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { gpmpc_set_error("pair kernel (scalar broadcast, full S) launch", e); return GPMPC_E_LAUNCH; }

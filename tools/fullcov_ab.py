@@ -15,7 +15,8 @@ from gaussian_process_mpc_amd.synth import synth_problem
 ap = argparse.ArgumentParser()
 ap.add_argument("--shapes", default="2048:4:1:20,1024:4:1:20,512:3:1:20,300:4:1:10")
 ap.add_argument("--batches", default="1,2,4,8,16")
-ap.add_argument("--forms", default="old:0:-1,two64:1:2,two128:1:4,two256:1:0,default:-1:-1")
+ap.add_argument("--forms", default="old:0:-1,two64:1:2,two128:1:4,two256:1:0,default:-1:-1",
+                help="name:GPMPC_FC_FORM:GPMPC_FC_TILING[:GPMPC_FC_CU[:GPMPC_FC_RSPLIT]] (-1: unset)")
 args = ap.parse_args()
 dev = g.require_gpu()
 forms = [f.split(":") for f in args.forms.split(",")]
@@ -39,8 +40,11 @@ for shape in args.shapes.split(","):
         x0 = torch.as_tensor(pb["x0"][:B], device=dev)
         U = torch.as_tensor(pb["U"][:B], device=dev)
         line, ref = f"{shape:>14s} B={B:<3d}", None
-        for name, form, tiling in forms:
-            for k, v in (("GPMPC_FC_FORM", form), ("GPMPC_FC_TILING", tiling)):
+        for spec in forms:
+            name, form, tiling = spec[:3]
+            cu = spec[3] if len(spec) > 3 else "-1"
+            rsp = spec[4] if len(spec) > 4 else "-1"
+            for k, v in (("GPMPC_FC_FORM", form), ("GPMPC_FC_TILING", tiling), ("GPMPC_FC_CU", cu), ("GPMPC_FC_RSPLIT", rsp)):
                 if v == "-1":
                     os.environ.pop(k, None)
                 else:
@@ -63,4 +67,5 @@ for shape in args.shapes.split(","):
                 err = max(float((r[k] - ref[k]).abs().max() / ref[k].abs().max()) for k in ("cost", "grad", "covs"))
             line += f"  {name}: {dt * 1e3:8.3f} ms ~{err:.0e}"
         print(line, flush=True)
-    os.environ.pop("GPMPC_FC_FORM", None); os.environ.pop("GPMPC_FC_TILING", None)
+    for k in ("GPMPC_FC_FORM", "GPMPC_FC_TILING", "GPMPC_FC_CU", "GPMPC_FC_RSPLIT"):
+        os.environ.pop(k, None)
