@@ -330,6 +330,8 @@ LEGS = [
     ("C3_shared_lambda", ["--config", "C3", "--shared-lambda", "--steps", "5", "--warmup", "2"]),
     ("C3_B1_graph", ["--config", "C3", "--batch", "1", "--graph", "--steps", "100", "--warmup", "20"]),
     ("C4_B1_graph", ["--config", "C4", "--batch", "1", "--graph", "--steps", "20", "--warmup", "5"]),
+    ("C5_B1", ["--config", "C5", "--batch", "1", "--steps", "20", "--warmup", "5"]),
+    ("N300_B256_shared_lambda", ["--config", "C3", "--n-train", "300", "--batch", "256", "--shared-lambda", "--steps", "20", "--warmup", "5"]),
     ("N300_B256", ["--config", "C3", "--n-train", "300", "--batch", "256", "--steps", "20", "--warmup", "5"]),
     ("closed_loop_newton", ["--closed-loop", "--cl-newton", "--cl-steps", "50"]),
 ]
@@ -557,7 +559,7 @@ def run_rank(args):
             kernel_timed_in = "the timed region"
         launch_s = (full_ms / full_n) * 1e-3 if full_n else float("nan")
         # mid-size batches run as concurrent sub-batches (step.hip split_count): one timed launch then covers B / S trajectories
-        plan = pack.plan(B, H, want_grad=want_grad, graph=args.graph) if not fullcov else {}
+        plan = pack.plan(B, H, want_grad=want_grad, graph=args.graph) if not fullcov else pack.plan_fullcov(B, H, want_grad=want_grad)
         persist = plan.get("form") == "persist"                # whole-horizon kernel: ONE launch per rollout call
         per_rollout = 1 if persist else (H if fused_path else max(H - 1, 1))
         n_timed_calls = args.steps if kernel_timed_in == "the timed region" else max(3, min(args.steps, 20))
@@ -579,6 +581,8 @@ def run_rank(args):
         issue_util = (i_f64 + i_int) * 4.0 * pairs_per_launch / 64.0 / (1024 * launch_s * 2.4e9)
         executed_frac = pairs_per_launch * i_fl / launch_s / 1e12 / FP64_PEAK_TFLOPS
         kname = plan.get("kernel") or f"gpmpc_pair_kernel_{sm}"
+        if fullcov and plan.get("form") == "four_launch":
+            kname = f"gpmpc_pair_kernel_{sm}"
         kname += (" (whole horizon of one trajectory per workgroup: every step's mean sums, pair sums and finish work)" if persist else
                   " (one launch per horizon step: mean sums + finish work + pair tiles; NOT a pair-only time)" if fused_path
                   else " (full variant; the cheaper horizon-step-1 variant is reported under first_step_variant)")

@@ -82,6 +82,7 @@ SIGNATURES = {
     "gpmpc_rollout": (_i, [_vp, _i, _i, _vp, _vp, ctypes.POINTER(CostParamsC), _u, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gpmpc_objective_gradient": (_i, [_vp, _i, _dp, _dp, ctypes.POINTER(CostParamsC), _u, _dp, _vp]),
     "gpmpc_rollout_fullcov_workspace_bytes": (_sz, [_vp, _i, _i, _u]),
+    "gpmpc_rollout_fullcov_describe": (_i, [_vp, _i, _i, _u, ctypes.c_char_p, _sz]),
     "gpmpc_rollout_fullcov": (_i, [_vp, _i, _i, _vp, _vp, ctypes.POINTER(CostParamsC), _u, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gpmpc_timing_enable": (_i, [_i]),
     "gpmpc_pair_kernel_time": (_i, [_dp, ctypes.POINTER(ctypes.c_longlong), _i]),

@@ -9,6 +9,7 @@
 // trajectory, gpmpc_moment_match evaluates means, full covariance and their Jacobians (one pair-kernel launch over the
 // ds variance units and the ds(ds-1)/2 cross units), the Jacobians of all steps are kept, and k_fc_tail evaluates the
 // risk-sensitive cost with full Sigma (src/mpc.py:179-198) and runs the reverse sweep.
+#include <cstdio>
 #include "gpmpc_internal.h"
 #include "moment_dev.h"
 
@@ -140,7 +141,9 @@ __device__ static double fc_input_cost(int H, int da, const gpmpc_cost_params& C
 #define GPMPC_FC_WORKERS 32
 #define GPMPC_FC_TAIL_TERMS ((GPMPC_MAX_DS + GPMPC_MAX_DS * GPMPC_MAX_DS + 3) / 4)
 // One workgroup (256 threads) per trajectory.  dynamic LDS:
-//   [WORKERS][ds*2ds] LU scratch | [H+1] cost terms | [H+1][ds + ds*ds] local derivatives | adjoint (2 x (ds + ds*ds)) | g (D + ds*ds)
+//   [WORKERS][ds*2ds] LU scratch | [H+1] cost terms | [H+1][ds + ds*ds] local derivatives | adjoint (2 x (ds + ds*ds)) | g (D + D*D) |
+//   U [H*da] | dJ/dU [H*da]
+// (the inputs and their gradient live in LDS: as global read-modify-writes of one lane the input cost was 20 dependent round trips.)
 // Reverse sweep (round 4): the adjoint of (mu_t, Sigma_t) is pulled through step t's Jacobians by FOUR lanes per needed input entry
 // (the D entries of u, the ds x ds state block of S; the action block of S is constant), each lane with its quarter of the
 // ds + ds^2 terms, the Jacobian values of step t-1 loaded while step t is summed: the sweep used to be 64 lanes x 30 entries x 20
@@ -153,6 +156,9 @@ __global__ __launch_bounds__(256) void k_fc_tail(FcArgs A) {
     double* s_dl = s_ct + (H + 1);
     double* s_adj = s_dl + (size_t)(H + 1) * nz;
     double* s_g = s_adj + 2 * nz;
+    double* s_U = s_g + D + D * D;
+    double* s_gU = s_U + H * da;
+    for (int r = tid; r < H * da; r += blockDim.x) { s_U[r] = A.U[(size_t)b * H * da + r]; s_gU[r] = 0.0; }
     const double* mu = A.out_means + (size_t)b * (H + 1) * ds;
     const double* Sg = A.out_covs + (size_t)b * (H + 1) * ds * ds;
     for (int i = tid; i <= H && tid < GPMPC_FC_WORKERS; i += GPMPC_FC_WORKERS)
@@ -182,13 +188,10 @@ __global__ __launch_bounds__(256) void k_fc_tail(FcArgs A) {
     };
     if (A.grad) fetch(H);
     __syncthreads();
-    const double* U = A.U + (size_t)b * H * da;
-    double* gU = A.grad ? A.out_grad + (size_t)b * H * da : nullptr;
     if (tid == 0) {
-        if (gU) for (int q = 0; q < H * da; ++q) gU[q] = 0.0;
         double total = 0.0;
         for (int i = 0; i <= H; ++i) total += s_ct[i];
-        total += fc_input_cost(H, da, A.cost, U, gU);
+        total += fc_input_cost(H, da, A.cost, s_U, A.grad ? s_gU : nullptr);
         A.out_cost[b] = total;
     }
     if (!A.grad) return;
@@ -214,11 +217,12 @@ __global__ __launch_bounds__(256) void k_fc_tail(FcArgs A) {
         for (int r = tid; r < nz + da; r += blockDim.x) {
             if (r < ds) nxt[r] = s_dl[(size_t)(t - 1) * nz + r] + s_g[r];
             else if (r < nz) nxt[r] = s_dl[(size_t)(t - 1) * nz + r] + s_g[D + (r - ds)];
-            else gU[(t - 1) * da + (r - nz)] += s_g[ds + (r - nz)];
+            else s_gU[(t - 1) * da + (r - nz)] += s_g[ds + (r - nz)];
         }
         __syncthreads();
         double* tmp = adj; adj = nxt; nxt = tmp;
     }
+    for (int r = tid; r < H * da; r += blockDim.x) A.out_grad[(size_t)b * H * da + r] = s_gU[r];
 }
 
 // ---------------------------------------------------------------------------
@@ -350,14 +354,17 @@ extern "C" int gpmpc_debug_fc_stamps(unsigned long long* host_out) {      // [64
 }
 #endif
 
-struct FcPlan2 { int tiling, waves, nwork, nunits, nm, pps, sps, gw, rsplit; size_t off_pp, off_sp0, off_sp1, off_part, off_G, off_dmu, off_dmS, off_dcu, off_dcS, total; };
+struct FcPlan2 { int tiling, waves, nwork, nunits, nm, pps, sps, gw, rsplit, cu; size_t off_pp, off_sp0, off_sp1, off_part, off_G, off_dmu, off_dmS, off_dcu, off_dcS, total; };
 
 // 1: the two-launch form applies and is taken (GPMPC_FC_FORM = 0 / 1 forces)
 static int plan_fc2(const gpmpc_pack* p, int B, int H, bool grad, FcPlan2* r) {
     if (p->npairs == 0 || !p->fullcov || p->D - p->ds > 2 || p->tune.pair_sb == 0 || p->tune.fc_form == 0) return 0;
+    // Measured over N = 300 ... 2048, B = 1 ... 128 (profiles/r04/fullcov_small_batch_ab.txt): the two-launch form wins while the
+    // large-tile launch of the four-launch form is below ~16 k workgroups, and at any batch for N <= 512; its tiles: the narrowest
+    // whose launch stays within ~16 k workgroups.
     const long w256 = (long)B * p->wl[1][0].nwork;
-    if (p->tune.fc_form != 1 && w256 >= 4096) return 0;             // the chip is full on the large tiles
-    r->tiling = ((long)B * p->wl[1][4].nwork >= 1024) ? 4 : 2;
+    if (p->tune.fc_form != 1 && w256 >= 16384 && p->Np > 512) return 0;
+    r->tiling = (long)B * p->wl[1][2].nwork <= 16384 ? 2 : ((long)B * p->wl[1][4].nwork <= 16384 ? 4 : 0);
     if (p->tune.fc_tiling == 0 || p->tune.fc_tiling == 2 || p->tune.fc_tiling == 4) r->tiling = p->tune.fc_tiling;
     const gpmpc_worklist& w = p->wl[1][r->tiling];
     const size_t ds = p->ds, D = p->D, HB = (size_t)(grad ? H : 0) * B;
@@ -369,6 +376,14 @@ static int plan_fc2(const gpmpc_pack* p, int B, int H, bool grad, FcPlan2* r) {
         r->rsplit = blocks < room ? blocks : (room > 1 ? room : 1);
         if (r->rsplit > 16) r->rsplit = 16;
         if (p->tune.fc_rsplit > 0) r->rsplit = p->tune.fc_rsplit > blocks ? blocks : p->tune.fc_rsplit;
+    }
+    // columns per iteration of the pair kernel (pair_kernel_sbf.h): 2, software-pipelined, while a wave's column chain bounds the launch
+    // (N = 2048, B = 1: 68 -> 57 us per launch, 4.7 TB/s of weights; N = 300 ... 1024 at B = 1: -12 %); 1 (8 instead of 5 waves per
+    // SIMD) once the chip is full
+    {
+        const long wgs = (long)B * r->nwork;
+        r->cu = (wgs < 6000 && !(p->Np < 512 && wgs >= 1024)) ? 2 : 1;
+        if (p->tune.fc_cu == 1 || p->tune.fc_cu == 2 || p->tune.fc_cu == 4) r->cu = p->tune.fc_cu;
     }
     r->pps = 2 * (p->D + p->D * p->D); r->sps = msps_of(p->D); r->gw = gpmpc_sbf_gw(p->D, p->ds);
     size_t off = 0;
@@ -405,14 +420,7 @@ static int run_fc2(const gpmpc_pack* p, const FcPlan2& r, FcArgs& T, bool grad, 
     PairSbfArgs Q;
     Q.M = p->M; Q.XT = p->XT; Q.pp = M.pp; Q.G = M.G; Q.part = M.part; Q.work = p->wl[1][r.tiling].work_dev;
     Q.Np = p->Np; Q.B = B; Q.nunits = r.nunits; Q.nwork = r.nwork; Q.pps = r.pps; Q.nm = r.nm; Q.ntri = p->ds;
-    // columns per iteration of the pair kernel: 4 for launches a wave's column chain bounds -- fewer than 4 waves per SIMD on a
-    // training set of some size, or ONE trajectory streaming more weights than the Infinity Cache holds (N = 2048, ds = 4: 268 MB per
-    // step, 2.13 -> 1.79 ms per rollout) --, else 1: the 20 more registers cost two waves per SIMD (profiles/r04/fullcov_small_batch_ab.txt)
-    {
-        const double mbytes = 8.0 * p->Np * (double)p->Np * (p->npairs + 0.5 * p->ds);
-        Q.cu = (((long)B * r.nwork < 1024 && p->Np >= 512 && p->Np < 1024) || (B == 1 && mbytes > 200e6)) ? 4 : 1;
-        if (p->tune.fc_cu == 1 || p->tune.fc_cu == 2 || p->tune.fc_cu == 4) Q.cu = p->tune.fc_cu;
-    }
+    Q.cu = r.cu;
     for (int t = 1; t <= H + 1; ++t) {
         M.sp = sp[t & 1]; A.sp_prev = sp[(t - 1) & 1];
         if (grad && t >= 2) {
@@ -453,6 +461,22 @@ extern "C" size_t gpmpc_rollout_fullcov_workspace_bytes(const gpmpc_pack* p, int
     return r.total;
 }
 
+extern "C" int gpmpc_rollout_fullcov_describe(const gpmpc_pack* p, int B, int H, unsigned flags, char* out, size_t out_bytes) {
+    if (!p || !out || out_bytes < 64 || B < 1 || H < 1) return GPMPC_E_ARG;
+    const bool grad = (flags & GPMPC_WANT_GRAD) != 0;
+    FcPlan2 r2;
+    if (plan_fc2(p, B, H, grad, &r2)) {
+        const gpmpc_worklist& w = p->wl[1][r2.tiling];
+        snprintf(out, out_bytes, "form=two_launch tiling=%dx%d workgroups=%ld columns_per_iteration=%d head_workgroups_per_unit=%d "
+                 "kernel=gpmpc_pair_kernel_sbf<%d,%d,%s,%d>", w.it, w.jt, (long)B * r2.nwork, r2.cu, r2.rsplit, p->D, p->ds,
+                 grad ? "true" : "false", r2.cu);
+    } else {
+        snprintf(out, out_bytes, "form=four_launch tiling=by_gpmpc_moment_match workgroups=0 columns_per_iteration=1 "
+                 "head_workgroups_per_unit=1 kernel=gpmpc_pair_kernel_sbf<%d,%d,%s,1>|staged", p->D, p->ds, grad ? "true" : "false");
+    }
+    return GPMPC_OK;
+}
+
 extern "C" int gpmpc_rollout_fullcov(const gpmpc_pack* p, int B, int H, const double* x0, const double* U,
                                      const gpmpc_cost_params* cost, unsigned flags, double* out_means, double* out_covs,
                                      double* out_cost, double* out_grad, void* workspace, size_t workspace_bytes,
@@ -476,7 +500,7 @@ extern "C" int gpmpc_rollout_fullcov(const gpmpc_pack* p, int B, int H, const do
     A.B = B; A.H = H; A.ds = p->ds; A.da = p->da; A.D = p->D; A.grad = grad ? 1 : 0;
     A.x0 = x0; A.U = U;
     const size_t nz = ds + ds * ds;
-    const size_t lds = sizeof(double) * ((size_t)GPMPC_FC_WORKERS * ds * 2 * ds + (H + 1) + (size_t)(H + 1) * nz + 2 * nz + D + D * D);
+    const size_t lds = sizeof(double) * ((size_t)GPMPC_FC_WORKERS * ds * 2 * ds + (H + 1) + (size_t)(H + 1) * nz + 2 * nz + D + D * D + 2 * (size_t)H * p->da);
     if (lds > 60 * 1024) return GPMPC_E_ARG;
     if (two) {
         A.out_means = out_means; A.out_covs = out_covs; A.out_cost = out_cost; A.out_grad = out_grad; A.cost = *cost;

@@ -89,12 +89,13 @@ __global__ __launch_bounds__(256) void gpmpc_pair_kernel_sbf(PairSbfArgs A) {
             }
         } else {
             // (column ranges of the work lists are multiples of 64 long, and so is jstart - j0)
-            for (int jc = jstart; jc < j1; jc += CU) {
-                double mij[CU];
-#pragma unroll
-                for (int q = 0; q < CU; ++q)
-                    mij[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, (jc - jstart + q) * Np * 8, 0));
-                __builtin_amdgcn_sched_barrier(0);               // the loads stay at the top of the iteration (pair_kernel_sb.h)
+            // Software pipeline: the M_ij loads of the NEXT group of CU columns are in flight while this group is evaluated (a wave
+            // that waits for its loads at the top of every iteration spends one HBM latency per CU columns: N = 2048, B = 1 68 us per
+            // launch at 3.9 TB/s).  The refill is unconditional (the last iteration re-reads its own columns): under a branch the
+            // compiler waits for ALL outstanding loads instead of counting them.
+            // Two register sets in alternation (a copy "this = next" would make the compiler wait for the loads it copies).
+            double ma[CU], mb[CU];
+            auto columns = [&](const int jc, const double (&mij)[CU]) {
 #pragma unroll
                 for (int q = 0; q < CU; ++q) {
                     typedef const double __attribute__((address_space(4))) gpmpc_cdouble;       // scalar loads whatever the compiler can prove (pair_kernel_sb.h)
@@ -111,6 +112,22 @@ __global__ __launch_bounds__(256) void gpmpc_pair_kernel_sbf(PairSbfArgs A) {
                         for (int k = 0; k < NW; ++k) acc[1 + D + k] = fma(P, g[D + 1 + k], acc[1 + D + k]);
                     }
                 }
+            };
+#pragma unroll
+            for (int q = 0; q < CU; ++q)
+                ma[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, q * Np * 8, 0));     // (in bounds for any jstart <= Np - 64)
+            for (int jc = jstart; jc < j1; jc += 2 * CU) {
+#pragma unroll
+                for (int q = 0; q < CU; ++q)
+                    mb[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, (jc - jstart + CU + q) * Np * 8, 0));
+                __builtin_amdgcn_sched_barrier(0);               // the loads stay ahead of the arithmetic (pair_kernel_sb.h)
+                columns(jc, ma);
+                const int jn = jc + 2 * CU < j1 ? jc + 2 * CU : jc;
+#pragma unroll
+                for (int q = 0; q < CU; ++q)
+                    ma[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, (jn - jstart + q) * Np * 8, 0));
+                __builtin_amdgcn_sched_barrier(0);
+                columns(jc + CU, mb);
             }
         }
     }

@@ -176,6 +176,18 @@ class GPPack:
             out[k] = int(v) if v.lstrip("-").isdigit() else v
         return out
 
+    def plan_fullcov(self, B, H, want_grad=True):
+        """What ``rollout_fullcov`` launches for this call shape (C ABI ``gpmpc_rollout_fullcov_describe``): dict with ``form``
+        (``two_launch`` | ``four_launch``), ``tiling``, ``workgroups``, ``columns_per_iteration``, ``head_workgroups_per_unit``, ``kernel``."""
+        buf = ctypes.create_string_buffer(512)
+        check(lib().gpmpc_rollout_fullcov_describe(self._h, int(B), int(H), _lib.WANT_GRAD if want_grad else 0, buf, 512),
+              "gpmpc_rollout_fullcov_describe")
+        out = {}
+        for kv in buf.value.decode().split():
+            k, v = kv.split("=", 1)
+            out[k] = int(v) if v.lstrip("-").isdigit() else v
+        return out
+
     def autotune(self, B, H, want_grad=True, graph=False):
         """Time the candidate plans of this call shape on this device and keep the fastest for later calls (C ABI
         ``gpmpc_pack_autotune``).  Returns a list of dicts (``name``, ``ms``, ``winner``, plan fields), the default plan first."""

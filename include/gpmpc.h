@@ -277,6 +277,12 @@ int gpmpc_rollout_fullcov(const gpmpc_pack* pack, int B, int H, const double* x0
                           const gpmpc_cost_params* cost_host, unsigned flags,
                           double* out_means, double* out_covs, double* out_cost, double* out_grad,
                           void* workspace, size_t workspace_bytes, void* stream);
+/* Diagnostic (no reference counterpart): what gpmpc_rollout_fullcov launches for this call shape, as one line of text --
+ * "form=<four_launch|two_launch> tiling=<rows>x<cols> workgroups=<of the pair kernel, per horizon step> columns_per_iteration=<1|2|4>
+ *  head_workgroups_per_unit=<n> kernel=<pair kernel>".  Small batches run TWO launches per horizon step (round 4; fullcov.hip): a head
+ * kernel that closes the previous step, assembles (u_t, S_t) and prepares every unit, and the pair kernel on narrow tiles; large batches
+ * four (assemble, prepare, pair kernel on 256x256 tiles, close).  out_bytes >= 64; returns 0 or GPMPC_E_ARG. */
+int gpmpc_rollout_fullcov_describe(const gpmpc_pack* pack, int B, int H, unsigned flags, char* out, size_t out_bytes);
 
 /* The solver callback pair RiskSensitiveMPC.objective(x) / gradient(x) (src/mpc.py:202-255) for ONE candidate, host in and
  * host out like the cyipopt callbacks themselves: x0_host [ds] current state, U_host [H][da] the candidate (Ipopt's x),

@@ -180,6 +180,23 @@ def test_c5_full_covariance_at_full_size_against_cport(G, c3):
         for d in range(2):
             np.testing.assert_allclose(float((g[k] * dirs[k, d]).sum()), c["ddir"][k, d], rtol=1e-4, atol=1e-7)
     assert np.abs(r["covs"][:, 1:, 0, 1].cpu().numpy()).max() > 0
+    # the same two trajectories as a batch of TWO and the first one ALONE: the two-launch small-batch form (fullcov.hip::k_fc_head +
+    # the pair kernel on 256x64 tiles, two columns per iteration), directly against the same C-port values
+    cost5 = G.CostParams(cfg["gamma"], big["Q"], big["R"])
+    assert pack5.plan_fullcov(64, cfg["H"])["form"] == "four_launch"
+    for sel in ([0, 63], [0]):
+        plan = pack5.plan_fullcov(len(sel), cfg["H"])
+        assert plan["form"] == "two_launch" and plan["tiling"] == "256x64" and plan["columns_per_iteration"] == 2, plan
+        rs = G.rollout_fullcov(pack5, big["x0"][sel], big["U"][sel], cost5)
+        k = len(sel)
+        np.testing.assert_allclose(rs["means"].cpu().numpy(), c["means"][:k], rtol=1e-5, atol=1e-9, err_msg=str(sel))
+        np.testing.assert_allclose(rs["covs"].cpu().numpy(), c["covs"][:k], rtol=1e-4, atol=1e-6 * np.abs(c["covs"]).max(), err_msg=str(sel))
+        np.testing.assert_allclose(rs["cost"].cpu().numpy(), c["cost"][:k], rtol=1e-6, err_msg=str(sel))
+        gs = rs["grad"].cpu().numpy()
+        for kk in range(k):
+            for d in range(2):
+                np.testing.assert_allclose(float((gs[kk] * dirs[kk, d]).sum()), c["ddir"][kk, d], rtol=1e-4, atol=1e-7, err_msg=str(sel))
+        np.testing.assert_allclose(gs, g[:k], rtol=1e-5, atol=1e-8 * np.abs(g).max())          # and the forms agree on the whole gradient
     del pack5
     torch.cuda.empty_cache()
 
