@@ -16,8 +16,11 @@
 // CU: columns per loop iteration (their M_ij loads issued together at the top).  1 for launches that fill the chip (C5: the other
 // waves of the SIMD hide a column's round trips); 2 / 4 for the small batches of the two-launch rollout form (fullcov.hip), where a
 // wave's column chain -- scalar loads of the G row, the M_ij load, the dependent exponent -- IS the run time of the launch.
+#ifndef GPMPC_SBF_MINWG
+#define GPMPC_SBF_MINWG 1       // A/B: 6 asks the compiler for six workgroups per CU from the two-column instances at D <= 5 (80 instead of 84 VGPRs,
+#endif                          // 6 instead of 5 waves per SIMD): measured SLOWER, N = 2048, B = 1 1.67 -> 1.79 ms (profiles/r04/fullcov_small_batch_ab.txt)
 template <int D, int NS2, bool GRAD, int CU = 1>
-__global__ __launch_bounds__(256) void gpmpc_pair_kernel_sbf(PairSbfArgs A) {
+__global__ __launch_bounds__(256, (CU == 2 && GRAD && D <= 5) ? GPMPC_SBF_MINWG : 1) void gpmpc_pair_kernel_sbf(PairSbfArgs A) {
     constexpr int NW = NS2 * (NS2 + 1) / 2;
     constexpr int GW = (D + 1 + NW + 1) & ~1;
     constexpr int NM = GRAD ? 1 + D + D * (D + 1) / 2 : 1, NA = GRAD ? 1 + D + NW : 1;
