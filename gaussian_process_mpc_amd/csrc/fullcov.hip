@@ -229,11 +229,13 @@ __global__ __launch_bounds__(256) void k_fc_tail(FcArgs A) {
 // Small batches: TWO launches per horizon step (round 4).  The step-per-four-launches form above (assemble, prep, pair kernel,
 // finish) leaves the chip to ~10 workgroups for three of the four launches and runs the pair kernel on 256x256 tiles (N = 2048,
 // B = 1: 528 workgroups, two waves per SIMD, each a chain of 256 dependent column round trips: 140 us of a 209 us step).  Here
-//   k_fc_head(t)  one workgroup per (trajectory, unit): closes step t-1 -- the Z0 sums of EVERY unit (each workgroup needs the whole
-//                 covariance to assemble S_t; bit-identical in all workgroups of a trajectory: same code, same order), the full
-//                 moment sums and the Jacobians of its OWN unit only (one thread of wave 3, concurrent with the set-up chains of
-//                 waves 0 / 1) --, assembles (u_t, S_t) in LDS and runs the prep phase of its unit (moment_dev.h);
-//   pair kernel   pair_kernel_sbf.h on 256x128 or 256x64 tiles (4 - 8 waves per SIMD at B = 1).
+//   k_fc_head(t)  workgroups per (trajectory, unit), by role: RS "column-row" workgroups (one row chunk of the unit's G rows each; the
+//                 first also writes the unit's set-up records and, for unit 0, the trajectory), one "mean" workgroup (variance units:
+//                 B = (S + Lambda)^-1, the O(N) mean sums, mean and mean Jacobians) and one "closing" workgroup (the full moment
+//                 sums and the Jacobians of ITS unit for step t-1).  The first two kinds sum the Z0 partial sums of EVERY unit (each
+//                 needs the whole covariance of step t-1 to assemble (u_t, S_t); bit-identical in all workgroups of a trajectory: same
+//                 code, same order) and run their part of the unit's D x D set-up themselves (moment_dev.h);
+//   pair kernel   pair_kernel_sbf.h on 256x64 (256x128, 256x256) tiles, two software-pipelined columns per iteration at small launches.
 // The set-up records (sp) are double-buffered by step parity: the workgroup of a cross unit reads the records of its two
 // variance units of the step being closed while their workgroups write this step's.
 // ---------------------------------------------------------------------------
@@ -242,6 +244,7 @@ struct FcHeadArgs {
     const double* sp_prev;        // records of the step being closed
     const double* x0; const double* U;
     int B, H, da;
+    int rsplit, zbase;            // row chunks per unit; role index of blockIdx.z = 0 (see k_fc_head)
     double* out_means; double* out_covs;
 };
 
@@ -254,10 +257,18 @@ __global__ __launch_bounds__(256) void k_fc_head(FcHeadArgs A, int t) {
     __shared__ double s_z[NMX], s_z0[GPMPC_MAX_DS + GPMPC_MAX_PAIRS], s_mu[GPMPC_MAX_DS], s_cv[GPMPC_MAX_DS * GPMPC_MAX_DS];
     const MomArgs& M = A.M;
     const int q = blockIdx.x, unit = blockIdx.y, tid = threadIdx.x, ds = M.ds, nunits = M.nunits, nm = M.nm, H = A.H;
-    const int rs = blockIdx.z, RS = gridDim.z;              // workgroups per unit: the first does everything, each its share of the column rows
-    const bool lead = rs == 0;
+    // Workgroups of a (trajectory, unit), by what they do after assembling the step's input: [0, RS) the column rows of one row chunk
+    // each (the first also the set-up records and the record of the trajectory), RS the mean side of a variance unit, RS + 1 the
+    // Jacobians of the step being closed.  The final call (t = H + 1) launches the last kind only.
+    const int RS = A.rsplit, zr = blockIdx.z + A.zbase;
+    const bool g_role = zr < RS, mean_role = zr == RS, close_role = zr > RS;
+    const int rs = g_role ? zr : 0;
+    if (mean_role && unit >= ds) return;                                  // cross units have no mean side
+    if (close_role && t <= H && !(t >= 2 && M.grad)) return;              // nothing to close
+    if (close_role && t > H && !M.grad && unit != 0) return;              // final call without Jacobians: unit 0 records step H
+    const bool all_units = !close_role || t > H;                          // needs the whole covariance of step t-1
 #if defined(GPMPC_FC_STAMPS)
-    if (tid == 0) sh.stamp = (t == 3 && q == 0 && rs == 0 && (unit == 0 || unit == nunits - 1)) ? (unit == 0 ? 0 : 32) : -1;
+    if (tid == 0) sh.stamp = (t == 3 && q == 0 && unit == 0 && zr <= RS + 1 && (zr == 0 || zr >= RS)) ? (zr == 0 ? 0 : (zr == RS ? 16 : 32)) : -1;
     __syncthreads();
 #endif
     GPMPC_FST(0);
@@ -266,9 +277,10 @@ __global__ __launch_bounds__(256) void k_fc_head(FcHeadArgs A, int t) {
         const double* __restrict__ part = M.part + (size_t)q * M.nwork * nm;
         int L = 1;
         while (2 * L * nunits <= 256 && L < 64) L *= 2;
-        {   // Z0 of every unit: L lanes per unit, two independent sums per lane, then the L partial sums in order
+        {   // Z0 of every unit (of this unit alone where that is all that is needed; the same lanes, the same order): L lanes per
+            // unit, two independent sums per lane, then the L partial sums in order
             const int u = tid / L, l = tid - u * L;
-            if (u < nunits) {
+            if (u < nunits && (all_units || u == unit)) {
                 const int w0 = M.ustart[u], w1 = M.ustart[u + 1];
                 double s0 = 0.0, s1 = 0.0;
                 int wi = w0 + l;
@@ -280,14 +292,14 @@ __global__ __launch_bounds__(256) void k_fc_head(FcHeadArgs A, int t) {
         }
         __syncthreads();
         GPMPC_FST(1);
-        if (tid < nunits) {
+        if (tid < nunits && (all_units || tid == unit)) {
             double s = 0.0;
             for (int l = 0; l < L; ++l) s += red[tid * L + l];
             s_z0[tid] = s;
         }
         __syncthreads();
         GPMPC_FST(2);
-        if (nm > 1 && lead) {   // the other moments of this workgroup's unit: 256 / nm lanes per moment
+        if (nm > 1 && close_role) {   // the other moments of this workgroup's unit: 256 / nm lanes per moment
             const int G = 256 / nm, g = tid / nm, m = tid - g * nm;
             if (g < G) {
                 const int w0 = M.ustart[unit], w1 = M.ustart[unit + 1];
@@ -307,7 +319,7 @@ __global__ __launch_bounds__(256) void k_fc_head(FcHeadArgs A, int t) {
         } else if (tid == 0) s_z[0] = s_z0[unit];
         GPMPC_FST(3);
         // moments of step t-1 (k_mom_finish's formulas)
-        if (tid < nunits) {
+        if (all_units && tid < nunits) {
             const double* sp = A.sp_prev + ((size_t)q * nunits + tid) * M.sps;
             const double c = sp[0];
             if (tid < ds) {
@@ -325,27 +337,32 @@ __global__ __launch_bounds__(256) void k_fc_head(FcHeadArgs A, int t) {
         }
         __syncthreads();
     }
-    // record the state of step t-1 (the workgroup of unit 0) and assemble the input distribution of step t (k_fc_assemble)
-    if (tid < ds) {
-        const double m = (t == 1) ? A.x0[(size_t)q * ds + tid] : s_mu[tid];
-        sh.u[tid] = m;
-        if (unit == 0 && lead) A.out_means[((size_t)q * (H + 1) + (t - 1)) * ds + tid] = m;
-    } else if (tid < D && t <= H) sh.u[tid] = A.U[((size_t)q * H + (t - 1)) * A.da + (tid - ds)];
-    if (tid < D * D) {
-        const int k = tid / D, l = tid - k * D;
-        double c = 0.0;
-        if (k < ds && l < ds) {
-            c = (t == 1) ? (k == l ? GPMPC_INIT_VAR : 0.0) : s_cv[k * ds + l];
-            if (unit == 0 && lead) A.out_covs[(((size_t)q * (H + 1) + (t - 1)) * ds + k) * ds + l] = c;
-        } else if (k >= ds && l >= ds) c = (k == l) ? GPMPC_ACTION_VAR : 0.0;
-        sh.S[tid] = c;
+    if (all_units) {
+        // record the state of step t-1 (one workgroup per trajectory) and assemble the input distribution of step t (k_fc_assemble)
+        const bool rec = unit == 0 && ((g_role && rs == 0) || close_role);
+        if (tid < ds) {
+            const double m = (t == 1) ? A.x0[(size_t)q * ds + tid] : s_mu[tid];
+            sh.u[tid] = m;
+            if (rec) A.out_means[((size_t)q * (H + 1) + (t - 1)) * ds + tid] = m;
+        } else if (tid < D && t <= H) sh.u[tid] = A.U[((size_t)q * H + (t - 1)) * A.da + (tid - ds)];
+        if (tid < D * D) {
+            const int k = tid / D, l = tid - k * D;
+            double c = 0.0;
+            if (k < ds && l < ds) {
+                c = (t == 1) ? (k == l ? GPMPC_INIT_VAR : 0.0) : s_cv[k * ds + l];
+                if (rec) A.out_covs[(((size_t)q * (H + 1) + (t - 1)) * ds + k) * ds + l] = c;
+            } else if (k >= ds && l >= ds) c = (k == l) ? GPMPC_ACTION_VAR : 0.0;
+            sh.S[tid] = c;
+        }
     }
     __syncthreads();
     GPMPC_FST(4);
-    if (t >= 2 && M.grad && lead) mom_finish_unit_wg<D>(M, A.sp_prev, q, unit, s_z, sh);      // Jacobians of step t-1, this unit
-    GPMPC_FST(5);
-    if (t > H) return;                                      // final call: closes step H only
-    mom_prep_body<D>(M, q, unit, sh, rs, RS);
+    if (close_role) {
+        if (M.grad) mom_finish_unit_wg<D>(M, A.sp_prev, q, unit, s_z, sh);      // Jacobians of step t-1, this unit
+        GPMPC_FST(5);
+        return;
+    }
+    mom_prep_body<D>(M, q, unit, sh, rs, RS, g_role ? 1 : 2);
 }
 
 #if defined(GPMPC_FC_STAMPS)
@@ -428,7 +445,8 @@ static int run_fc2(const gpmpc_pack* p, const FcPlan2& r, FcArgs& T, bool grad, 
             M.dmean_du = T.dmean_du + sl * ds * Dz; M.dmean_dS = T.dmean_dS + sl * ds * Dz * Dz;
             M.dcov_du = T.dcov_du + sl * ds * ds * Dz; M.dcov_dS = T.dcov_dS + sl * ds * ds * Dz * Dz;
         }
-        hipLaunchKernelGGL(k_fc_head<D>, dim3(B, r.nunits, t > H ? 1 : r.rsplit), dim3(256), 0, s, A, t);
+        A.rsplit = r.rsplit; A.zbase = t > H ? r.rsplit + 1 : 0;
+        hipLaunchKernelGGL(k_fc_head<D>, dim3(B, r.nunits, t > H ? 1 : r.rsplit + 2), dim3(256), 0, s, A, t);
         if (t > H) break;
         if (int rc = gpmpc_timed_pair_sbf(p->D, grad, p->ds, r.waves, Q, s)) return rc;
     }

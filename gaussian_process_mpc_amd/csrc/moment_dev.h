@@ -53,12 +53,12 @@ __device__ static double small_inverse(int n, double* a /*[n][n]*/, double* inv 
 // D x D algebra by the whole workgroup, in LDS (round 4: as single-lane chains of dependent LDS round trips the set-up of a unit cost
 // 20 - 30 us -- most of a small-batch step of the full-covariance rollout).  Every thread of the workgroup must call these (barriers).
 //
-// Inverse and determinant of one or two independent D x D matrices (threads [0, D^2): a0 -> i0; [64, 64 + D^2): a1 -> i1), Gauss-Jordan
+// Inverse and determinant of one or two independent D x D matrices (threads [0, D^2): a0 -> i0; [64, 64 + D^2): a1 -> i1; `which`), Gauss-Jordan
 // WITHOUT pivoting: the callers pass sym(S) + diag(lambda) with S a covariance.  a*: in, destroyed; det[0 / 1]: the determinants.
 template <int D>
-__device__ __forceinline__ void lds_inverse_pair(double* a0, double* i0, double* a1, double* i1, double* det, const bool two) {
+__device__ __forceinline__ void lds_inverse_pair(double* a0, double* i0, double* a1, double* i1, double* det, const int which /* bit 0: a0, bit 1: a1 */) {
     const int w = threadIdx.x >> 6, e = threadIdx.x & 63;
-    const bool on = e < D * D && (w == 0 || (w == 1 && two));
+    const bool on = e < D * D && ((w == 0 && (which & 1)) || (w == 1 && (which & 2)));
     double* const a = w == 0 ? a0 : a1;
     double* const iv = w == 0 ? i0 : i1;
     const int r = e / D, c = e - r * D;
@@ -129,10 +129,14 @@ struct MomPrepLds {
 
 // Everything of k_mom_prep after the input distribution (sh.u, sh.S) is in LDS: one workgroup of 256 threads per (query q, unit).
 template <int D>
-// rs, RS: this workgroup is number rs of the RS that share the unit: all of them run the (cheap, bit-identical) set-up, the
-// first alone the mean sums and every store but the column rows, each the column rows of its own 1 / RS of the training set.
-__device__ __forceinline__ void mom_prep_body(const MomArgs& A, const int q, const int unit, MomPrepLds<D>& sh, const int rs = 0, const int RS = 1) {
-    const bool lead = rs == 0;
+// role: bit 0 -- the variance-side set-up (A = (Lambda/2 + S)^-1, its Cholesky factor; the cross units' whole set-up) and the column rows
+// of row chunk rs of RS, the first chunk also the set-up records; bit 1 -- the mean side of a variance unit (B = (S + Lambda)^-1, the O(N)
+// mean sums, mean and mean Jacobians).  k_mom_prep: one workgroup does both (role 3); k_fc_head (fullcov.hip) splits them over
+// workgroups, which all run their part of the (cheap, bit-identical) set-up themselves.
+__device__ __forceinline__ void mom_prep_body(const MomArgs& A, const int q, const int unit, MomPrepLds<D>& sh, const int rs = 0, const int RS = 1,
+                                              const int role = 3) {
+    const bool need_g = (role & 1) != 0, need_mean = (role & 2) != 0;
+    const bool lead = need_g && rs == 0;
     constexpr int NV = MomPrepLds<D>::NV;
     constexpr bool STAGE = MomPrepLds<D>::STAGE;
     double* const s_u = sh.u; double* const s_S = sh.S; double* const s_B = sh.B; double* const s_scr = sh.scr; double* const s_out = sh.out;
@@ -157,17 +161,16 @@ __device__ __forceinline__ void mom_prep_body(const MomArgs& A, const int q, con
             }
             __syncthreads();
             // B = (S + Lambda)^-1, det(Lambda^-1 S + I) = det(S + Lambda) / det(Lambda);  A likewise with Lambda / 2
-            lds_inverse_pair<D>(s_tmpA, s_B, s_tmp, s_tmp + D * D, sh.det, true);
+            lds_inverse_pair<D>(s_tmpA, s_B, s_tmp, s_tmp + D * D, sh.det, (need_mean ? 1 : 0) | (need_g ? 2 : 0));
             if (threadIdx.x == 0) {
                 double detlam = 1.0, dethalf = 1.0;
                 for (int k = 0; k < D; ++k) { detlam *= lam[k]; dethalf *= 0.5 * lam[k]; }
-                const double detm = sh.det[0] / detlam, detv = sh.det[1] / dethalf;
                 const double sf = A.sf[a];
-                s_cm = sf * sf / sqrt(detm);
-                if (lead) { sp[0] = 1.0 / sqrt(detv); sp[2] = sf * sf; }
+                if (need_mean) s_cm = sf * sf / sqrt(sh.det[0] / detlam);
+                if (lead) { sp[0] = 1.0 / sqrt(sh.det[1] / dethalf); sp[2] = sf * sf; }
             }
             GPMPC_FST(9);
-            lds_cholesky_upper<D>(s_tmp + D * D, 0.125, s_L, s_Cm);        // Cholesky A/8 = L L^T, Cm = L^T (upper)
+            if (need_g) lds_cholesky_upper<D>(s_tmp + D * D, 0.125, s_L, s_Cm);        // Cholesky A/8 = L L^T, Cm = L^T (upper)
             GPMPC_FST(10);
         }
         if (lead && threadIdx.x < D * D) {
@@ -176,7 +179,7 @@ __device__ __forceinline__ void mom_prep_body(const MomArgs& A, const int q, con
             sp[3 + D * D + e] = s_Cm[e];
             pp[D + e] = s_Cm[e]; pp[D + D * D + D + e] = s_Cm[e];
         }
-        if (threadIdx.x >= 64 && threadIdx.x < 64 + D) {
+        if (need_g && threadIdx.x >= 64 && threadIdx.x < 64 + D) {
             const int k = threadIdx.x - 64;
             double s = 0.0;
             for (int l = k; l < D; ++l) s += s_Cm[k * D + l] * s_u[l];
@@ -184,7 +187,7 @@ __device__ __forceinline__ void mom_prep_body(const MomArgs& A, const int q, con
             if (lead) { pp[k] = s; pp[D + D * D + k] = s; }
         }
         __syncthreads();
-        if (lead) {
+        if (need_mean) {
         double u[D];
         const double* Bm = s_B;      // read from LDS in the loop (wave-uniform addresses: broadcast reads): 2 D^2 registers less
 #pragma unroll
@@ -262,12 +265,13 @@ __device__ __forceinline__ void mom_prep_body(const MomArgs& A, const int q, con
                 dmu_dS[e] = -0.5 * mu * s_B[e] + 0.5 * cm * s;
             }
         }
-        }       // lead
+        }       // need_mean
         __syncthreads();
     }
     // cross-covariance units (a < b): Gaussian-product form of covariance_prop_torch (:402-465)
     //   Lab = (La^-1 + Lb^-1)^-1, w_a = Lab La^-1, w_b = Lab Lb^-1, Bab = (S + Lab)^-1, c = det(Lab^-1 S + I)^-1/2,
     //   Cm^T Cm = Bab / 2, rows p_i = Cm (w_a o (u - x_i)), columns q_j = Cm (w_b o (u - x_j)).
+    if (unit >= ds && !need_g) return;                         // (cross units have no mean side)
     if (unit >= ds) {
         const int pr = unit - ds;
         const int a = A.pair_ab[2 * pr], b = A.pair_ab[2 * pr + 1];
@@ -281,7 +285,7 @@ __device__ __forceinline__ void mom_prep_body(const MomArgs& A, const int q, con
             Mt[e] = 0.5 * (s_S[r * D + c] + s_S[c * D + r]) + (r == c ? lab : 0.0);
         }
         __syncthreads();
-        lds_inverse_pair<D>(Mt, Bab, nullptr, nullptr, sh.det, false);
+        lds_inverse_pair<D>(Mt, Bab, nullptr, nullptr, sh.det, 1);
         if (lead && e == 0) {
             double detlab = 1.0;
             for (int k = 0; k < D; ++k) detlab *= la[k] * lb[k] / (la[k] + lb[k]);
@@ -312,7 +316,7 @@ __device__ __forceinline__ void mom_prep_body(const MomArgs& A, const int q, con
         }
     }
     GPMPC_FST(13);
-    if (!A.G) return;
+    if (!A.G || !need_g) return;
     // Column rows of every unit for the scalar-broadcast pair kernel: [q_j (D) | |q_j|^2 | q_jk q_jl (k <= l < ns2) | pad]
     // with q_j = cvec_c - T_c x_j, the unit's COLUMN-side transform written above by this workgroup.
     __syncthreads();

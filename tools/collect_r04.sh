@@ -13,12 +13,14 @@ for c in C3 C4 C5; do bash tools/prof_trace.sh $c > $O/trace_$c.log 2>&1; cp gpu
 bash tools/prof_trace.sh C3 --shared-lambda > $O/trace_C3_shared.log 2>&1; cp gpurun_out/trace_C3/kernel_stats_C3.csv $O/kernel_stats_C3_shared.csv; cp gpurun_out/trace_C3/bench_traced_C3.json $O/bench_traced_C3_shared.json
 bash tools/prof_trace.sh C3 --batch 1 > $O/trace_C3_B1.log 2>&1; cp gpurun_out/trace_C3/kernel_stats_C3.csv $O/kernel_stats_C3_B1.csv; cp gpurun_out/trace_C3/bench_traced_C3.json $O/bench_traced_C3_B1.json
 bash tools/prof_trace.sh C4 --batch 1 > $O/trace_C4_B1.log 2>&1; cp gpurun_out/trace_C4/kernel_stats_C4.csv $O/kernel_stats_C4_B1.csv; cp gpurun_out/trace_C4/bench_traced_C4.json $O/bench_traced_C4_B1.json
+bash tools/prof_trace.sh C5 --batch 1 > $O/trace_C5_B1.log 2>&1; cp gpurun_out/trace_C5/kernel_stats_C5.csv $O/kernel_stats_C5_B1.csv; cp gpurun_out/trace_C5/bench_traced_C5.json $O/bench_traced_C5_B1.json
 bash tools/prof_trace.sh C3 --n-train 300 --batch 256 > $O/trace_N300_B256.log 2>&1; cp gpurun_out/trace_C3/kernel_stats_C3.csv $O/kernel_stats_N300_B256.csv; cp gpurun_out/trace_C3/bench_traced_C3.json $O/bench_traced_N300_B256.json
 # PMC (separate passes, counters only)
 for c in C3 C4 C5; do bash tools/prof_pmc.sh $c > $O/pmc_$c.log 2>&1; cp gpurun_out/pmc_$c/pmc_$c.txt gpurun_out/pmc_$c/pmc_$c.json $O/ 2>/dev/null; done
 bash tools/prof_pmc.sh C3 --shared-lambda > $O/pmc_C3_shared.log 2>&1; cp gpurun_out/pmc_C3/pmc_C3.txt $O/pmc_C3_shared.txt; cp gpurun_out/pmc_C3/pmc_C3.json $O/pmc_C3_shared.json
 PMC_BATCH=1 PMC_STEPS=3 bash tools/prof_pmc.sh C3 --batch 1 > $O/pmc_C3_B1.log 2>&1; cp gpurun_out/pmc_C3/pmc_C3.txt $O/pmc_C3_B1.txt; cp gpurun_out/pmc_C3/pmc_C3.json $O/pmc_C3_B1.json
 PMC_BATCH=1 PMC_STEPS=2 bash tools/prof_pmc.sh C4 --batch 1 > $O/pmc_C4_B1.log 2>&1; cp gpurun_out/pmc_C4/pmc_C4.txt $O/pmc_C4_B1.txt; cp gpurun_out/pmc_C4/pmc_C4.json $O/pmc_C4_B1.json
+PMC_BATCH=1 PMC_STEPS=3 bash tools/prof_pmc.sh C5 --batch 1 > $O/pmc_C5_B1.log 2>&1; cp gpurun_out/pmc_C5/pmc_C5.txt $O/pmc_C5_B1.txt; cp gpurun_out/pmc_C5/pmc_C5.json $O/pmc_C5_B1.json
 fi
 if [ $STEP = all ] || [ $STEP = bench ]; then
 python bench.py > $O/bench_C3.json 2> $O/bench_C3.err || echo "bench C3 failed"
@@ -31,6 +33,8 @@ done
 python bench.py --config C3 --steps 5 --warmup 2 --no-cpu-baseline --forward-only > $O/bench_C3_fwd.json 2>/dev/null
 for b in 1 4 16 32; do python bench.py --config C3 --batch $b --steps 20 --warmup 5 --no-cpu-baseline --graph > $O/bench_C3_B$b.json 2>/dev/null; done
 python bench.py --config C4 --batch 1 --steps 10 --warmup 3 --no-cpu-baseline --graph > $O/bench_C4_B1.json 2>/dev/null
+for b in 1 2 4 8; do python bench.py --config C5 --batch $b --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $O/bench_C5_B$b.json 2>/dev/null; done
+python bench.py --config C3 --n-train 300 --batch 256 --shared-lambda --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $O/bench_N300_B256_shared.json 2>/dev/null
 for n in 300 512; do python bench.py --config C3 --n-train $n --batch 256 --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $O/bench_N${n}_B256.json 2>/dev/null; done
 for b in 8 16 32; do python bench.py --config C3 --n-train 1024 --batch $b --steps 50 --warmup 10 --no-cpu-baseline --no-extras --graph > $O/bench_N1024_B$b.json 2>/dev/null; done
 python bench.py --gpus 2 --oversubscribe --backend gloo --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_2rank_gloo_one_card.json 2>$O/bench_2rank.err
@@ -40,6 +44,7 @@ fi
 if [ $STEP = all ] || [ $STEP = maps ]; then
 python tools/batch_map.py > $O/batch_size_map.txt 2>&1
 python tools/batch_map.py --shapes 300:2:1:10,300:4:1:10,512:3:1:20 --batches 192,256,512,1024 >> $O/batch_size_map.txt 2>&1
+python tools/batch_map.py --fullcov --shapes 300:4:1:10,1024:4:1:20,2048:4:1:20 --batches 1,2,4,8,16,64 > $O/batch_size_map_fullcov.txt 2>&1
 fi
 for f in $O/bench_*.json; do python - "$f" <<'PY'
 import json, sys

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Phase timeline of the head kernel of the two-launch full-covariance rollout (csrc/fullcov.hip::k_fc_head), trajectory 0, horizon
-step 3, the workgroups of the first variance unit and of the last cross unit; diagnostic build:
+step 3, the three kinds of workgroups of the first variance unit; diagnostic build:
     make -C gaussian_process_mpc_amd/csrc BUILD=build_fst LIB=libgpmpc_hip_fst.so EXTRA="-DGPMPC_FC_STAMPS"
     GPMPC_LIB_PATH=.../libgpmpc_hip_fst.so GPMPC_FC_FORM=1 python tools/fc_stamps.py 2048:4:1:20:1"""
 import ctypes, os, sys
@@ -29,7 +29,7 @@ st = np.array(list(buf), dtype=np.int64)
 names = {0: "start", 1: "Z0 partial sums (all units)", 2: "Z0 combined", 3: "own-unit moment sums", 4: "moments + assemble", 5: "closing algebra of the own unit (Jacobians)", 8: "body start",
          9: "inverses (variance unit)", 10: "Cholesky", 11: "set-up stores + row loop", 12: "block sum", 13: "mean Jacobians | cross set-up",
          14: "column rows (G)"}
-for base, title in ((0, "variance unit 0"), (32, "last cross unit")):
+for base, title in ((0, "variance unit 0: column-row workgroup 0"), (16, "variance unit 0: mean workgroup"), (32, "variance unit 0: closing workgroup")):
     print(title)
     prev = st[base]
     for k in sorted(names):
