@@ -244,7 +244,8 @@ struct FcHeadArgs {
     const double* sp_prev;        // records of the step being closed
     const double* x0; const double* U;
     int B, H, da;
-    int rsplit, zbase;            // row chunks per unit; role index of blockIdx.z = 0 (see k_fc_head)
+    int rsplit, zbase;            // row chunks per unit (RS); role index of blockIdx.z = 0 (see k_fc_head)
+    const double* part0;          // [B][nwork] Z0 partial sums of the pair kernel, contiguous
     double* out_means; double* out_covs;
 };
 
@@ -259,7 +260,9 @@ __global__ __launch_bounds__(256) void k_fc_head(FcHeadArgs A, int t) {
     const int q = blockIdx.x, unit = blockIdx.y, tid = threadIdx.x, ds = M.ds, nunits = M.nunits, nm = M.nm, H = A.H;
     // Workgroups of a (trajectory, unit), by what they do after assembling the step's input: [0, RS) the column rows of one row chunk
     // each (the first also the set-up records and the record of the trajectory), RS the mean side of a variance unit, RS + 1 the
-    // Jacobians of the step being closed.  The final call (t = H + 1) launches the last kind only.
+    // Jacobians of the step being closed.  The final call (t = H + 1) launches the last kind only.  (The mean side split over row
+    // chunks with an arrival counter was built and measured: the device-scope fence it needs writes back and invalidates L2 on this
+    // multi-XCD part, 16 k cycles per workgroup; profiles/r04/fc_head_stamps_ticket.txt.)
     const int RS = A.rsplit, zr = blockIdx.z + A.zbase;
     const bool g_role = zr < RS, mean_role = zr == RS, close_role = zr > RS;
     const int rs = g_role ? zr : 0;
@@ -267,6 +270,31 @@ __global__ __launch_bounds__(256) void k_fc_head(FcHeadArgs A, int t) {
     if (close_role && t <= H && !(t >= 2 && M.grad)) return;              // nothing to close
     if (close_role && t > H && !M.grad && unit != 0) return;              // final call without Jacobians: unit 0 records step H
     const bool all_units = !close_role || t > H;                          // needs the whole covariance of step t-1
+    // Between two head kernels the pair kernel streams hundreds of MB through the L2: whatever this kernel reads first comes from the
+    // Infinity Cache / HBM (~2.5 k cycles per dependent round trip, 5 of them in a row as first written).  Everything small that the
+    // later phases read -- hyper-parameters, the set-up records of the step being closed, the work-list index -- is touched NOW, in
+    // the shadow of the partial-sum loads, and found in the CU's vector cache afterwards.
+    double warm = 0.0;
+    {
+        const int nlam = ds * D;
+        if (tid < nlam) warm += M.lam[tid];
+        if (tid < ds) warm += M.sf[tid];
+        if (tid <= nunits) warm += (double)M.ustart[tid];
+        if (tid < 2 * M.npairs) warm += (double)M.pair_ab[tid];
+        if (t >= 2) {
+            const double* rec = A.sp_prev + (size_t)q * nunits * M.sps;
+            for (int e = tid * 8; e < nunits * M.sps; e += 256 * 8) warm += rec[e];      // one load per 64-byte half line
+        }
+    }
+    // a column-row workgroup's training points: requested now, needed after the sums and the set-up
+    double xpre[D + 1];
+    {
+        const int rchunk = (((M.Np + 255) / 256 + RS - 1) / RS) * 256, i = rs * rchunk + tid;
+        const bool in = !close_role && t <= H && i < M.Np && i < (rs + 1) * rchunk;
+#pragma unroll
+        for (int k = 0; k < D; ++k) xpre[k] = in ? M.XT[(size_t)k * M.Np + i] : 0.0;
+        xpre[D] = 0.0;
+    }
 #if defined(GPMPC_FC_STAMPS)
     if (tid == 0) sh.stamp = (t == 3 && q == 0 && unit == 0 && zr <= RS + 1 && (zr == 0 || zr >= RS)) ? (zr == 0 ? 0 : (zr == RS ? 16 : 32)) : -1;
     __syncthreads();
@@ -275,8 +303,8 @@ __global__ __launch_bounds__(256) void k_fc_head(FcHeadArgs A, int t) {
     if (t >= 2) {
         double* red = STAGE ? sh.g : s_small;             // 256 doubles; the staging buffer of the prep phase is free until then
         const double* __restrict__ part = M.part + (size_t)q * M.nwork * nm;
-        int L = 1;
-        while (2 * L * nunits <= 256 && L < 64) L *= 2;
+        const double* __restrict__ p0 = A.part0 + (size_t)q * M.nwork;     // (strided by nm doubles in `part`: a cache line per value)
+        const int L = 256 / nunits < 64 ? 256 / nunits : 64;      // lanes per unit
         {   // Z0 of every unit (of this unit alone where that is all that is needed; the same lanes, the same order): L lanes per
             // unit, two independent sums per lane, then the L partial sums in order
             const int u = tid / L, l = tid - u * L;
@@ -284,9 +312,9 @@ __global__ __launch_bounds__(256) void k_fc_head(FcHeadArgs A, int t) {
                 const int w0 = M.ustart[u], w1 = M.ustart[u + 1];
                 double s0 = 0.0, s1 = 0.0;
                 int wi = w0 + l;
-#pragma unroll 4
-                for (; wi + L < w1; wi += 2 * L) { s0 += part[(size_t)wi * nm]; s1 += part[(size_t)(wi + L) * nm]; }
-                if (wi < w1) s0 += part[(size_t)wi * nm];
+#pragma unroll 8
+                for (; wi + L < w1; wi += 2 * L) { s0 += p0[wi]; s1 += p0[wi + L]; }
+                if (wi < w1) s0 += p0[wi];
                 red[tid] = s0 + s1;
             }
         }
@@ -360,9 +388,11 @@ __global__ __launch_bounds__(256) void k_fc_head(FcHeadArgs A, int t) {
     if (close_role) {
         if (M.grad) mom_finish_unit_wg<D>(M, A.sp_prev, q, unit, s_z, sh);      // Jacobians of step t-1, this unit
         GPMPC_FST(5);
+        if (warm == 1.2345e301) A.out_means[0] = warm;
         return;
     }
-    mom_prep_body<D>(M, q, unit, sh, rs, RS, g_role ? 1 : 2);
+    mom_prep_body<D>(M, q, unit, sh, rs, RS, g_role ? 1 : 2, g_role, xpre);
+    if (warm == 1.2345e301) A.out_means[0] = warm;           // (never: keeps the warm-up loads)
 }
 
 #if defined(GPMPC_FC_STAMPS)
@@ -371,7 +401,7 @@ extern "C" int gpmpc_debug_fc_stamps(unsigned long long* host_out) {      // [64
 }
 #endif
 
-struct FcPlan2 { int tiling, waves, nwork, nunits, nm, pps, sps, gw, rsplit, cu; size_t off_pp, off_sp0, off_sp1, off_part, off_G, off_dmu, off_dmS, off_dcu, off_dcS, total; };
+struct FcPlan2 { int tiling, waves, nwork, nunits, nm, pps, sps, gw, rsplit, cu; size_t off_part0, off_pp, off_sp0, off_sp1, off_part, off_G, off_dmu, off_dmS, off_dcu, off_dcS, total; };
 
 // 1: the two-launch form applies and is taken (GPMPC_FC_FORM = 0 / 1 forces)
 static int plan_fc2(const gpmpc_pack* p, int B, int H, bool grad, FcPlan2* r) {
@@ -407,7 +437,7 @@ static int plan_fc2(const gpmpc_pack* p, int B, int H, bool grad, FcPlan2* r) {
     auto take = [&](size_t n) { size_t o = off; off += (n * sizeof(double) + 255) & ~(size_t)255; return o; };
     r->off_pp = take((size_t)B * r->nunits * r->pps);
     r->off_sp0 = take((size_t)B * r->nunits * r->sps); r->off_sp1 = take((size_t)B * r->nunits * r->sps);
-    r->off_part = take((size_t)B * r->nwork * r->nm);
+    r->off_part = take((size_t)B * r->nwork * r->nm); r->off_part0 = take((size_t)B * r->nwork);
     r->off_G = take((size_t)B * r->nunits * p->Np * r->gw);
     r->off_dmu = take(HB * ds * D); r->off_dmS = take(HB * ds * D * D);
     r->off_dcu = take(HB * ds * ds * D); r->off_dcS = take(HB * ds * ds * D * D);
@@ -437,7 +467,7 @@ static int run_fc2(const gpmpc_pack* p, const FcPlan2& r, FcArgs& T, bool grad, 
     PairSbfArgs Q;
     Q.M = p->M; Q.XT = p->XT; Q.pp = M.pp; Q.G = M.G; Q.part = M.part; Q.work = p->wl[1][r.tiling].work_dev;
     Q.Np = p->Np; Q.B = B; Q.nunits = r.nunits; Q.nwork = r.nwork; Q.pps = r.pps; Q.nm = r.nm; Q.ntri = p->ds;
-    Q.cu = r.cu;
+    Q.cu = r.cu; Q.part0 = (double*)(ws + r.off_part0); A.part0 = Q.part0;
     for (int t = 1; t <= H + 1; ++t) {
         M.sp = sp[t & 1]; A.sp_prev = sp[(t - 1) & 1];
         if (grad && t >= 2) {

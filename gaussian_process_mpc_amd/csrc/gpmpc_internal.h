@@ -136,6 +136,7 @@ struct PairSbfArgs {
     const int* work;      // [nwork][4] = {unit, i0, j0, j1}
     int Np, B, nunits, nwork, pps, nm, ntri;
     int cu;               // columns per loop iteration: 1 | 2 | 4 (pair_kernel_sbf.h)
+    double* part0;        // [B][nwork]: the Z0 partial sums once more, contiguous (k_fc_head sums them for EVERY unit in every workgroup), or null
 };
 static inline int gpmpc_sbf_gw(int D, int ns2) { return (D + 1 + ns2 * (ns2 + 1) / 2 + 1) & ~1; }
 int gpmpc_launch_pair_sbf(int D, bool grad, int ns2, int waves, const PairSbfArgs& a, hipStream_t s);

@@ -29,7 +29,8 @@ __global__ __launch_bounds__(256) void k_mom_prep(MomArgs A) {
     if (threadIdx.x < D) sh.u[threadIdx.x] = A.u[(size_t)q * D + threadIdx.x];
     if (threadIdx.x < D * D) sh.S[threadIdx.x] = A.S[(size_t)q * D * D + threadIdx.x];
     __syncthreads();
-    mom_prep_body<D>(A, q, unit, sh);
+    const double none[D + 1] = {};
+    mom_prep_body<D>(A, q, unit, sh, 0, 1, 3, false, none);
 }
 
 template <int D>
@@ -315,7 +316,7 @@ static int run_mom(const gpmpc_pack* p, MomArgs& A, const MomPlan& r, bool grad,
     if (r.sbf) {
         PairSbfArgs Q;
         Q.M = p->M; Q.XT = p->XT; Q.pp = A.pp; Q.G = A.G; Q.part = A.part; Q.work = P.work;
-        Q.Np = p->Np; Q.B = A.nq; Q.nunits = r.nunits; Q.nwork = r.nwork; Q.pps = r.pps; Q.nm = r.nm; Q.ntri = p->ds; Q.cu = 1;
+        Q.Np = p->Np; Q.B = A.nq; Q.nunits = r.nunits; Q.nwork = r.nwork; Q.pps = r.pps; Q.nm = r.nm; Q.ntri = p->ds; Q.cu = 1; Q.part0 = nullptr;
         rc = gpmpc_timed_pair_sbf(D, grad, A.ns2, r.waves, Q, s);
     } else {
         rc = gpmpc_timed_pair(D, false, grad, r.tb, P.colsplit ? 4 : r.waves, P, s);

@@ -57,51 +57,55 @@ __device__ static double small_inverse(int n, double* a /*[n][n]*/, double* inv 
 // WITHOUT pivoting: the callers pass sym(S) + diag(lambda) with S a covariance.  a*: in, destroyed; det[0 / 1]: the determinants.
 template <int D>
 __device__ __forceinline__ void lds_inverse_pair(double* a0, double* i0, double* a1, double* i1, double* det, const int which /* bit 0: a0, bit 1: a1 */) {
+    // Each matrix is the work of ONE wave (D^2 <= 64 lanes): its LDS operations execute in program order, so the steps need no
+    // workgroup barrier between them -- only the compiler must not move them (wave_barrier) --; one barrier at the end publishes the results.
     const int w = threadIdx.x >> 6, e = threadIdx.x & 63;
     const bool on = e < D * D && ((w == 0 && (which & 1)) || (w == 1 && (which & 2)));
-    double* const a = w == 0 ? a0 : a1;
-    double* const iv = w == 0 ? i0 : i1;
-    const int r = e / D, c = e - r * D;
-    double arc = 0.0, irc = 0.0, dt = 1.0;
-    if (on) { arc = a[e]; irc = (r == c) ? 1.0 : 0.0; }
-    for (int k = 0; k < D; ++k) {
-        if (on) { a[e] = arc; iv[e] = irc; }
-        __syncthreads();
-        if (on) {
+    if (on) {
+        double* const a = w == 0 ? a0 : a1;
+        double* const iv = w == 0 ? i0 : i1;
+        const int r = e / D, c = e - r * D;
+        double arc = a[e], irc = (r == c) ? 1.0 : 0.0, dt = 1.0;
+        for (int k = 0; k < D; ++k) {
+            a[e] = arc; iv[e] = irc;
+            __builtin_amdgcn_wave_barrier();
             const double pv = a[k * D + k], ip = 1.0 / pv, f = a[r * D + k];
             const double akc = a[k * D + c] * ip, ikc = iv[k * D + c] * ip;
             dt *= pv;
             if (r == k) { arc = akc; irc = ikc; }
             else { arc = fma(-f, akc, arc); irc = fma(-f, ikc, irc); }
+            __builtin_amdgcn_wave_barrier();
         }
-        __syncthreads();
+        iv[e] = irc;
+        if (e == 0) det[w] = dt;
     }
-    if (on) { iv[e] = irc; if (e == 0) det[w] = dt; }
     __syncthreads();
 }
 
-// Upper-triangular Cm with Cm^T Cm = scale * sym(Am) (Cholesky by columns; L: D^2 doubles of LDS scratch).
+// Upper-triangular Cm with Cm^T Cm = scale * sym(Am) (Cholesky by columns; L: D^2 doubles of LDS scratch); wave 0 alone, as above.
 template <int D>
 __device__ __forceinline__ void lds_cholesky_upper(const double* Am, const double scale, double* L, double* Cm) {
     const int tid = threadIdx.x;
-    if (tid < D * D) L[tid] = 0.0;
-    __syncthreads();
-    for (int c = 0; c < D; ++c) {
-        if (tid == c) {
-            double s = scale * 0.5 * (Am[c * D + c] + Am[c * D + c]);
-            for (int l = 0; l < c; ++l) s -= L[c * D + l] * L[c * D + l];
-            L[c * D + c] = sqrt(s);
+    if (tid < 64) {
+        if (tid < D * D) L[tid] = 0.0;
+        __builtin_amdgcn_wave_barrier();
+        for (int c = 0; c < D; ++c) {
+            if (tid == c) {
+                double s = scale * 0.5 * (Am[c * D + c] + Am[c * D + c]);
+                for (int l = 0; l < c; ++l) s -= L[c * D + l] * L[c * D + l];
+                L[c * D + c] = sqrt(s);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (tid > c && tid < D) {
+                const int r = tid;
+                double s = scale * 0.5 * (Am[r * D + c] + Am[c * D + r]);
+                for (int l = 0; l < c; ++l) s -= L[r * D + l] * L[c * D + l];
+                L[r * D + c] = s / L[c * D + c];
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        __syncthreads();
-        if (tid > c && tid < D) {
-            const int r = tid;
-            double s = scale * 0.5 * (Am[r * D + c] + Am[c * D + r]);
-            for (int l = 0; l < c; ++l) s -= L[r * D + l] * L[c * D + l];
-            L[r * D + c] = s / L[c * D + c];
-        }
-        __syncthreads();
+        if (tid < D * D) { const int r = tid / D, c = tid - r * D; Cm[tid] = (c >= r) ? L[c * D + r] : 0.0; }
     }
-    if (tid < D * D) { const int r = tid / D, c = tid - r * D; Cm[tid] = (c >= r) ? L[c * D + r] : 0.0; }
     __syncthreads();
 }
 
@@ -133,8 +137,9 @@ template <int D>
 // of row chunk rs of RS, the first chunk also the set-up records; bit 1 -- the mean side of a variance unit (B = (S + Lambda)^-1, the O(N)
 // mean sums, mean and mean Jacobians).  k_mom_prep: one workgroup does both (role 3); k_fc_head (fullcov.hip) splits them over
 // workgroups, which all run their part of the (cheap, bit-identical) set-up themselves.
-__device__ __forceinline__ void mom_prep_body(const MomArgs& A, const int q, const int unit, MomPrepLds<D>& sh, const int rs = 0, const int RS = 1,
-                                              const int role = 3) {
+// xpre (optional): the D coordinates of this thread's first row of the chunk, loaded by the caller ahead of time.
+__device__ __forceinline__ void mom_prep_body(const MomArgs& A, const int q, const int unit, MomPrepLds<D>& sh, const int rs, const int RS,
+                                              const int role, const bool use_pre, const double (&xpre)[D + 1]) {
     const bool need_g = (role & 1) != 0, need_mean = (role & 2) != 0;
     const bool lead = need_g && rs == 0;
     constexpr int NV = MomPrepLds<D>::NV;
@@ -195,44 +200,68 @@ __device__ __forceinline__ void mom_prep_body(const MomArgs& A, const int q, con
         double v[NV];
 #pragma unroll
         for (int m = 0; m < NV; ++m) v[m] = 0.0;
-        // (the loads of the next row are issued ahead of the arithmetic of this one: with one workgroup per unit nothing else hides them)
-        double xn[D], bn = 0.0;
-        if ((int)threadIdx.x < A.Np) {
+        // ONE workgroup sums all rows of the unit, one wave per SIMD: nothing hides a load or a dependent chain but the loop itself, and
+        // between two head kernels the pair kernel has swept the training set out of the L2 (a load costs ~2.5 k cycles).  So: batches
+        // of RB rows per thread, the loads of TWO batches in flight (two register sets in alternation), the rows of a batch evaluated
+        // in interleaved pairs; the accumulations keep the order of the rows.  N = 2048: 12.4 k -> see profiles/r04/fc_head_stamps.txt.
+        constexpr int RB = D <= 5 ? 4 : 2;
+        const int BD = blockDim.x;
+        double xa[RB][D], ba[RB], xb[RB][D], bb[RB];
+        auto fetch = [&](double (&x)[RB][D], double (&b)[RB], const int base) {
 #pragma unroll
-            for (int k = 0; k < D; ++k) xn[k] = A.XT[(size_t)k * A.Np + threadIdx.x];
-            bn = A.beta[(size_t)a * A.Np + threadIdx.x];
-        }
-        for (int i = threadIdx.x; i < A.Np; i += blockDim.x) {
-            double d[D], qf = 0.0;
-            int boff = 0;
-            asm volatile("" : "+v"(boff));      // opaque offset: keeps the D^2 reads of B in the loop instead of 2 D^2 hoisted registers
+            for (int r = 0; r < RB; ++r) {
+                const int i = base + r * BD;
 #pragma unroll
-            for (int k = 0; k < D; ++k) d[k] = u[k] - xn[k];
-            const double bi = bn;
-            if (i + (int)blockDim.x < A.Np) {
-#pragma unroll
-                for (int k = 0; k < D; ++k) xn[k] = A.XT[(size_t)k * A.Np + i + blockDim.x];
-                bn = A.beta[(size_t)a * A.Np + i + blockDim.x];
+                for (int k = 0; k < D; ++k) x[r][k] = i < A.Np ? A.XT[(size_t)k * A.Np + i] : 0.0;
+                b[r] = i < A.Np ? A.beta[(size_t)a * A.Np + i] : 0.0;         // past the end: weight zero
             }
+        };
+        auto rows = [&](const double (&x)[RB][D], const double (&b)[RB], const int base) {
 #pragma unroll
-            for (int k = 0; k < D; ++k) {
-                double bd = 0.0;
+            for (int r0 = 0; r0 < RB; r0 += 2) {
+                if (base + r0 * BD >= A.Np) continue;               // (wave-uniform: Np is a multiple of 64) nothing but padding left
+                double d[2][D], qf[2] = {0.0, 0.0};
+                int boff = 0;
+                asm volatile("" : "+v"(boff));      // opaque offset: keeps the D^2 reads of B in the loop instead of 2 D^2 hoisted registers
 #pragma unroll
-                for (int l = 0; l < D; ++l) bd = fma(Bm[boff + k * D + l], d[l], bd);
-                qf = fma(bd, d[k], qf);
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int k = 0; k < D; ++k) d[r][k] = u[k] - x[r0 + r][k];
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    double bd0 = 0.0, bd1 = 0.0;
+#pragma unroll
+                    for (int l = 0; l < D; ++l) { const double bm = Bm[boff + k * D + l]; bd0 = fma(bm, d[0][l], bd0); bd1 = fma(bm, d[1][l], bd1); }
+                    qf[0] = fma(bd0, d[0][k], qf[0]); qf[1] = fma(bd1, d[1][k], qf[1]);
+                }
+                const double ex0 = exp(-0.5 * qf[0]), ex1 = exp(-0.5 * qf[1]);
+                const double pr[2] = {b[r0] * ex0, b[r0 + 1] * ex1};
+                if (A.out_l) {
+                    const int i = base + r0 * BD;
+                    if (i < A.N) A.out_l[((size_t)q * ds + a) * A.N + i] = s_cm * ex0;
+                    if (i + BD < A.N) A.out_l[((size_t)q * ds + a) * A.N + i + BD] = s_cm * ex1;
+                }
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const double p = pr[r];
+                    v[0] += p;
+                    int o = 1 + D;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) {
+                        const double pd = p * d[r][k];
+                        v[1 + k] += pd;
+#pragma unroll
+                        for (int l = k; l < D; ++l) { v[o] = fma(pd, d[r][l], v[o]); ++o; }
+                    }
+                }
             }
-            const double ex = exp(-0.5 * qf);
-            const double p = bi * ex;
-            if (A.out_l && i < A.N) A.out_l[((size_t)q * ds + a) * A.N + i] = s_cm * ex;
-            v[0] += p;
-            int o = 1 + D;
-#pragma unroll
-            for (int k = 0; k < D; ++k) {
-                const double pd = p * d[k];
-                v[1 + k] += pd;
-#pragma unroll
-                for (int l = k; l < D; ++l) { v[o] = fma(pd, d[l], v[o]); ++o; }
-            }
+        };
+        fetch(xa, ba, threadIdx.x);
+        for (int base = threadIdx.x; base < A.Np; base += 2 * RB * BD) {
+            fetch(xb, bb, base + RB * BD);
+            rows(xa, ba, base);
+            fetch(xa, ba, base + 2 * RB * BD);
+            rows(xb, bb, base + RB * BD);
         }
         const double cm = s_cm;
         GPMPC_FST(11);
@@ -339,7 +368,7 @@ __device__ __forceinline__ void mom_prep_body(const MomArgs& A, const int q, con
                 int toff = 0;
                 asm volatile("" : "+v"(toff));      // as for B above: T stays in LDS
 #pragma unroll
-                for (int k = 0; k < D; ++k) x[k] = A.XT[(size_t)k * A.Np + i];
+                for (int k = 0; k < D; ++k) x[k] = (use_pre && need_g && i0 == row0) ? xpre[k] : A.XT[(size_t)k * A.Np + i];
                 double* g = STAGE ? s_g + (size_t)threadIdx.x * A.gw : Gu + (size_t)i * A.gw;
 #pragma unroll
                 for (int k = 0; k < D; ++k) {

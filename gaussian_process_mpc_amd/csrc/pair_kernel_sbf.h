@@ -16,6 +16,9 @@
 // CU: columns per loop iteration (their M_ij loads issued together at the top).  1 for launches that fill the chip (C5: the other
 // waves of the SIMD hide a column's round trips); 2 / 4 for the small batches of the two-launch rollout form (fullcov.hip), where a
 // wave's column chain -- scalar loads of the G row, the M_ij load, the dependent exponent -- IS the run time of the launch.
+#ifndef GPMPC_SBF_NT
+#define GPMPC_SBF_NT 0          // cache policy of the weight loads of the multi-column (small-batch) instances: 0 default | 2 non-temporal
+#endif
 #ifndef GPMPC_SBF_MINWG
 #define GPMPC_SBF_MINWG 1       // A/B: 6 asks the compiler for six workgroups per CU from the two-column instances at D <= 5 (80 instead of 84 VGPRs,
 #endif                          // 6 instead of 5 waves per SIMD): measured SLOWER, N = 2048, B = 1 1.67 -> 1.79 ms (profiles/r04/fullcov_small_batch_ab.txt)
@@ -118,17 +121,17 @@ __global__ __launch_bounds__(256, (CU == 2 && GRAD && D <= 5) ? GPMPC_SBF_MINWG 
             };
 #pragma unroll
             for (int q = 0; q < CU; ++q)
-                ma[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, q * Np * 8, 0));     // (in bounds for any jstart <= Np - 64)
+                ma[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, q * Np * 8, GPMPC_SBF_NT));     // (in bounds for any jstart <= Np - 64)
             for (int jc = jstart; jc < j1; jc += 2 * CU) {
 #pragma unroll
                 for (int q = 0; q < CU; ++q)
-                    mb[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, (jc - jstart + CU + q) * Np * 8, 0));
+                    mb[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, (jc - jstart + CU + q) * Np * 8, GPMPC_SBF_NT));
                 __builtin_amdgcn_sched_barrier(0);               // the loads stay ahead of the arithmetic (pair_kernel_sb.h)
                 columns(jc, ma);
                 const int jn = jc + 2 * CU < j1 ? jc + 2 * CU : jc;
 #pragma unroll
                 for (int q = 0; q < CU; ++q)
-                    ma[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, (jn - jstart + q) * Np * 8, 0));
+                    ma[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, (jn - jstart + q) * Np * 8, GPMPC_SBF_NT));
                 __builtin_amdgcn_sched_barrier(0);
                 columns(jc + CU, mb);
             }
@@ -172,6 +175,7 @@ __global__ __launch_bounds__(256, (CU == 2 && GRAD && D <= 5) ? GPMPC_SBF_MINWG 
             s += (r4[0] + r4[NM]) + (r4[2 * NM] + r4[3 * NM]);
         }
         A.part[((size_t)b * A.nwork + wi) * A.nm + m] = s;
+        if (m == 0 && A.part0) A.part0[(size_t)b * A.nwork + wi] = s;
     }
 }
 

@@ -59,6 +59,20 @@ int main() {
     EXPECT_ZERO(gpmpc_rollout_fullcov_workspace_bytes(nullptr, 1, 3, 0));
     EXPECT_NEG(gpmpc_rollout_fullcov(nullptr, 1, 3, dummy, dummy, &cp, 0, dummy, dummy, dummy, nullptr, dummy, 64, nullptr));
     EXPECT_NEG(gpmpc_objective_gradient(nullptr, 3, dummy, dummy, &cp, 1, dummy, nullptr));
+    // round-4 entry points
+    char text[256];
+    EXPECT_NEG(gpmpc_plan_describe(nullptr, 1, 3, 0, text, sizeof(text)));
+    EXPECT_NEG(gpmpc_rollout_fullcov_describe(nullptr, 1, 3, 0, text, sizeof(text)));
+    EXPECT_NEG(gpmpc_pack_autotune(nullptr, 1, 3, 0, text, sizeof(text)));
+    EXPECT_NEG(gpmpc_pack_autotune_clear(nullptr));
+    EXPECT_NEG(gpmpc_pack_build_strided(nullptr, dummy, dummy, dummy, 8, 64, dummy, dummy, nullptr));
+    EXPECT_NEG(gpmpc_store_host(nullptr, dummy, 8, nullptr));
+    EXPECT_NEG(gpmpc_store_host(dummy, nullptr, 8, nullptr));
+    EXPECT_ZERO(gpmpc_gp_append_workspace_bytes(0, 3));
+    EXPECT_NEG(gpmpc_gp_append(0, 3, dummy, dummy, dummy, 1.0, 0.0, dummy, dummy, 8, dummy, 8, dummy, dummy, dummy, 8, dummy, 64, nullptr));
+    EXPECT_NEG(gpmpc_gp_append(4, GPMPC_MAX_D + 1, dummy, dummy, dummy, 1.0, 0.0, dummy, dummy, 8, dummy, 8, dummy, dummy, dummy, 8, dummy, 64, nullptr));
+    EXPECT_NEG(gpmpc_gp_append(4, 3, nullptr, dummy, dummy, 1.0, 0.0, dummy, dummy, 8, dummy, 8, dummy, dummy, dummy, 8, dummy, 64, nullptr));
+    EXPECT_NEG(gpmpc_gp_append(4, 3, dummy, dummy, dummy, 1.0, 0.0, dummy, dummy, 2, dummy, 8, dummy, dummy, dummy, 8, dummy, 64, nullptr));     // leading dimension < n
     EXPECT_ZERO(gpmpc_timing_enable(0));
     double ms = 0; long long nl = 0;
     EXPECT_ZERO(gpmpc_pair_kernel_time(&ms, &nl, 1));

@@ -12,6 +12,7 @@ for d in gaussian_process_mpc_amd oracle tests tools include profiles examples b
     [ -e $d ] && cp -a $d .stage/$NAME/
 done
 rm -rf .stage/$NAME/gaussian_process_mpc_amd/csrc/build* .stage/$NAME/tools/ubench
+rm -f .stage/$NAME/profiles/*/sanitizer_cpu.log          # (CPU sanitizer logs quote compiler flags that gpurun refuses to carry to a GPU box)
 find .stage/$NAME -name __pycache__ -prune -exec rm -rf {} + 2>/dev/null || true
 ln -s ../../gpurun_out .stage/$NAME/gpurun_out
 ln -s gaussian_process_mpc_amd ".stage/$NAME/gaussian-process-mpc_amd" 2>/dev/null || true
