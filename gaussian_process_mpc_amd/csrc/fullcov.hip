@@ -60,55 +60,73 @@ __global__ void k_fc_assemble(FcArgs A, int t) {
 // State cost with a full covariance and its derivatives (src/mpc.py:182-185):
 //   (1/gamma) log det(I + gamma Q Sig) + e^T Z e,  Z = (I + gamma Q Sig)^-1 Q = (Q^-1 + gamma Sig)^-1
 //   d/dmu = (Z + Z^T) e,   d/dSig = sym( Z^T - gamma (Z^T e)(Z e)^T )         (gamma = 0: Q^T, tr(Q Sig) + e^T Q e)
-__device__ static double fc_state_cost(int ds, const gpmpc_cost_params& C, const double* mu, const double* Sig, double* w,
+// One lane per horizon step; the state dimension is a template parameter so that the ds x 2ds elimination lives in registers (as
+// runtime-indexed LDS scratch the H + 1 terms were ~70 us of dependent LDS round trips at ds = 4).  Partial pivoting by
+// compare-and-swap of whole rows (no runtime-indexed row).
+template <int DS>
+__device__ static double fc_state_cost(const gpmpc_cost_params& C, const double* __restrict__ mu, const double* __restrict__ Sig,
                                        double* dmu, double* dSig) {
     const double g = C.gamma;
-    double e[GPMPC_MAX_DS];
-    for (int k = 0; k < ds; ++k) e[k] = mu[k] - C.x_ref[k];
-    const int ld = 2 * ds;
+    double sg[DS * DS], e[DS], w[DS][2 * DS];
+#pragma unroll
+    for (int k = 0; k < DS * DS; ++k) sg[k] = Sig[k];
+#pragma unroll
+    for (int k = 0; k < DS; ++k) e[k] = mu[k] - C.x_ref[k];
     double det = 1.0;
-    if (g == 0.0) {
-        for (int r = 0; r < ds; ++r) for (int c = 0; c < ds; ++c) w[r * ld + ds + c] = C.Q[r * ds + c];
-    } else {
-        for (int r = 0; r < ds; ++r)
-            for (int c = 0; c < ds; ++c) {
-                double s = 0.0;
-                for (int l = 0; l < ds; ++l) s += C.Q[r * ds + l] * Sig[l * ds + c];
-                w[r * ld + c] = (r == c ? 1.0 : 0.0) + g * s;
-                w[r * ld + ds + c] = C.Q[r * ds + c];
+#pragma unroll
+    for (int r = 0; r < DS; ++r)
+#pragma unroll
+        for (int c = 0; c < DS; ++c) {
+            double s = 0.0;
+#pragma unroll
+            for (int l = 0; l < DS; ++l) s += C.Q[r * DS + l] * sg[l * DS + c];
+            w[r][c] = (r == c ? 1.0 : 0.0) + g * s;
+            w[r][DS + c] = C.Q[r * DS + c];
+        }
+    if (g != 0.0) {
+#pragma unroll
+        for (int k = 0; k < DS; ++k) {
+#pragma unroll
+            for (int r = k + 1; r < DS; ++r) {
+                if (fabs(w[r][k]) > fabs(w[k][k])) {
+#pragma unroll
+                    for (int c = 0; c < 2 * DS; ++c) { const double tmp = w[k][c]; w[k][c] = w[r][c]; w[r][c] = tmp; }
+                    det = -det;
+                }
             }
-        for (int k = 0; k < ds; ++k) {
-            int piv = k; double best = fabs(w[k * ld + k]);
-            for (int r = k + 1; r < ds; ++r) { const double v = fabs(w[r * ld + k]); if (v > best) { best = v; piv = r; } }
-            if (piv != k) {
-                for (int c = 0; c < ld; ++c) { const double tmp = w[k * ld + c]; w[k * ld + c] = w[piv * ld + c]; w[piv * ld + c] = tmp; }
-                det = -det;
-            }
-            const double pv = w[k * ld + k];
+            const double pv = w[k][k];
             det *= pv;
             const double inv = 1.0 / pv;
-            for (int c = 0; c < ld; ++c) w[k * ld + c] *= inv;
-            for (int r = 0; r < ds; ++r) {
+#pragma unroll
+            for (int c = 0; c < 2 * DS; ++c) w[k][c] *= inv;
+#pragma unroll
+            for (int r = 0; r < DS; ++r) {
                 if (r == k) continue;
-                const double f = w[r * ld + k];
-                for (int c = 0; c < ld; ++c) w[r * ld + c] = fma(-f, w[k * ld + c], w[r * ld + c]);
+                const double f = w[r][k];
+#pragma unroll
+                for (int c = 0; c < 2 * DS; ++c) w[r][c] = fma(-f, w[k][c], w[r][c]);
             }
         }
     }
-    double ze[GPMPC_MAX_DS], zte[GPMPC_MAX_DS], quad = 0.0, trq = 0.0;
-    for (int k = 0; k < ds; ++k) {
+    double ze[DS], zte[DS], quad = 0.0, trq = 0.0;
+#pragma unroll
+    for (int k = 0; k < DS; ++k) {
         double s = 0.0, st = 0.0;
-        for (int l = 0; l < ds; ++l) { s += w[k * ld + ds + l] * e[l]; st += w[l * ld + ds + k] * e[l]; trq += C.Q[k * ds + l] * Sig[l * ds + k]; }
+#pragma unroll
+        for (int l = 0; l < DS; ++l) { s += w[k][DS + l] * e[l]; st += w[l][DS + k] * e[l]; trq += C.Q[k * DS + l] * sg[l * DS + k]; }
         ze[k] = s; zte[k] = st;
         quad += e[k] * s;
     }
     if (dmu) {
-        for (int k = 0; k < ds; ++k) dmu[k] = ze[k] + zte[k];
-        for (int k = 0; k < ds; ++k)
-            for (int l = 0; l < ds; ++l) {
-                const double gkl = w[l * ld + ds + k] - g * zte[k] * ze[l];     // Z^T - gamma (Z^T e)(Z e)^T
-                const double glk = w[k * ld + ds + l] - g * zte[l] * ze[k];
-                dSig[k * ds + l] = 0.5 * (gkl + glk);
+#pragma unroll
+        for (int k = 0; k < DS; ++k) dmu[k] = ze[k] + zte[k];
+#pragma unroll
+        for (int k = 0; k < DS; ++k)
+#pragma unroll
+            for (int l = 0; l < DS; ++l) {
+                const double gkl = w[l][DS + k] - g * zte[k] * ze[l];     // Z^T - gamma (Z^T e)(Z e)^T
+                const double glk = w[k][DS + l] - g * zte[l] * ze[k];
+                dSig[k * DS + l] = 0.5 * (gkl + glk);
             }
     }
     return (g == 0.0 ? trq : log(det) / g) + quad;
@@ -148,9 +166,11 @@ __device__ static double fc_input_cost(int H, int da, const gpmpc_cost_params& C
 // (the D entries of u, the ds x ds state block of S; the action block of S is constant), each lane with its quarter of the
 // ds + ds^2 terms, the Jacobian values of step t-1 loaded while step t is summed: the sweep used to be 64 lanes x 30 entries x 20
 // dependent global round trips (230 us at H = 20, a tenth of a B = 1 rollout).
+template <int DS>
 __global__ __launch_bounds__(256) void k_fc_tail(FcArgs A) {
     extern __shared__ double s_dyn[];
-    const int b = blockIdx.x, ds = A.ds, da = A.da, D = A.D, H = A.H, nz = ds + ds * ds, tid = threadIdx.x;
+    constexpr int ds = DS;
+    const int b = blockIdx.x, da = A.da, D = A.D, H = A.H, nz = ds + ds * ds, tid = threadIdx.x;
     double* s_lu = s_dyn;
     double* s_ct = s_lu + GPMPC_FC_WORKERS * ds * 2 * ds;
     double* s_dl = s_ct + (H + 1);
@@ -161,9 +181,9 @@ __global__ __launch_bounds__(256) void k_fc_tail(FcArgs A) {
     for (int r = tid; r < H * da; r += blockDim.x) { s_U[r] = A.U[(size_t)b * H * da + r]; s_gU[r] = 0.0; }
     const double* mu = A.out_means + (size_t)b * (H + 1) * ds;
     const double* Sg = A.out_covs + (size_t)b * (H + 1) * ds * ds;
-    for (int i = tid; i <= H && tid < GPMPC_FC_WORKERS; i += GPMPC_FC_WORKERS)
-        s_ct[i] = fc_state_cost(ds, A.cost, mu + i * ds, Sg + i * ds * ds, s_lu + tid * ds * 2 * ds,
-                                A.grad ? s_dl + (size_t)i * nz : nullptr, A.grad ? s_dl + (size_t)i * nz + ds : nullptr);
+    for (int i = tid; i <= H; i += blockDim.x)
+        s_ct[i] = fc_state_cost<DS>(A.cost, mu + i * ds, Sg + i * ds * ds,
+                                    A.grad ? s_dl + (size_t)i * nz : nullptr, A.grad ? s_dl + (size_t)i * nz + ds : nullptr);
     // the entry / term assignment of the sweep and the first prefetch (independent of the cost terms)
     const int n = tid >> 2, c4 = tid & 3, ne = D + ds * ds;
     const bool on = A.grad && n < ne;
@@ -484,6 +504,20 @@ static int run_fc2(const gpmpc_pack* p, const FcPlan2& r, FcArgs& T, bool grad, 
     return GPMPC_OK;
 }
 
+static int launch_fc_tail(const FcArgs& A, int B, size_t lds, hipStream_t s) {
+    switch (A.ds) {
+        case 1: hipLaunchKernelGGL(k_fc_tail<1>, dim3(B), dim3(256), lds, s, A); break;
+        case 2: hipLaunchKernelGGL(k_fc_tail<2>, dim3(B), dim3(256), lds, s, A); break;
+        case 3: hipLaunchKernelGGL(k_fc_tail<3>, dim3(B), dim3(256), lds, s, A); break;
+        case 4: hipLaunchKernelGGL(k_fc_tail<4>, dim3(B), dim3(256), lds, s, A); break;
+        case 5: hipLaunchKernelGGL(k_fc_tail<5>, dim3(B), dim3(256), lds, s, A); break;
+        case 6: hipLaunchKernelGGL(k_fc_tail<6>, dim3(B), dim3(256), lds, s, A); break;
+        default: return GPMPC_E_ARG;
+    }
+    GPMPC_HIP(hipGetLastError());
+    return GPMPC_OK;
+}
+
 struct FcPlan { size_t off_u, off_S, off_mean, off_cov, off_var, off_dvu, off_dvS, off_dmu, off_dmS, off_dcu, off_dcS, off_mm, mm_bytes, total; };
 
 static void plan_fc(const gpmpc_pack* p, int B, int H, bool grad, FcPlan* r) {
@@ -563,9 +597,7 @@ extern "C" int gpmpc_rollout_fullcov(const gpmpc_pack* p, int B, int H, const do
             case 8: rc = run_fc2<8>(p, r2, A, grad, ws, s); break;
         }
         if (rc != GPMPC_OK) return rc;
-        hipLaunchKernelGGL(k_fc_tail, dim3(B), dim3(256), lds, s, A);
-        GPMPC_HIP(hipGetLastError());
-        return GPMPC_OK;
+        return launch_fc_tail(A, B, lds, s);
     }
     A.u = (double*)(ws + r.off_u); A.S = (double*)(ws + r.off_S);
     A.mean = (double*)(ws + r.off_mean); A.cov = (double*)(ws + r.off_cov);
@@ -587,7 +619,5 @@ extern "C" int gpmpc_rollout_fullcov(const gpmpc_pack* p, int B, int H, const do
         if (rc != GPMPC_OK) return rc;
     }
     hipLaunchKernelGGL(k_fc_assemble, gb, tb, 0, s, A, H + 1);      // records step H
-    hipLaunchKernelGGL(k_fc_tail, dim3(B), dim3(256), lds, s, A);
-    GPMPC_HIP(hipGetLastError());
-    return GPMPC_OK;
+    return launch_fc_tail(A, B, lds, s);
 }

@@ -1,13 +1,13 @@
 #!/bin/bash
 # Collects the judged artefacts of the round-4 build into gpurun_out/r04c/ (run through gpurun from the repo root or a staged copy;
 # tools/.githead must hold the HEAD the snapshot was taken at).  Copy the result into profiles/r04/ afterwards.
-#   bash tools/collect_r04.sh [prof|bench|maps|all]
+#   bash tools/collect_r04.sh [trace|pmc|bench|maps|all]
 set -u
 R=$(pwd)
 O=$R/gpurun_out/r04c
 mkdir -p $O
 STEP=${1:-all}
-if [ $STEP = all ] || [ $STEP = prof ]; then
+if [ $STEP = all ] || [ $STEP = trace ]; then
 # kernel traces (rocprofv3 --kernel-trace --stats)
 for c in C3 C4 C5; do bash tools/prof_trace.sh $c > $O/trace_$c.log 2>&1; cp gpurun_out/trace_$c/kernel_stats_$c.csv gpurun_out/trace_$c/bench_traced_$c.json $O/ 2>/dev/null; done
 bash tools/prof_trace.sh C3 --shared-lambda > $O/trace_C3_shared.log 2>&1; cp gpurun_out/trace_C3/kernel_stats_C3.csv $O/kernel_stats_C3_shared.csv; cp gpurun_out/trace_C3/bench_traced_C3.json $O/bench_traced_C3_shared.json
@@ -15,9 +15,13 @@ bash tools/prof_trace.sh C3 --batch 1 > $O/trace_C3_B1.log 2>&1; cp gpurun_out/t
 bash tools/prof_trace.sh C4 --batch 1 > $O/trace_C4_B1.log 2>&1; cp gpurun_out/trace_C4/kernel_stats_C4.csv $O/kernel_stats_C4_B1.csv; cp gpurun_out/trace_C4/bench_traced_C4.json $O/bench_traced_C4_B1.json
 bash tools/prof_trace.sh C5 --batch 1 > $O/trace_C5_B1.log 2>&1; cp gpurun_out/trace_C5/kernel_stats_C5.csv $O/kernel_stats_C5_B1.csv; cp gpurun_out/trace_C5/bench_traced_C5.json $O/bench_traced_C5_B1.json
 bash tools/prof_trace.sh C3 --n-train 300 --batch 256 > $O/trace_N300_B256.log 2>&1; cp gpurun_out/trace_C3/kernel_stats_C3.csv $O/kernel_stats_N300_B256.csv; cp gpurun_out/trace_C3/bench_traced_C3.json $O/bench_traced_N300_B256.json
+fi
+if [ $STEP = all ] || [ $STEP = pmc ] || [ $STEP = pmc1 ]; then
 # PMC (separate passes, counters only)
 for c in C3 C4 C5; do bash tools/prof_pmc.sh $c > $O/pmc_$c.log 2>&1; cp gpurun_out/pmc_$c/pmc_$c.txt gpurun_out/pmc_$c/pmc_$c.json $O/ 2>/dev/null; done
 bash tools/prof_pmc.sh C3 --shared-lambda > $O/pmc_C3_shared.log 2>&1; cp gpurun_out/pmc_C3/pmc_C3.txt $O/pmc_C3_shared.txt; cp gpurun_out/pmc_C3/pmc_C3.json $O/pmc_C3_shared.json
+fi
+if [ $STEP = all ] || [ $STEP = pmc ] || [ $STEP = pmc2 ]; then
 PMC_BATCH=1 PMC_STEPS=3 bash tools/prof_pmc.sh C3 --batch 1 > $O/pmc_C3_B1.log 2>&1; cp gpurun_out/pmc_C3/pmc_C3.txt $O/pmc_C3_B1.txt; cp gpurun_out/pmc_C3/pmc_C3.json $O/pmc_C3_B1.json
 PMC_BATCH=1 PMC_STEPS=2 bash tools/prof_pmc.sh C4 --batch 1 > $O/pmc_C4_B1.log 2>&1; cp gpurun_out/pmc_C4/pmc_C4.txt $O/pmc_C4_B1.txt; cp gpurun_out/pmc_C4/pmc_C4.json $O/pmc_C4_B1.json
 PMC_BATCH=1 PMC_STEPS=3 bash tools/prof_pmc.sh C5 --batch 1 > $O/pmc_C5_B1.log 2>&1; cp gpurun_out/pmc_C5/pmc_C5.txt $O/pmc_C5_B1.txt; cp gpurun_out/pmc_C5/pmc_C5.json $O/pmc_C5_B1.json
