@@ -28,6 +28,15 @@ for case in range(n_cases):
         B = min(B, 260)
     gamma = float(rng.choice([-1.0, 1e-5, 0.0, 0.5]))
     sb = str(rng.choice(["auto", "auto", "staged", "sbf"]))
+    # round 4: the two-launch small-batch form (fullcov.hip::k_fc_head) on each tiling / column unroll / head split, and the four-launch form
+    fc = str(rng.choice(["auto", "auto", "four", "two64", "two128", "two256c4", "two64c1r3", "two64c2r1"]))
+    FC = {"auto": {}, "four": {"GPMPC_FC_FORM": "0"}, "two64": {"GPMPC_FC_FORM": "1", "GPMPC_FC_TILING": "2"},
+          "two128": {"GPMPC_FC_FORM": "1", "GPMPC_FC_TILING": "4"}, "two256c4": {"GPMPC_FC_FORM": "1", "GPMPC_FC_TILING": "0", "GPMPC_FC_CU": "4"},
+          "two64c1r3": {"GPMPC_FC_FORM": "1", "GPMPC_FC_TILING": "2", "GPMPC_FC_CU": "1", "GPMPC_FC_RSPLIT": "3"},
+          "two64c2r1": {"GPMPC_FC_FORM": "1", "GPMPC_FC_TILING": "2", "GPMPC_FC_CU": "2", "GPMPC_FC_RSPLIT": "1"}}
+    for k in ("GPMPC_FC_FORM", "GPMPC_FC_TILING", "GPMPC_FC_CU", "GPMPC_FC_RSPLIT"):
+        os.environ.pop(k, None)
+    os.environ.update(FC[fc])
     os.environ.pop("GPMPC_PAIR_SB", None)
     if sb == "staged":
         os.environ["GPMPC_PAIR_SB"] = "0"
@@ -51,7 +60,7 @@ for case in range(n_cases):
     finite = all(bool(torch.isfinite(v).all()) for v in r.values())
     ok = finite and err["means"] < 1e-5 and err["covs"] < 1e-4 and err["cost"] < 1e-6 and err["ddir"] < 1e-4
     bad += 0 if ok else 1
-    print(f"case {case:3d}: N={N:4d} ds={ds} da={da} H={H} B={B:4d} gamma={gamma:g} {sb:6s} "
+    print(f"case {case:3d}: N={N:4d} ds={ds} da={da} H={H} B={B:4d} gamma={gamma:g} {sb:6s} {fc:9s} "
           + " ".join(f"{k} {v:.1e}" for k, v in err.items()) + ("" if ok else "   <-- FAIL"), flush=True)
     for k in worst:
         worst[k] = max(worst[k], err[k])
