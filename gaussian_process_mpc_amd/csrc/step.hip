@@ -1097,7 +1097,9 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
         const bool pshared = shared_on && p->ds >= 2 && D >= 3 && D <= 6;
         const bool shared_ahead = shared_on && !pshared && p->ds >= 3;
         r->png = 1;
-        if (diag && !lowprec && p->da >= 1 && p->da <= 2 && p->Np <= GPMPC_PERSIST_MAXNP_HOST && H * p->da <= 1024 && tn.persist != 0 &&
+        // (never for the sub-batches of a split call: they run the launches of the WHOLE batch's plan -- a sub-batch that happened to fit
+        // this kernel used to come back with this branch's work-list fields and the whole batch's form: an empty grid)
+        if (!shape && diag && !lowprec && p->da >= 1 && p->da <= 2 && p->Np <= GPMPC_PERSIST_MAXNP_HOST && H * p->da <= 1024 && tn.persist != 0 &&
             pw && (tn.persist > 0 || (p->Np <= (pshared ? 448 : 512) && D <= 6 && !shared_ahead))) {
             r->fused = 3; r->sb = 0; r->shared = 0; r->tb = 1; r->rgroup = 1; r->colunroll = 1; r->fq = 1;
             r->pwaves = pw;
