@@ -68,7 +68,8 @@ class Dynamics(object):
         else:
             modes = []
             # one device copy of the new input rows and one of ALL targets for the ds GPs (they were 2 ds host-to-device copies)
-            shared = {"y_all": torch.tensor(np.asarray(next_state, dtype=np.float64).reshape(-1, self.state_dim)).to(self.device)}
+            # (made on first use: the in-place path of a single observation sends its targets as kernel arguments instead)
+            shared = {"y_all_host": np.asarray(next_state, dtype=np.float64).reshape(-1, self.state_dim)}
             for a, (g, y) in enumerate(zip(self.gpr_err, ys)):
                 if not np.isscalar(y) and np.ndim(y) > 0:
                     n_obs, yy = len(y), np.asarray(y)[:, None]

@@ -13,6 +13,23 @@ import torch
 from ._lib import check, host_doubles, lib, ptr, require_gpu, stream_ptr
 
 
+def _exp_numpy(t):
+    return torch.exp(t).numpy()
+
+
+def _exp_item(t):
+    return torch.exp(t).item()
+
+
+def _exp_tuple(t):
+    return tuple(float(v) for v in torch.exp(t).numpy())
+
+
+def _noise_var_of(t):
+    # src/gpr.py:170: the noise variance on the diagonal of Ky is float32(sigma_n^2)
+    return float((torch.exp(t) ** 2 * torch.ones(1)).item())
+
+
 class GaussianProcessRegression(object):
     def __init__(self, x_dim, nominal_model=None):
         self.device = require_gpu()
@@ -32,6 +49,7 @@ class GaussianProcessRegression(object):
         self._beta = None
         self._adam = None           # (optimizer, host parameters) of update_hyperparams, created on first use
         self._hcache = {}           # host copies of the log-hypers, keyed on tensor identity and version
+        self._vcache = {}           # values derived from them (exp, noise variance), same key
         self._built_hypers = None   # (lambdas, sigma_f, noise variance) the current Kf / Ky / Ky_inv were built with
         self._appends_since_rebuild = 0
         self.rebuild_every = 64     # incremental appends between two full rebuilds (bounds the accumulated round-off)
@@ -73,23 +91,34 @@ class GaussianProcessRegression(object):
             self._hcache[name] = c
         return c[2]
 
+    def _hval(self, name, fn):
+        """`fn(host copy of the log tensor)`, evaluated once per value of the tensor (same key as `_host`): the closed loop reads the
+        hyper-parameters ~15 times per environment step (up-to-date check of the incremental update, kernel arguments, pack key) and
+        each read was a torch.exp + .item() / .numpy() on the host, 60-80 us per step together (profiles/r04/append_profile.txt)."""
+        t = getattr(self, name)
+        c = self._vcache.get((name, fn))
+        if c is None or c[0] is not t or c[1] != t._version:
+            c = (t, t._version, fn(self._host(name)))
+            self._vcache[(name, fn)] = c
+        return c[2]
+
     def set_lambdas(self, lambdas):
         self.log_lambdas = self._log_param(lambdas)
 
     def get_lambdas(self):
-        return torch.exp(self._host("log_lambdas")).numpy()
+        return self._hval("log_lambdas", _exp_numpy).copy()
 
     def set_sigma_f(self, sigma_f):
         self.log_sigma_f = self._log_param(sigma_f)
 
     def get_sigma_f(self):
-        return torch.exp(self._host("log_sigma_f")).item()
+        return self._hval("log_sigma_f", _exp_item)
 
     def set_sigma_n(self, sigma_n):
         self.log_sigma_n = self._log_param(sigma_n)
 
     def get_sigma_n(self):
-        return torch.exp(self._host("log_sigma_n")).item()
+        return self._hval("log_sigma_n", _exp_item)
 
     # -- data
     def append_train_data(self, x, y, incremental=False):
@@ -123,7 +152,9 @@ class GaussianProcessRegression(object):
             x = torch.tensor(np.asarray(x), requires_grad=False).type(torch.float64).to(self.device)
             if shared is not None:
                 shared["x"] = x
-        if shared is not None and "y_all" in shared:
+        if shared is not None and ("y_all" in shared or "y_all_host" in shared):
+            if "y_all" not in shared:
+                shared["y_all"] = torch.tensor(shared["y_all_host"]).to(self.device)
             y = shared["y_all"][:, column:column + 1].contiguous()
         else:
             y = torch.tensor(y, requires_grad=False).type(torch.float64).to(self.device)
@@ -197,7 +228,7 @@ class GaussianProcessRegression(object):
         self._pending = None
 
     def _current_hypers(self):
-        return (tuple(float(v) for v in self.get_lambdas()), float(self.get_sigma_f()), self._noise_var())
+        return (self._hval("log_lambdas", _exp_tuple), float(self.get_sigma_f()), self._noise_var())
 
     def se_kernel(self, x1, x2):
         """sigma_f^2 exp(-1/2 (x1 - x2)^T Lambda^-1 (x1 - x2)) for two points: 0-dim device tensor (src/gpr.py:124-135),
@@ -525,7 +556,7 @@ class GaussianProcessRegression(object):
     # -- hyper-parameter training (src/gpr.py:173-251, 334-370)
     def _noise_var(self):
         # src/gpr.py:170: the noise variance on the diagonal of Ky is float32(sigma_n^2)
-        return float((torch.exp(self._host("log_sigma_n")) ** 2 * torch.ones(1)).item())
+        return self._hval("log_sigma_n", _noise_var_of)
 
     def _ml_terms(self):
         """One device pass (C ABI ``gpmpc_ml_grad``): [d ml/d log lambda (D), d/d log sigma_f, d/d log sigma_n, r^T alpha]."""

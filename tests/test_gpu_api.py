@@ -636,7 +636,9 @@ def test_side_stream_rebuild_catches_up_and_swaps(G):
             full_on_step += 1                               # a synchronous rebuild on the step: must not happen
         elif inc._appends_since_rebuild <= before:
             swaps += 1
-            assert 1 <= inc._appends_since_rebuild <= 16    # restarted from the caught-up observations
+            # restarted from the caught-up observations: as many as the host managed to append while the side stream rebuilt (16 at
+            # the round-3 append cost; more since the data path got faster)
+            assert 1 <= inc._appends_since_rebuild <= 64
     assert full_on_step == 0 and swaps >= extra // 40, (full_on_step, swaps)
     inc.finish_async_rebuild()
     ref.append_train_data(X, y)                             # one rebuild from scratch
