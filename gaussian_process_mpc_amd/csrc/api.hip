@@ -262,6 +262,56 @@ extern "C" int gpmpc_kinv_append(int n, const double* Kinv_dev, const double* k_
 // src/gpr.py:90-122, :159-171): k = K_f(X, x_new), then Kf, Ky and Ky_inv of the n + 1 points written into the OUTPUT buffers (leading
 // dimension ld_out >= n + 1) from the INPUT buffers (ld_in >= n); input and output must not alias (ping-pong two buffer sets).
 // Four launches, no allocation, no host round trip.
+struct AppendHyp { double lam[GPMPC_MAX_D]; double sf2; };
+
+// k_append_kvec + k_append_vw in one launch: row workgroup r evaluates k itself (workgroup 0 also stores it) and v[r], wv[r]
+__global__ __launch_bounds__(256) void k_append_vw2(const double* __restrict__ X, int n, int D, const double* __restrict__ xnew, AppendHyp H,
+                                                     const double* __restrict__ Kinv, size_t ld, double* __restrict__ kout,
+                                                     double* __restrict__ v, double* __restrict__ wv) {
+    __shared__ double s_scr[32], s_out[2];
+    const int r = blockIdx.x;
+    double acc[2] = {0.0, 0.0};
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        double d2 = 0.0;
+        for (int d = 0; d < D; ++d) { const double t = X[(size_t)i * D + d] - xnew[d]; d2 = fma(t * t, 1.0 / H.lam[d], d2); }
+        const double ki = H.sf2 * exp(-0.5 * d2);
+        if (r == 0) kout[i] = ki;
+        acc[0] = fma(Kinv[(size_t)r * ld + i], ki, acc[0]);
+        acc[1] = fma(Kinv[(size_t)i * ld + r], ki, acc[1]);
+    }
+    block_sum<2>(acc, s_scr, s_out);
+    if (threadIdx.x == 0) { v[r] = s_out[0]; wv[r] = s_out[1]; }
+}
+
+// k_append_q + k_append_fill in one launch: every workgroup evaluates q = 1 / (kappa - k . v) itself (n products, fixed order)
+__global__ __launch_bounds__(256) void k_append_fill2(const double* __restrict__ Kinv, size_t ld_in, const double* __restrict__ v,
+                                                       const double* __restrict__ wv, double kappa, int n, double* __restrict__ out, size_t ld_out,
+                                                       const double* __restrict__ k, const double* __restrict__ Kf_in, const double* __restrict__ Ky_in,
+                                                       size_t ld_k, double* __restrict__ Kf_out, double* __restrict__ Ky_out, double kff, double noise_var) {
+    __shared__ double s_scr[16], s_out[1];
+    double acc[1] = {0.0};
+    for (int i = threadIdx.x; i < n; i += blockDim.x) acc[0] = fma(k[i], v[i], acc[0]);
+    block_sum<1>(acc, s_scr, s_out);
+    const double qq = 1.0 / (kappa - s_out[0]);
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y, m = n + 1;
+    if (j >= m) return;
+    double val;
+    if (i < n && j < n) val = fma(qq * v[i], wv[j], Kinv[(size_t)i * ld_in + j]);
+    else if (i < n) val = -qq * v[i];
+    else if (j < n) val = -qq * wv[j];
+    else val = qq;
+    out[(size_t)i * ld_out + j] = val;
+    if (Kf_out) {
+        double kf, ky;
+        if (i < n && j < n) { kf = Kf_in[(size_t)i * ld_k + j]; ky = Ky_in[(size_t)i * ld_k + j]; }
+        else if (i < n) { kf = k[i]; ky = kf; }
+        else if (j < n) { kf = k[j]; ky = kf; }
+        else { kf = kff; ky = kff + noise_var; }
+        Kf_out[(size_t)i * ld_out + j] = kf;
+        Ky_out[(size_t)i * ld_out + j] = ky;
+    }
+}
+
 extern "C" size_t gpmpc_gp_append_workspace_bytes(int n, int D) { return n < 1 ? 0 : sizeof(double) * (3 * (size_t)n + 8 + D + 8); }
 
 extern "C" int gpmpc_gp_append(int n, int D, const double* X_dev, const double* xnew_dev, const double* lambdas_host, double sigma_f,
@@ -274,14 +324,17 @@ extern "C" int gpmpc_gp_append(int n, int D, const double* X_dev, const double* 
     if (Kf_in == Kf_out || Ky_in == Ky_out || Kinv_in == Kinv_out) return GPMPC_E_ARG;
     if (workspace_bytes < gpmpc_gp_append_workspace_bytes(n, D)) return GPMPC_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    double* v = (double*)workspace; double* wv = v + n; double* k = wv + n; double* q = k + n; double* lam = q + 8;
-    if (int rcu = gpmpc_upload_small(lam, lambdas_host, sizeof(double) * D, s)) return rcu;
-    const double sf2 = sigma_f * sigma_f;
-    hipLaunchKernelGGL(k_append_kvec, dim3((n + 255) / 256), dim3(256), 0, s, X_dev, n, D, xnew_dev, lam, sf2, k);
-    hipLaunchKernelGGL(k_append_vw, dim3(n), dim3(256), 0, s, Kinv_in, ld_in, k, n, v, wv);
-    hipLaunchKernelGGL(k_append_q, dim3(1), dim3(256), 0, s, k, v, n, sf2 + noise_var, q);
-    hipLaunchKernelGGL(k_append_fill, dim3((n + 1 + 255) / 256, n + 1), dim3(256), 0, s, Kinv_in, ld_in, v, wv, q, n, Kinv_out, ld_out,
-                       (const double*)k, Kf_in, Ky_in, ld_k_in, Kf_out, Ky_out, sf2, noise_var);
+    double* v = (double*)workspace; double* wv = v + n; double* k = wv + n;
+    // Two launches (they were five: lambda upload, k vector, v / w, q, fill -- each a dependent launch boundary on a path that is
+    // launch latency and nothing else at n ~ 300): the hyper-parameters travel as kernel arguments, every row workgroup evaluates
+    // the k vector itself, every fill workgroup the scalar q.  Same expressions, same summation orders: bit-identical results.
+    AppendHyp hyp;
+    memset(&hyp, 0, sizeof(hyp));
+    for (int d = 0; d < D; ++d) hyp.lam[d] = lambdas_host[d];
+    hyp.sf2 = sigma_f * sigma_f;
+    hipLaunchKernelGGL(k_append_vw2, dim3(n), dim3(256), 0, s, X_dev, n, D, xnew_dev, hyp, Kinv_in, ld_in, k, v, wv);
+    hipLaunchKernelGGL(k_append_fill2, dim3((n + 1 + 255) / 256, n + 1), dim3(256), 0, s, Kinv_in, ld_in, (const double*)v, (const double*)wv,
+                       hyp.sf2 + noise_var, n, Kinv_out, ld_out, (const double*)k, Kf_in, Ky_in, ld_k_in, Kf_out, Ky_out, hyp.sf2, noise_var);
     GPMPC_HIP(hipGetLastError());
     return GPMPC_OK;
 }

@@ -99,7 +99,7 @@ def test_diag_rollout_every_shape_vs_cport(G, ds, da):
         np.testing.assert_allclose(f["vars"].cpu().numpy(), r["vars"].cpu().numpy(), rtol=1e-7)
 
 
-@pytest.mark.parametrize("ds,da", [(2, 1), (2, 2), (3, 1), (3, 2), (4, 1), (4, 2), (5, 1), (5, 2)])
+@pytest.mark.parametrize("ds,da", [(2, 1), (2, 2), (3, 1), (3, 2), (4, 1), (4, 2), (5, 1), (5, 2), (6, 1), (6, 2)])
 def test_fullcov_rollout_every_shape_vs_cport(G, ds, da, monkeypatch):
     """Full-covariance rollout (config 5 semantics): the staged kernel (small batch) and pair_kernel_sbf.h (large batch)
     at every input dimension up to 7, against the C port: means, covariances, cost, and the analytic gradient held to
