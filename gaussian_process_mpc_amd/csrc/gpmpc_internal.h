@@ -65,6 +65,8 @@ struct gpmpc_pack {
     int fullcov;    // cross-covariance weight matrices are allocated and kept up to date
     int pair_a[GPMPC_MAX_PAIRS > 0 ? GPMPC_MAX_PAIRS : 1], pair_b[GPMPC_MAX_PAIRS > 0 ? GPMPC_MAX_PAIRS : 1];
     int* pair_ab_dev;   // [npairs][2]
+    int ncol_host;      // the value last written to ncol_dev
+    int* ncol_dev;      // [1] columns that carry weight: N rounded up to 8 (<= Np); written by every pack build (traj_persist.h reads it)
     double* X;      // dev [Np][D], rows >= N zero
     double* XT;     // dev [D][Np]
     double* beta;   // dev [ds][Np], zero padded
@@ -193,7 +195,8 @@ struct PersistArgs {
     const double* x0; const double* U; int B, H;
     double* means; double* vars; double* jac;      // [B][H+1][ds] x2, [B][H][2ds][2ds+da] (jac may be null: objective only)
     double* gscr;                                  // [B][ds][Np][GW] column rows, one slot per workgroup
-    int total;                                     // columns of the flattened (GP, row block, column) space: ds * 64 * T (T + 1) / 2
+    const int* ncol;                               // device: columns that carry weight (N rounded up to 8, <= Np); gpmpc_pack::ncol_dev
+    int total;                                     // (host bookkeeping) columns of the flattened (GP, row block, column) space at ncol = Np
 };
 template <int D> int gpmpc_launch_persist_D(bool grad, int ns2, int waves, int ng, const PersistArgs& a, hipStream_t s);
 

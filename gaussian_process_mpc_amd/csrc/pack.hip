@@ -263,6 +263,8 @@ extern "C" int gpmpc_pack_create(gpmpc_pack** out, int n_train, int state_dim, i
     if (e == hipSuccess) e = hipMalloc(&p->M, sizeof(double) * Np * Np * state_dim);
     if (e == hipSuccess) e = hipMalloc(&p->lam, sizeof(double) * state_dim * D);
     if (e == hipSuccess) e = hipMalloc(&p->sf, sizeof(double) * state_dim);
+    if (e == hipSuccess) e = hipMalloc(&p->ncol_dev, 64);
+    if (e == hipSuccess) { const int nc0 = p->Np; e = hipMemcpy(p->ncol_dev, &nc0, sizeof(int), hipMemcpyHostToDevice); p->ncol_host = nc0; }
     if (e == hipSuccess && p->npairs > 0) {
         int hab[2 * GPMPC_MAX_PAIRS];
         for (int k = 0; k < p->npairs; ++k) { hab[2 * k] = p->pair_a[k]; hab[2 * k + 1] = p->pair_b[k]; }
@@ -325,6 +327,7 @@ extern "C" int gpmpc_pack_destroy(gpmpc_pack* p) {
     if (p->M) (void)hipFree(p->M);
     if (p->lam) (void)hipFree(p->lam);
     if (p->sf) (void)hipFree(p->sf);
+    if (p->ncol_dev) (void)hipFree(p->ncol_dev);
     gpmpc_graph_cache_free(p->graph_cache);
     gpmpc_cb_cache_free(p->cb_cache);
     gpmpc_tuned_free(p->tuned);
@@ -398,6 +401,14 @@ static int pack_build_impl(gpmpc_pack* p, const double* X_dev, const double* Y_d
     if (p->fullcov && p->npairs > 0)
         hipLaunchKernelGGL(k_pack_cross, dim3((p->Np + 255) / 256, p->Np, p->npairs), dim3(256), 0, s, p->beta, p->XT, p->lam,
                            p->sf, p->pair_ab_dev, p->N, p->Np, p->D, p->ds, p->M + (size_t)p->ds * p->Np * p->Np);
+    {   // the column count that carries weight (traj_persist.h): re-sent when it changes (every 8th observation of a growing set)
+        int nc = ((p->N + 7) / 8) * 8;
+        if (nc > p->Np) nc = p->Np;
+        if (nc != p->ncol_host) {
+            if (int rcu = gpmpc_upload_small(p->ncol_dev, &nc, sizeof(int), s)) return rcu;
+            p->ncol_host = nc;
+        }
+    }
     GPMPC_HIP(hipGetLastError());
     p->built = 1;
     return GPMPC_OK;

@@ -1341,6 +1341,7 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
         Q.gscr = (double*)(ws + r.off_G);
         const int T = p->Np / 64;
         Q.total = ((p->ds + r.png - 1) / r.png) * 32 * T * (T + 1);
+        Q.ncol = p->ncol_dev;
         const int rc = timed_launch(GPMPC_TIME_FUSED, s, [&] { return launch_persist(p->D, grad, p->ds, r.pwaves, r.png, Q, s); });
         if (rc != GPMPC_OK) return rc;
         A.finished = 1;

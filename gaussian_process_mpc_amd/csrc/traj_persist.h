@@ -92,7 +92,17 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6), NW = nthr >> 6;
     const int Np = A.Np, T = Np >> 6;
-    const int per_gp = 32 * T * (T + 1);           // columns of one GP: 64 * T (T + 1) / 2
+    // Columns >= N carry zero weights: the column space of row block r ends at Nc = N rounded up to 8, not at the padded size -- for the
+    // training-set sizes of the reference's experiments that is much of the loop (N = 200: Np = 256, 224 of 640 column steps per GP; N = 300: 8 %;
+    // N = 400: 19 %).  Nc is read from the pack (device memory, refreshed by every pack build: a captured launch stays valid when the
+    // training set grows within its padded size).  start(r) = sum_{r' < r} (Nc - 64 r') = r Nc - 32 r (r - 1).
+#if defined(GPMPC_PERSIST_NO_CLIP)
+    const int Nc = Np;                             // A/B: the padded column space of the first version
+#else
+    const int Nc = __builtin_amdgcn_readfirstlane(*A.ncol);
+#endif
+    const int per_gp = T * Nc - 32 * T * (T - 1);  // columns of one GP
+    const int total = ((DS + NG - 1) / NG) * per_gp;
     double* __restrict__ s_X = s_dyn;
     double* __restrict__ s_U = s_dyn + (size_t)D * Np;       // the trajectory's actions, [H][da]
 
@@ -101,7 +111,7 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
     for (int e = tid; e < A.H * DA; e += nthr) s_U[e] = A.U[(size_t)b * A.H * DA + e];
     // boundaries on multiples of 8 columns (row blocks start on multiples of 64); computed once (64-bit divisions)
     if (tid <= NW) {
-        const int lo = tid == NW ? A.total : (int)(((long)A.total * tid / NW + 4) & ~7L);
+        const int lo = tid == NW ? total : (int)(((long)total * tid / NW + 4) & ~7L);
         s_rng[tid] = lo;
         if (tid < NW) s_ga[tid] = lo / per_gp;
     }
@@ -112,8 +122,8 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
         A.vars[((size_t)b * (A.H + 1)) * DS + tid] = GPMPC_INIT_VAR;
     }
     // this wave's range of the flattened column space
-    const int r_lo = (int)(((long)A.total * w / NW + 4) & ~7L), r_hi = w == NW - 1 ? A.total : (int)(((long)A.total * (w + 1) / NW + 4) & ~7L);
-    const int gp_first = r_lo < A.total ? r_lo / per_gp : DS;     // the unit (GP, or group of NG GPs) the range starts in (slot 0 of s_part; slot 1 = the next)
+    const int r_lo = (int)(((long)total * w / NW + 4) & ~7L), r_hi = w == NW - 1 ? total : (int)(((long)total * (w + 1) / NW + 4) & ~7L);
+    const int gp_first = r_lo < total ? r_lo / per_gp : DS;     // the unit (GP, or group of NG GPs) the range starts in (slot 0 of s_part; slot 1 = the next)
     // mean sums: a group of wpg waves per GP
     const int wpg = NW / DS > 0 ? NW / DS : 1;
     const int am = w / wpg, tg = (w - am * wpg) * 64 + lane;       // GP of this wave in phase 2, index of the thread within the group
@@ -252,10 +262,10 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
                 const int u = pos / per_gp, rem = pos - u * per_gp;
                 if (u != u_cur) { flush(slot); slot = 1; u_cur = u; }
                 int r = 0;
-                while (r + 1 < T && 64 * ((r + 1) * T - (r + 1) * r / 2) <= rem) ++r;
-                const int bstart = 64 * (r * T - r * (r - 1) / 2);
+                while (r + 1 < T && (r + 1) * Nc - 32 * (r + 1) * r <= rem) ++r;
+                const int bstart = r * Nc - 32 * r * (r - 1);
                 const int j0 = 64 * r + (rem - bstart);
-                const int blen = Np - 64 * r;
+                const int blen = Nc - 64 * r;
                 int n = bstart + blen - rem;
                 if (n > r_hi - pos) n = r_hi - pos;
                 const int i0 = 64 * r;
@@ -363,10 +373,10 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
                 if (a != a_cur) { flush(slot); slot = 1; a_cur = a; }
                 // row block r: the largest r with start(r) = 64 (r T - r (r - 1) / 2) <= rem
                 int r = 0;
-                while (r + 1 < T && 64 * ((r + 1) * T - (r + 1) * r / 2) <= rem) ++r;
-                const int bstart = 64 * (r * T - r * (r - 1) / 2);
+                while (r + 1 < T && (r + 1) * Nc - 32 * (r + 1) * r <= rem) ++r;
+                const int bstart = r * Nc - 32 * r * (r - 1);
                 const int j0 = 64 * r + (rem - bstart);            // first column of the segment
-                const int blen = Np - 64 * r;                      // columns of the row block
+                const int blen = Nc - 64 * r;                      // columns of the row block
                 int n = bstart + blen - rem;                       // ... left in it
                 if (n > r_hi - pos) n = r_hi - pos;
                 const int i0 = 64 * r;
