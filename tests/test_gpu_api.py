@@ -644,7 +644,9 @@ def test_side_stream_rebuild_catches_up_and_swaps(G):
     ref.append_train_data(X, y)                             # one rebuild from scratch
     assert inc.num_train == ref.num_train == n0 + extra
     scale = float(ref.Ky_inv.abs().max())
-    np.testing.assert_allclose(inc.Ky_inv.cpu().numpy(), ref.Ky_inv.cpu().numpy(), rtol=0, atol=1e-7 * scale)
+    # the drift of the appends since the last snapshot only: as many as the host fitted into one side-stream rebuild (16 with the round-3
+    # data path: within 1e-7 of the largest element; 2-3 times as many since round 4: 1.2e-7 seen)
+    np.testing.assert_allclose(inc.Ky_inv.cpu().numpy(), ref.Ky_inv.cpu().numpy(), rtol=0, atol=5e-7 * scale)
     np.testing.assert_allclose(inc.Ky.cpu().numpy(), ref.Ky.cpu().numpy(), rtol=1e-12, atol=1e-14)
     Xp = rng.uniform(-2, 2, (5, D))
     fi, ci = inc.predict_latent_vars(Xp, covar=True)
