@@ -1864,6 +1864,13 @@ extern "C" int gpmpc_pack_autotune(gpmpc_pack* p, int B, int H, unsigned flags, 
         };
         hipGraphExec_t exec = nullptr;
         if (use_graph) {
+            // The first launch of a kernel in a process loads its code object: that must not happen inside a stream capture (a process
+            // whose FIRST device work was this call crashed intermittently -- tools/autotune_probe.py on a fresh box, round 4): every
+            // candidate runs once as plain launches before it is captured.
+            if (pass == 0) {
+                const int r0 = enqueue(st);
+                if (r0 != GPMPC_OK || hipStreamSynchronize(st) != hipSuccess) { cand[k].ms = -1.0; continue; }
+            }
             hipGraph_t graph = nullptr;
             if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { rc = GPMPC_E_LAUNCH; break; }
             const int r1 = enqueue(st);
