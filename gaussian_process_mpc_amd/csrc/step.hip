@@ -1081,7 +1081,7 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
         const double fill16 = (double)B / ((double)g16 * cu), fill8 = (double)B / ((double)g8 * 2 * cu);
         int pw = 0;
         if (fill8 >= 0.9) pw = 8;
-        else if (fill16 >= (g16 == 1 ? 0.7 : 0.9)) pw = 16;
+        else if (fill16 >= (g16 == 1 ? (p->Np <= 256 ? 0.6 : 0.7) : 0.9)) pw = 16;     // (Np <= 256, B = 160: x1.13 against the one-launch form; profiles/r04/autotune_persist_threshold.txt)
         if (tn.persist == 8 || tn.persist == 16) pw = tn.persist;
         // With ONE lambda for all GPs the step-per-launch forms share exponent and exp across the GPs of a pair, this kernel does not
         // (yet): from three GPs on they are ahead of it (shared packs, ms per batch, step-per-launch | 16 waves | 8 waves: N = 300, ds = 4,
@@ -1851,6 +1851,8 @@ extern "C" int gpmpc_pack_autotune(gpmpc_pack* p, int B, int H, unsigned flags, 
     for (int k = 0; k < p->ds; ++k) cost.Q[k * p->ds + k] = 1.0;
     for (int k = 0; k < p->da; ++k) cost.R[k * p->da + k] = 0.01;
     const unsigned fl = grad ? GPMPC_WANT_GRAD : 0;
+    hipGraphExec_t execs[40] = {};
+    const bool trace = getenv("GPMPC_AUTOTUNE_TRACE") != nullptr;      // diagnostic: names every candidate on stderr before it runs
     const bool was_timing = timing_on();
     if (was_timing) gpmpc_timing_enable(0);                   // per-kernel events cannot be recorded inside the captures below
     // ---- time every candidate: one captured graph (or the plain launches), one warm-up, then replays for >= ~2 ms or 3 times ----
@@ -1858,15 +1860,19 @@ extern "C" int gpmpc_pack_autotune(gpmpc_pack* p, int B, int H, unsigned flags, 
     for (int k = 0; k < nc && rc == GPMPC_OK; ++k) {              // process (code upload, cold caches) must not be charged to the default plan
         if (pass == 1 && cand[k].ms < 0.0) continue;              // failed to enqueue in the first pass
         const Cand& c = cand[k];
+        if (trace) fprintf(stderr, "[autotune] pass %d candidate %d (%s): fused=%d tiling=%d sb=%d tb=%d shared=%d pwaves=%d colunroll=%d split=%d\n", pass, k, c.why,
+                           c.r.fused, c.r.tiling, c.r.sb, c.r.tb, c.r.shared, c.r.pwaves, c.r.colunroll, c.S);
         auto enqueue = [&](hipStream_t s) {
             return c.S <= 1 ? enqueue_rollout(p, B, H, x0, U, &cost, fl, nullptr, nullptr, oc, og, ws, wsb, s, nullptr, false, &c.r)
                             : enqueue_split(p, gc, c.S, c.r, s, B, H, x0, U, &cost, fl, nullptr, nullptr, oc, og, ws);
         };
-        hipGraphExec_t exec = nullptr;
-        if (use_graph) {
-            // The first launch of a kernel in a process loads its code object: that must not happen inside a stream capture (a process
-            // whose FIRST device work was this call crashed intermittently -- tools/autotune_probe.py on a fresh box, round 4): every
-            // candidate runs once as plain launches before it is captured.
+        // One captured graph per candidate, kept for both passes and destroyed together after the last replay: capturing, instantiating
+        // and destroying ~25 graphs (some with two or four parallel branches) back to back crashed intermittently inside
+        // hipGraphLaunch (native backtrace: the replay of the re-captured default plan in pass 1; 1 run in ~10, round 4).
+        hipGraphExec_t& exec = execs[k];
+        if (use_graph && !exec) {
+            // (every candidate also runs once as plain launches before it is captured: warm caches, and nothing is launched for the
+            // first time in the process inside a capture)
             if (pass == 0) {
                 const int r0 = enqueue(st);
                 if (r0 != GPMPC_OK || hipStreamSynchronize(st) != hipSuccess) { cand[k].ms = -1.0; continue; }
@@ -1902,11 +1908,12 @@ extern "C" int gpmpc_pack_autotune(gpmpc_pack* p, int B, int H, unsigned flags, 
             const double per = (double)ms1 / n;
             if (best < 0.0 || per < best) best = per;
         }
-        if (exec) (void)hipGraphExecDestroy(exec);
         if (r2 != GPMPC_OK) cand[k].ms = -1.0;
         else if (pass == 0 || best < cand[k].ms) cand[k].ms = best;
     }
     (void)hipStreamSynchronize(st);
+    (void)hipDeviceSynchronize();
+    for (int k = 0; k < nc; ++k) if (execs[k]) (void)hipGraphExecDestroy(execs[k]);
     if (was_timing) gpmpc_timing_enable(1);
     int win = -1;
     for (int k = 0; k < nc; ++k) if (cand[k].ms > 0.0 && (win < 0 || cand[k].ms < cand[win].ms)) win = k;
