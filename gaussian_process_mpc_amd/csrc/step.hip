@@ -1080,8 +1080,11 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
         const int g16 = (B + cu - 1) / cu, g8 = (B + 2 * cu - 1) / (2 * cu);
         const double fill16 = (double)B / ((double)g16 * cu), fill8 = (double)B / ((double)g8 * 2 * cu);
         int pw = 0;
-        if (fill8 >= 0.9) pw = 8;
-        else if (fill16 >= (g16 == 1 ? (p->Np <= 256 ? 0.6 : 0.7) : 0.9)) pw = 16;     // (Np <= 256, B = 160: x1.13 against the one-launch form; profiles/r04/autotune_persist_threshold.txt)
+        // thresholds re-measured with gpmpc_pack_autotune on the column-clipped kernel (profiles/r04/autotune_persist_threshold.txt): one
+        // generation of 16-wave workgroups from 0.6 (Np <= 256: B = 160 x1.13) / 0.7 (Np <= 448) / 0.9 (Np = 512: B = 192 was x0.87)
+        // trajectories per CU; two generations and more from 0.75 (N = 300, B = 384 x1.15), 8-wave workgroups from 0.85 (B = 448 x1.20)
+        if (fill8 >= 0.85) pw = 8;
+        else if (fill16 >= (g16 == 1 ? (p->Np <= 256 ? 0.6 : (p->Np <= 448 ? 0.7 : 0.9)) : 0.75)) pw = 16;
         if (tn.persist == 8 || tn.persist == 16) pw = tn.persist;
         // With ONE lambda for all GPs the step-per-launch forms share exponent and exp across the GPs of a pair, this kernel does not
         // (yet): from three GPs on they are ahead of it (shared packs, ms per batch, step-per-launch | 16 waves | 8 waves: N = 300, ds = 4,
