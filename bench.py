@@ -52,6 +52,9 @@ def parse_args():
     ap.add_argument("--no-legs", action="store_true",
                     help="skip the secondary workloads the default run times after the headline (C4, C5, C3 with one lambda, C3 at B = 1 "
                          "as one graph, the closed loop): each is a short bench.py child process, reported under `extras`")
+    ap.add_argument("--full-json", action="store_true",
+                    help="print the FULL record on stdout (every note and definition: ~4 KB per line, 14 KB with the legs) instead of "
+                         "the compact one; the default run prints the compact record and writes the full one to stderr")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the PCIe-inclusive and objective-only side measurements (profiling passes: only the timed workload runs)")
     ap.add_argument("--kinv-cache", default="",
@@ -67,6 +70,9 @@ def parse_args():
     ap.add_argument("--cl-pretrain", type=int, default=200)
     ap.add_argument("--cl-steps", type=int, default=200)
     ap.add_argument("--cl-horizon", type=int, default=10)
+    ap.add_argument("--cl-starts", type=int, default=1,
+                    help="closed loop: lock-step multi-start solve with this many starts (RiskSensitiveMPC.n_starts; every solver "
+                         "iteration is one batched rollout of that many candidate plans)")
     ap.add_argument("--cl-distinct", action="store_true", help="closed loop: a different lambda per GP (no shared inverse)")
     ap.add_argument("--cl-async", action="store_true", help="closed loop: the every-64 full rebuild on a side stream (catch-up + swap)")
     ap.add_argument("--cl-newton", action="store_true",
@@ -293,7 +299,7 @@ def measured_traffic(config, B, want_grad, kernel_hint):
     FETCH_SIZE x 2 for the gfx950 wide-read correction + WRITE_SIZE, both in KiB).  None when no summary matches."""
     d, rnd, name = None, None, None
     sh = "_shared" if kernel_hint == "sbs" else ""
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         for name in (f"pmc_{config}_B{B}{sh}.json", f"pmc_{config}{sh}.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", rnd, name)) as f:
@@ -334,39 +340,92 @@ LEGS = [
     ("N300_B256_shared_lambda", ["--config", "C3", "--n-train", "300", "--batch", "256", "--shared-lambda", "--steps", "20", "--warmup", "5"]),
     ("N300_B256", ["--config", "C3", "--n-train", "300", "--batch", "256", "--steps", "20", "--warmup", "5"]),
     ("closed_loop_newton", ["--closed-loop", "--cl-newton", "--cl-steps", "50"]),
+    ("closed_loop_newton_16_starts", ["--closed-loop", "--cl-newton", "--cl-steps", "50", "--cl-starts", "16"]),
 ]
+
+
+def short_kernel(name):
+    """Kernel instance without the explanatory parenthetical the full record appends."""
+    return (name or "").split(" (")[0]
 
 
 def run_legs(timeout_s=240):
     """The other BASELINE configs and regimes, each as a short `bench.py` child process AFTER the headline's timed region (the
     headline line stays what it was; a child starts with a fresh GPU context and frees everything on exit).  Returns
-    {name: compact record}; a leg that fails or times out is recorded as such, never dropped silently."""
-    keep_roof = ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches", "sub_batches_per_call",
-                 "issue_util", "executed_flops_frac", "hbm_algorithmic_GBs", "hbm_frac", "kernel_timed_in", "valu_frac_algorithmic")
-    out = {}
+    ({name: COMPACT record}, {name: full record}): the driver keeps 8 KB of stdout, so the stdout line carries at most ~250 bytes
+    per leg -- value, ms_per_step, kernel, bound, frac, avg_launch_ms -- and the full records (commands, workload strings, every
+    roofline key) go to stderr and gpurun_out/.  A leg that fails or times out is recorded as such, never dropped silently."""
+    out, full = {}, {}
     for name, argv in LEGS:
-        cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--no-cpu-baseline", "--no-extras", "--no-legs"]
+        cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--no-cpu-baseline", "--no-extras", "--no-legs", "--full-json"]
         t0 = time.perf_counter()
         try:
             p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
             lines = [ln for ln in p.stdout.splitlines() if ln.lstrip().startswith("{")]
             if p.returncode != 0 or not lines:
-                out[name] = {"error": f"exit status {p.returncode}", "stderr_tail": p.stderr[-400:], "command": " ".join(argv)}
+                out[name] = {"error": f"exit status {p.returncode}"}
+                full[name] = {"error": f"exit status {p.returncode}", "stderr_tail": p.stderr[-400:], "command": " ".join(argv)}
                 continue
             d = json.loads(lines[-1])
         except subprocess.TimeoutExpired:
-            out[name] = {"error": f"timed out after {timeout_s} s", "command": " ".join(argv)}
+            out[name] = {"error": f"timed out after {timeout_s} s"}
+            full[name] = dict(out[name], command=" ".join(argv))
             continue
-        rec = {"command": "bench.py " + " ".join(argv), "value": d.get("value"), "unit": d.get("unit"),
-               "higher_is_better": d.get("higher_is_better"), "steps": d.get("steps"), "warmup": d.get("warmup"),
-               "ms_per_step": d.get("ms_per_step"), "workload": (d.get("config") or {}).get("workload"),
-               "leg_wall_s": time.perf_counter() - t0}
-        if "roofline" in d:
-            rec["roofline"] = {k: d["roofline"].get(k) for k in keep_roof if k in d["roofline"]}
-        for k in ("step_ms", "split_ms_mean", "inverse_update_ms", "step_ms_excluding_solve"):
-            if k in d:
-                rec[k] = d[k]
-        out[name] = rec
+        d["command"] = "bench.py " + " ".join(argv)
+        d["leg_wall_s"] = time.perf_counter() - t0
+        full[name] = d
+        rec = {"value": _sig(d.get("value")), "unit": d.get("unit"), "ms_per_step": _sig(d.get("ms_per_step"))}
+        r = d.get("roofline")
+        if r:
+            rec.update({"kernel": short_kernel(r.get("kernel")), "bound": r.get("bound"), "frac": _sig(r.get("frac"), 3),
+                        "avg_launch_ms": _sig(r.get("avg_launch_ms"))})
+        if "step_ms" in d:                                 # closed loop: ms per environment step
+            rec.update({"p95": _sig(d["step_ms"].get("p95")), "max": _sig(d["step_ms"].get("max")),
+                        "solve": _sig((d.get("split_ms_mean") or {}).get("solve")),
+                        "inverse_update": _sig((d.get("inverse_update_ms") or {}).get("append_mean")),
+                        "starts": d.get("starts")})
+            rec.pop("ms_per_step", None)
+        out[name] = {k: v for k, v in rec.items() if v is not None}
+    return out, full
+
+
+def _sig(v, n=4):
+    """Round to n significant digits (compact JSON); passes None / non-floats through."""
+    if not isinstance(v, float) or v != v or v in (float("inf"), float("-inf")) or v == 0.0:
+        return v
+    from math import floor, log10
+    return round(v, n - 1 - int(floor(log10(abs(v)))))
+
+
+# keys of the full roofline / cpu_baseline blocks that stay on the stdout line (numbers and short identifiers; the explanatory
+# strings -- bound_note, definition, *_note, traffic_source, sample details -- go to stderr and DESIGN.md section 5)
+ROOF_KEEP = ("kernel", "bound", "served_from", "achieved", "peak", "unit", "frac", "traffic", "traffic_measured_in_run", "traffic_sidecar",
+             "algorithmic_flops_per_pair", "pairs_per_launch", "avg_launch_ms", "launches", "sub_batches_per_call", "issue_util",
+             "executed_flops_frac", "hbm_frac", "valu_frac_algorithmic", "first_step_variant", "kernel_timed_in", "plan")
+CPU_KEEP = ("value", "unit", "cores", "kind", "sample", "cpu_model", "faithful_1_thread", "o2_value", "c_port_value",
+            "c_port_value_1_thread", "oracle_over_reference_time", "gpu_over_cpu", "gpu_over_c_port")
+
+
+def compact_record(full):
+    """The stdout line: every top-level key of the contract, `roofline` and `cpu_baseline` with their numbers, `extras` compact."""
+    out = {}
+    for k, v in full.items():
+        if k == "roofline":
+            r = {kk: v[kk] for kk in ROOF_KEEP if kk in v}
+            r["kernel"] = short_kernel(r.get("kernel"))
+            if isinstance(r.get("plan"), dict):
+                r["plan"] = {kk: r["plan"][kk] for kk in ("form", "tiling", "workgroups", "launches_per_step", "split") if kk in r["plan"]}
+            r["kernel_timed_in"] = "timed region" if r.get("kernel_timed_in") == "the timed region" else "separate uncaptured pass"
+            r["notes"] = "definitions: DESIGN.md section 5; full record on stderr (BENCH_FULL) and in gpurun_out/bench_full.json"
+            out[k] = {kk: (_sig(vv, 5) if isinstance(vv, float) else vv) for kk, vv in r.items()}
+        elif k == "cpu_baseline":
+            out[k] = {kk: (_sig(v[kk], 4) if isinstance(v[kk], float) else v[kk]) for kk in CPU_KEEP if kk in v}
+        elif k in ("extras_full", "multi_gpu_notes"):
+            continue
+        elif k == "sustained":
+            out[k] = {kk: _sig(vv) if isinstance(vv, float) else vv for kk, vv in v.items()}
+        else:
+            out[k] = v
     return out
 
 
@@ -615,7 +674,7 @@ def run_rank(args):
                      else ("bench.py spawn" if world > 1 else "single process")},
             "roofline": ({
                 "kernel": kname,
-                "bound": "infinity_cache" if ic_resident else "hbm",
+                "bound": "hbm", "served_from": "infinity_cache" if ic_resident else "hbm",
                 "bound_note": f"weight stream: one launch must read the upper triangles of the {ds} weight matrices ({m_launch / 1e6:.1f} MB "
                               f"algorithmic) and that takes longer at 8 TB/s ({t_hbm * 1e6:.1f} us) than the column loop's VALU "
                               f"instructions at the spec clock ({t_valu * 1e6:.1f} us); "
@@ -634,6 +693,7 @@ def run_rank(args):
             }) | {
                 "kernel_timed_in": kernel_timed_in, "plan": plan,
                 "traffic": traffic, "traffic_source": traffic_src,
+                "traffic_sidecar": traffic_src.split(" ")[0] if traffic_src else None,
                 "traffic_measured_in_run": False,
                 "traffic_note": "PMC counters need separate rocprofv3 --pmc passes: `traffic` is the per-launch figure of the tracked "
                                 "sidecar named in traffic_source (its HEAD is stated there), null when none matches this workload",
@@ -698,7 +758,7 @@ def run_rank(args):
         default_run = (args.config == "C3" and not args.batch and not args.n_train and not args.shared_lambda and not args.graph
                        and not args.forward_only)
         if world == 1 and default_run and not args.no_legs and not args.no_extras:
-            out["extras"] = run_legs()
+            out["extras"], out["extras_full"] = run_legs()
         if not args.no_cpu_baseline and world == 1:
             res = cpu_baseline(pb, cfg, fullcov, args.cpu_reps)
             H_s = res["H_sample"]
@@ -729,7 +789,21 @@ def run_rank(args):
             if isinstance(v, float) and (v != v or v in (float("inf"), float("-inf"))):
                 return None
             return v
-        print(json.dumps(_clean(out), allow_nan=False), flush=True)
+        full = _clean(out)
+        if args.full_json:
+            full.pop("extras_full", None)
+            print(json.dumps(full, allow_nan=False), flush=True)
+        else:
+            # stdout: the compact record (< 6 KB: the driver keeps an 8 KB tail); stderr + gpurun_out/: everything
+            print("BENCH_FULL " + json.dumps(full, allow_nan=False), file=sys.stderr, flush=True)
+            try:
+                if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+                    with open(os.path.join(ROOT, "gpurun_out", "bench_full.json"), "w") as f:
+                        json.dump(full, f)
+            except OSError:
+                pass
+            line = json.dumps(compact_record(full), allow_nan=False, separators=(",", ":"))
+            print(line, flush=True)
     if world > 1:
         dist.destroy_process_group()
     return 0
@@ -749,6 +823,7 @@ def run_closed_loop(args):
     plant = g.PendulumPlant()
     H = args.cl_horizon
     mpc = g.RiskSensitiveMPC(1e-5, H, 2, 1, Q=2 * np.eye(2), R=0.001 * np.eye(1))
+    mpc.n_starts = max(1, args.cl_starts)
     for k, gp in enumerate(mpc.dynamics.gpr_err):         # hypers before data, as in pretrain_uncertainty.py:100-105
         gp.set_lambdas(np.array([0.5, 0.5, 0.5]) * (1.0 + (0.1 * k if args.cl_distinct else 0.0)))
         gp.set_sigma_n(1e-3)
@@ -775,15 +850,20 @@ def run_closed_loop(args):
                                    refresh="newton" if args.cl_newton else None); sync()
     obs = nxt0
     n0 += 1
-    rows = []
+    rows, ticks, plan_cost = [], [], []
     for it in range(args.cl_steps):
         sync(); ta = time.perf_counter()
         mpc.dynamics.pack(); sync(); tb = time.perf_counter()
         action = mpc.get_optimal_trajectory(obs)[0, :]; tc = time.perf_counter()
+        if mpc.last_solve_info is not None:                # (untimed bookkeeping: the cost of the plan that was returned)
+            ticks.append(mpc.last_solve_info["evaluations"]); plan_cost.append(float(np.min(mpc.last_solve_info["f"])))
+        else:
+            plan_cost.append(float(mpc.objective(np.asarray(mpc.last_traj))))
+        tc2 = time.perf_counter()
         nxt, _, _, _, _ = plant.step(action); td = time.perf_counter()
         before = mpc.dynamics.gpr_err[0]._appends_since_rebuild
         mpc.dynamics.append_train_data(obs, action, nxt, incremental=not args.cl_rebuild); sync(); te = time.perf_counter()
-        rows.append((tb - ta, tc - tb, td - tc, te - td, mpc.dynamics.gpr_err[0]._appends_since_rebuild <= before))
+        rows.append((tb - ta, tc - tb, td - tc2, te - td, mpc.dynamics.gpr_err[0]._appends_since_rebuild <= before))
         obs = nxt
     r = np.array([[a, b, c, d] for a, b, c, d, _ in rows]) * 1e3
     full = np.array([x[4] for x in rows])
@@ -813,6 +893,9 @@ def run_closed_loop(args):
                               "full_rebuild_mean": float(r[full, 3].mean()) if full.any() else None,
                               "full_rebuilds": int(full.sum())},
         "first_build_ms": t_first_build,
+        "starts": mpc.n_starts,
+        "batched_evaluations_per_solve_mean": float(np.mean(ticks)) if ticks else None,
+        "planned_cost_mean": float(np.mean(plan_cost)) if plan_cost else None,
         "solve_callbacks_note": "solve = scipy L-BFGS-B stand-in on the objective / gradient callbacks (cyipopt absent): optimiser "
                                 "results are unpinned, the timing split is what is reported",
     }

@@ -32,8 +32,8 @@
 // phase by thread 0, and the column-loop interval of every wave -- read back with gpmpc_debug_persist_stamps (tools/persist_stamps.py).
 #if defined(GPMPC_PERSIST_STAMPS)
 static __device__ unsigned long long g_persist_stamps[64];
-#define GPMPC_PST(slot) do { if (t == 3 && blockIdx.x == 0 && tid == 0) g_persist_stamps[slot] = __builtin_amdgcn_s_memtime(); } while (0)
-#define GPMPC_PSTW(slot) do { if (t == 3 && blockIdx.x == 0 && lane == 0) g_persist_stamps[(slot) + w] = __builtin_amdgcn_s_memtime(); } while (0)
+#define GPMPC_PST(slot) do { if (t == 3 && blockIdx.x == 0 && threadIdx.x == 0) g_persist_stamps[slot] = __builtin_amdgcn_s_memtime(); } while (0)
+#define GPMPC_PSTW(slot) do { if (t == 3 && blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_persist_stamps[(slot) + w] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define GPMPC_PST(slot) do { } while (0)
 #define GPMPC_PSTW(slot) do { } while (0)
@@ -59,6 +59,7 @@ static __device__ unsigned long long g_persist_stamps[64];
 #ifndef GPMPC_PERSIST_ROTPRIO
 #define GPMPC_PERSIST_ROTPRIO 1
 #endif
+#define GPMPC_PERSIST_MAXDEV 64
 #ifndef GPMPC_PERSIST_MAXNP
 #define GPMPC_PERSIST_MAXNP 1024                   // X in LDS: Np * D doubles (57 KB at D = 7)
 #endif
@@ -78,8 +79,6 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
     // Not only speed: the D = 8, ds = 7 instance with 94 VGPR + 80 SGPR spills returned means with the low mantissa word of some
     // double lost (1e-6 relative, deterministic, the objective-only instance and every lighter one exact) -- a spill-path miscompile;
     // tests/test_gpu_instances.py holds every (ds, da) instance to the C port.
-    constexpr int MG = GPMPC_PERSIST_MG ? GPMPC_PERSIST_MG : (D >= 7 ? 2 : 4);
-    constexpr int ILPW = GPMPC_PERSIST_ILP ? GPMPC_PERSIST_ILP : (D >= 7 ? 1 : 2);
     extern __shared__ double s_dyn[];              // X: [D][Np]
     __shared__ double s_tab[GPMPC_EXP_N];
     __shared__ double s_part[16 * 2 * NG * 4 * NM];    // [wave][first | second unit of the wave's range][GP of the unit][row of 16 lanes][moment]
@@ -87,9 +86,9 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
     __shared__ double s_z[DS * NM], s_ms[DS * NV];
     __shared__ double s_uin[D], s_sin[D];
     __shared__ double s_B[DS * D], s_Ak[DS * D], s_sc[DS * D], s_cv[DS * D], s_r1[DS * D], s_r2[DS * D];
-    __shared__ double s_c[DS], s_cm[DS], s_sf2[DS];
+    __shared__ double s_c[DS], s_cm[DS], s_sf2[DS], s_lam[DS * D], s_avar;
     __shared__ int s_rng[17], s_ga[16];            // range boundaries of the waves in the flattened column space; GP a range starts in
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
+    const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6), NW = nthr >> 6;
     const int Np = A.Np, T = Np >> 6;
     // Columns >= N carry zero weights: the column space of row block r ends at Nc = N rounded up to 8, not at the padded size -- for the
@@ -115,7 +114,8 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
         s_rng[tid] = lo;
         if (tid < NW) s_ga[tid] = lo / per_gp;
     }
-    const double lam_mine = A.lam[tid < DS * D ? tid : 0];
+    if (tid == 0) s_avar = GPMPC_ACTION_VAR;                   // (a constant read from LDS per step: held in a register pair it was a spill)
+    if (tid < DS * D) s_lam[tid] = A.lam[tid];             // (read per step from LDS: a register held across the step loop is a spill)
     if (tid < DS) { s_uin[tid] = A.x0[(size_t)b * DS + tid]; s_sin[tid] = GPMPC_INIT_VAR; }
     if (tid < DS) {
         A.means[((size_t)b * (A.H + 1)) * DS + tid] = s_uin[tid];
@@ -126,9 +126,8 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
     const int gp_first = r_lo < total ? r_lo / per_gp : DS;     // the unit (GP, or group of NG GPs) the range starts in (slot 0 of s_part; slot 1 = the next)
     // mean sums: a group of wpg waves per GP
     const int wpg = NW / DS > 0 ? NW / DS : 1;
-    const int am = w / wpg, tg = (w - am * wpg) * 64 + lane;       // GP of this wave in phase 2, index of the thread within the group
+    const int am = w / wpg, tgw = (w - am * wpg) * 64;             // GP of this wave in phase 2, first thread index of the wave within the group
     double* __restrict__ Gs = A.gscr + (size_t)b * DS * Np * GW;
-    const int lane8 = lane * 8;
 
     for (int t = 1; t <= A.H; ++t) {
         // Everything below that depends only on the thread index (row / GP of a thread in each phase, addresses, an integer division) is
@@ -141,14 +140,15 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
 #else
         const int tz = 0;
 #endif
-        const int tiz = tid + tz;
+        // (the lane index too: mbcnt with a base the compiler cannot hoist, so that neither tid nor lane is held across the step loop)
+        const int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, tz)), tiz = w * 64 + ln, l8 = ln * 8;
         GPMPC_PST(0);
         // ---- 1: input moments of the action dimensions, then the per-(GP, dimension) scalars ------------------------------------
-        if (DA > 0 && tid >= DS && tid < D) { s_uin[tid] = s_U[(t - 1) * DA + (tid - DS)]; s_sin[tid] = GPMPC_ACTION_VAR; }
+        if (DA > 0 && tiz >= DS && tiz < D) { s_uin[tiz] = s_U[(t - 1) * DA + (tiz - DS)]; s_sin[tiz] = s_avar; }
         GPMPC_LDS_BARRIER();
         if (tiz < DS * D) {
             const int a = tiz / D, k = tiz - a * D;
-            const double lam = lam_mine, sk = s_sin[k], uk = s_uin[k];
+            const double lam = s_lam[tiz], sk = s_sin[k], uk = s_uin[k];
             s_B[tiz] = 1.0 / (sk + lam);
             s_Ak[tiz] = 1.0 / (0.5 * lam + sk);
             const double sc = rsqrt(8.0 * (0.5 * lam + sk));       // the pair transform h = sc (u - x), as step_fused.h
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
         // weights of this thread's points in the mean sums of GP am: requested now, used in 2b
         constexpr int PT = 4;
         double bpre[PT];
-        const int tgz = tg + tz;
+        const int tgz = tgw + ln;
 #pragma unroll
         for (int q = 0; q < PT; ++q) {
             const int i = tgz + q * 64 * wpg;
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
 #pragma unroll
             for (int m = 0; m < NV; ++m) {
                 const double sr = wave_row_sum(v[m]);
-                if ((lane & 15) == 0) s_mred[(w * 4 + (lane >> 4)) * NV + m] = sr;
+                if ((ln & 15) == 0) s_mred[(w * 4 + (ln >> 4)) * NV + m] = sr;
             }
         }
         GPMPC_PST(3);
@@ -237,50 +237,56 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
         }
         GPMPC_PST(6);
         GPMPC_PSTW(16);
-        // ---- 3 (one lambda for all GPs): this wave's range over units of NG GPs ----------------------------------------------------
-        if constexpr (SH) {
-            double zsum[NG][NM];
-#pragma unroll
-            for (int q = 0; q < NG; ++q)
-#pragma unroll
-                for (int m = 0; m < NM; ++m) zsum[q][m] = 0.0;
+        // ---- 3: this wave's range of the N^2 sum, over UNITS of NG GPs (NG = 1: a unit is a GP) ------------------------------------
+        // Round 5.  The loop is latency-bound per wave, not issue-bound (tools/ubench/latency_probe.hip: a scalar load of a G row that
+        // is not in the scalar cache takes ~550 cycles, an LDS table read 60; four waves per SIMD hide 3 x 115 cycles per column): the
+        // compiler's own schedule waited for scalar loads twice and for the table four times per two columns.  Columns are therefore
+        // evaluated in BATCHES of KC with the stages pinned by sched_barriers -- all G rows of the batch (one scalar-load wait), all
+        // exponents and table reads (one LDS wait), then the weights and moment sums -- and the weight loads of the next group of
+        // columns are in flight meanwhile (both kinds of unit now: the shared-lambda units had no weight prefetch).  The lane sums of a
+        // (unit, row block) segment are reduced and ADDED to the wave's LDS slot at the end of the segment instead of living in
+        // 2 NG (1 + 2 D) registers across the whole range: that was what spilled (k_traj_persist<5,4,true,2>: 40 VGPR spills).
+        {
+            // columns per batch (KC (D + 1 + ds) doubles of G rows in SGPRs, KC sets of exp temporaries in VGPRs) and per group of
+            // weight loads (two groups in flight): what fits the 128 registers of four waves per SIMD WITHOUT a spill (tools/spill_guard.py)
+            constexpr int KC = (D >= 7 || (NG > 1 && D >= 6)) ? 1 : 2;
+            constexpr int MGc = GPMPC_PERSIST_MG ? GPMPC_PERSIST_MG : ((NG > 1 || D >= 6) ? 2 : 4);
+            static_assert(MGc % KC == 0 && 8 % (2 * MGc) == 0, "segment lengths are multiples of 8 columns");
             int pos = r_lo, slot = 0, u_cur = gp_first;
+            for (int e = ln; e < 2 * NG * 4 * NM; e += 64) s_part[w * (2 * NG * 4 * NM) + e] = 0.0;   // (a wave's LDS operations execute in order)
             const double* Gl = Gs;
-            asm volatile("" : "+s"(Gl) :: "memory");
+            asm volatile("" : "+s"(Gl) :: "memory");               // rows written a moment ago: keep the scalar loads behind the barrier
             typedef const double __attribute__((address_space(4))) gpmpc_cdouble;
-            auto flush = [&](int sl) {
-#pragma unroll
-                for (int q = 0; q < NG; ++q)
-#pragma unroll
-                    for (int m = 0; m < NM; ++m) {
-                        const double sr = wave_row_sum(zsum[q][m]);
-                        if ((lane & 15) == 0) s_part[(((w * 2 + sl) * NG + q) * 4 + (lane >> 4)) * NM + m] = sr;
-                        zsum[q][m] = 0.0;
-                    }
-            };
             while (pos < r_hi) {
                 const int u = pos / per_gp, rem = pos - u * per_gp;
-                if (u != u_cur) { flush(slot); slot = 1; u_cur = u; }
+                if (u != u_cur) { slot = 1; u_cur = u; }
+                // row block r: the largest r with start(r) = r Nc - 32 r (r - 1) <= rem
                 int r = 0;
                 while (r + 1 < T && (r + 1) * Nc - 32 * (r + 1) * r <= rem) ++r;
                 const int bstart = r * Nc - 32 * r * (r - 1);
-                const int j0 = 64 * r + (rem - bstart);
-                const int blen = Nc - 64 * r;
-                int n = bstart + blen - rem;
+                const int j0 = 64 * r + (rem - bstart);            // first column of the segment
+                const int blen = Nc - 64 * r;                      // columns of the row block
+                int n = bstart + blen - rem;                       // ... left in it
                 if (n > r_hi - pos) n = r_hi - pos;
                 const int i0 = 64 * r;
                 __amdgpu_buffer_rsrc_t Mrs[NG];
 #pragma unroll
                 for (int q = 0; q < NG; ++q) {
-                    const int a = u * NG + q < DS ? u * NG + q : DS - 1;
+                    const int a = u * NG + q < DS ? u * NG + q : DS - 1;       // (a partial last unit re-reads the last GP; not combined)
                     Mrs[q] = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(A.M + ((size_t)a * Np + j0) * Np + i0), 0, 0x7fffffff, 0x00020000);
                 }
+                double mga[MGc][NG], mgb[MGc][NG];
+#pragma unroll
+                for (int c = 0; c < MGc; ++c)
+#pragma unroll
+                    for (int q = 0; q < NG; ++q) mga[c][q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs[q], l8, c * Np * 8, 0));
+                const int at = SH ? 0 : u;                         // the transform of GP 0 is that of every GP when lambda is shared
                 double hi2[D], qi;
                 {
                     double q = 0.0;
 #pragma unroll
                     for (int k = 0; k < D; ++k) {
-                        const double h = fma(-s_sc[k], s_X[k * Np + i0 + lane], s_cv[k]);      // the transform of GP 0 = of every GP
+                        const double h = fma(-s_sc[at * D + k], s_X[k * Np + i0 + ln], s_cv[at * D + k]);
                         hi2[k] = (2.0 * GPMPC_EXP_NEG_INV_C) * h;
                         q = fma(h, h, q);
                     }
@@ -291,130 +297,50 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
                 for (int q = 0; q < NG; ++q)
 #pragma unroll
                     for (int m = 0; m < NA; ++m) acc[q][m] = 0.0;
-                const double* Ga = Gl + (size_t)j0 * GW;
-                constexpr int CS = 2;                                  // columns per iteration
-                for (int jc = 0; jc < n; jc += CS) {                   // n is a multiple of 8
-#if GPMPC_PERSIST_ROTPRIO
-                    switch (((jc >> GPMPC_PERSIST_PRIO_SHIFT) + (w >> 2)) & 3) {
-                        case 0: __builtin_amdgcn_s_setprio(0); break;
-                        case 1: __builtin_amdgcn_s_setprio(1); break;
-                        case 2: __builtin_amdgcn_s_setprio(2); break;
-                        default: __builtin_amdgcn_s_setprio(3); break;
+                const double* Ga = Gl + ((size_t)at * Np + j0) * GW;
+                // KC columns: rows -> exponents + table reads -> weights x exp, moment sums
+                auto batch = [&](int j, const double (*mw)[NG]) {
+                    double g[KC][GW];
+#pragma unroll
+                    for (int c = 0; c < KC; ++c) {
+                        const gpmpc_cdouble* __restrict__ gp = (const gpmpc_cdouble*)(Ga + (size_t)(j + c) * GW);
+#pragma unroll
+                        for (int k = 0; k < D + 1 + NS2; ++k) g[c][k] = gp[k];
                     }
-#endif
-                    double mij[CS][NG];
+                    __builtin_amdgcn_sched_barrier(0);
+                    double fr[KC], pq[KC], Tv[KC];
+                    int ni[KC];
 #pragma unroll
-                    for (int c = 0; c < CS; ++c)
+                    for (int c = 0; c < KC; ++c) {
+                        double sx = qi + g[c][D];
 #pragma unroll
-                        for (int q = 0; q < NG; ++q)
-                            mij[c][q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs[q], lane8, (jc + c) * Np * 8, 0));
+                        for (int k = 0; k < D; ++k) sx = fma(hi2[k], g[c][k], sx);
+                        const double ax = __builtin_fabs(sx);      // gpmpc_exp_neg_scaled (fast_exp.h), split around the table read
+                        ni[c] = (int)(-ax);
+                        fr[c] = __builtin_amdgcn_fract(ax);
+                        Tv[c] = s_tab[ni[c] & (GPMPC_EXP_N - 1)];
+                        if (NG == 1) pq[c] = fma(fr[c], fma(fr[c], GPMPC_EXP_A3, GPMPC_EXP_A2), GPMPC_EXP_A1);   // in the shadow of the table read
+                    }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int c = 0; c < CS; ++c) {
-                        const gpmpc_cdouble* __restrict__ g = (const gpmpc_cdouble*)(Ga + (size_t)(jc + c) * GW);
-                        double sx = qi + g[D];
-#pragma unroll
-                        for (int k = 0; k < D; ++k) sx = fma(hi2[k], g[k], sx);
-                        const double e = gpmpc_exp_neg_scaled(sx, s_tab);
+                    for (int c = 0; c < KC; ++c) {
+                        if (NG > 1) pq[c] = fma(fr[c], fma(fr[c], GPMPC_EXP_A3, GPMPC_EXP_A2), GPMPC_EXP_A1);    // (two GPs' sums: registers are short)
+                        const double e = ldexp(fma(Tv[c] * fr[c], pq[c], Tv[c]), ni[c] >> GPMPC_EXP_BITS);
 #pragma unroll
                         for (int q = 0; q < NG; ++q) {
-                            const double P = mij[c][q] * e;
+                            const double P = mw[c][q] * e;
                             acc[q][0] += P;
                             if (GRAD) {
 #pragma unroll
-                                for (int k = 0; k < D; ++k) acc[q][GRAD ? 1 + k : 0] = fma(P, g[k], acc[q][GRAD ? 1 + k : 0]);
+                                for (int k = 0; k < D; ++k) acc[q][GRAD ? 1 + k : 0] = fma(P, g[c][k], acc[q][GRAD ? 1 + k : 0]);
 #pragma unroll
-                                for (int k = 0; k < NS2; ++k) acc[q][GRAD ? 1 + D + k : 0] = fma(P, g[D + 1 + k], acc[q][GRAD ? 1 + D + k : 0]);
+                                for (int k = 0; k < NS2; ++k) acc[q][GRAD ? 1 + D + k : 0] = fma(P, g[c][D + 1 + k], acc[q][GRAD ? 1 + D + k : 0]);
                             }
                         }
                     }
-                }
-#pragma unroll
-                for (int q = 0; q < NG; ++q) {
-                    const double rs = acc[q][0];
-                    zsum[q][0] += rs;
-                    if (GRAD) {
-#pragma unroll
-                        for (int k = 0; k < D; ++k) {
-                            const double h = (0.5 / GPMPC_EXP_NEG_INV_C) * hi2[k], v = acc[q][GRAD ? 1 + k : 0];
-                            zsum[q][GRAD ? 1 + k : 0] += fma(h, rs, v);
-                            if (k < NS2) zsum[q][GRAD ? 1 + D + k : 0] += fma(h * h, rs, fma(2.0 * h, v, acc[q][GRAD ? 1 + D + (k < NS2 ? k : 0) : 0]));
-                        }
-                    }
-                }
-                pos += n;
-            }
-            GPMPC_PSTW(32);
-#if GPMPC_PERSIST_ROTPRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
-            if (r_lo < r_hi) flush(slot);
-            GPMPC_PSTW(48);
-        } else
-        // ---- 3: this wave's range of the N^2 sum ------------------------------------------------------------------------------
-        {
-            double zsum[NM];
-#pragma unroll
-            for (int m = 0; m < NM; ++m) zsum[m] = 0.0;
-            int pos = r_lo, slot = 0, a_cur = gp_first;
-            const double* Gl = Gs;
-            asm volatile("" : "+s"(Gl) :: "memory");               // rows written a moment ago: keep the scalar loads behind the barrier
-            typedef const double __attribute__((address_space(4))) gpmpc_cdouble;
-            auto flush = [&](int sl) {                              // reduce the lane sums of one GP, rows of 16 lanes
-#pragma unroll
-                for (int m = 0; m < NM; ++m) {
-                    const double sr = wave_row_sum(zsum[m]);
-                    if ((lane & 15) == 0) s_part[((w * 2 + sl) * 4 + (lane >> 4)) * NM + m] = sr;
-                    zsum[m] = 0.0;
-                }
-            };
-            while (pos < r_hi) {
-                const int a = pos / per_gp, rem = pos - a * per_gp;
-                if (a != a_cur) { flush(slot); slot = 1; a_cur = a; }
-                // row block r: the largest r with start(r) = 64 (r T - r (r - 1) / 2) <= rem
-                int r = 0;
-                while (r + 1 < T && (r + 1) * Nc - 32 * (r + 1) * r <= rem) ++r;
-                const int bstart = r * Nc - 32 * r * (r - 1);
-                const int j0 = 64 * r + (rem - bstart);            // first column of the segment
-                const int blen = Nc - 64 * r;                      // columns of the row block
-                int n = bstart + blen - rem;                       // ... left in it
-                if (n > r_hi - pos) n = r_hi - pos;
-                const int i0 = 64 * r;
-                const __amdgpu_buffer_rsrc_t Mrs = __builtin_amdgcn_make_buffer_rsrc(
-                    const_cast<double*>(A.M + ((size_t)a * Np + j0) * Np + i0), 0, 0x7fffffff, 0x00020000);
-                double mga[MG], mgb[MG];
-#pragma unroll
-                for (int q = 0; q < MG; ++q) mga[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, q * Np * 8, 0));
-                double hi2[D], qi;
-                {
-                    double q = 0.0;
-#pragma unroll
-                    for (int k = 0; k < D; ++k) {
-                        const double h = fma(-s_sc[a * D + k], s_X[k * Np + i0 + lane], s_cv[a * D + k]);
-                        hi2[k] = (2.0 * GPMPC_EXP_NEG_INV_C) * h;
-                        q = fma(h, h, q);
-                    }
-                    qi = GPMPC_EXP_NEG_INV_C * q;
-                }
-                double acc[NA];
-#pragma unroll
-                for (int m = 0; m < NA; ++m) acc[m] = 0.0;
-                const double* Ga = Gl + ((size_t)a * Np + j0) * GW;
-                auto column = [&](int j, double mij) {
-                    const gpmpc_cdouble* __restrict__ g = (const gpmpc_cdouble*)(Ga + (size_t)j * GW);
-                    double sx = qi + g[D];
-#pragma unroll
-                    for (int k = 0; k < D; ++k) sx = fma(hi2[k], g[k], sx);
-                    const double P = mij * gpmpc_exp_neg_scaled(sx, s_tab);
-                    acc[0] += P;
-                    if (GRAD) {
-#pragma unroll
-                        for (int k = 0; k < D; ++k) acc[GRAD ? 1 + k : 0] = fma(P, g[k], acc[GRAD ? 1 + k : 0]);
-#pragma unroll
-                        for (int k = 0; k < NS2; ++k) acc[GRAD ? 1 + D + k : 0] = fma(P, g[D + 1 + k], acc[GRAD ? 1 + D + k : 0]);
-                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 };
-                for (int jc = 0; jc < n; jc += 2 * MG) {           // n is a multiple of 8
+                for (int jc = 0; jc < n; jc += 2 * MGc) {          // n is a multiple of 8
 #if GPMPC_PERSIST_ROTPRIO
                     // The four waves a SIMD holds of this workgroup are arbitrated by age: left alone the oldest runs ahead and the
                     // youngest finishes 40 % later, the SIMD half empty at the end (stamps: wave 2 109 k cycles, wave 15 165 k for
@@ -427,32 +353,45 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
                     }
 #endif
 #pragma unroll
-                    for (int q = 0; q < MG; ++q)
-                        mgb[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, (jc + MG + q) * Np * 8, 0));
+                    for (int c = 0; c < MGc; ++c)
+#pragma unroll
+                        for (int q = 0; q < NG; ++q)
+                            mgb[c][q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs[q], l8, (jc + MGc + c) * Np * 8, 0));
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int q = 0; q < MG; ++q) { column(jc + q, mga[q]); if (q % ILPW == ILPW - 1) __builtin_amdgcn_sched_barrier(0); }
+                    for (int c = 0; c < MGc; c += KC) batch(jc + c, &mga[c]);
                     {   // unconditional (the last iteration re-requests its own first group, unused): under a branch the compiler's
                         // wait counts merge both paths and every wait below becomes "all loads done"
-                        const int jn = jc + 2 * MG < n ? jc + 2 * MG : jc;
+                        const int jn = jc + 2 * MGc < n ? jc + 2 * MGc : jc;
 #pragma unroll
-                        for (int q = 0; q < MG; ++q)
-                            mga[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, (jn + q) * Np * 8, 0));
+                        for (int c = 0; c < MGc; ++c)
+#pragma unroll
+                            for (int q = 0; q < NG; ++q)
+                                mga[c][q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs[q], l8, (jn + c) * Np * 8, 0));
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int q = 0; q < MG; ++q) { column(jc + MG + q, mgb[q]); if (q % ILPW == ILPW - 1) __builtin_amdgcn_sched_barrier(0); }
+                    for (int c = 0; c < MGc; c += KC) batch(jc + MGc + c, &mgb[c]);
                 }
-                // per-lane combination into the m-moments of this row block (pair_kernel_sb.h), summed over the row blocks of the GP
-                {
-                    const double rs = acc[0];
-                    zsum[0] += rs;
+                // per-ln combination into the m-moments of this (unit, row block) segment (pair_kernel_sb.h), reduced over rows of 16
+                // lanes and added to the wave's slot of the unit: segments in program order, rows as (0 + 1) + (2 + 3) in the combine
+#pragma unroll
+                for (int q = 0; q < NG; ++q) {
+                    const double rs = acc[q][0];
+                    double* sp = &s_part[(((w * 2 + slot) * NG + q) * 4 + (ln >> 4)) * NM];
+                    // one moment at a time (nothing held): row sum over 16 lanes, then ds_add_f64 by the row's first lane -- same lane,
+                    // program order: the slot sums its segments in a fixed order
+                    auto add = [&](int m, double v) {
+                        const double sr = wave_row_sum(v);
+                        if ((ln & 15) == 0) __hip_atomic_fetch_add(&sp[m], sr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    };
+                    add(0, rs);
                     if (GRAD) {
 #pragma unroll
                         for (int k = 0; k < D; ++k) {
-                            const double h = (0.5 / GPMPC_EXP_NEG_INV_C) * hi2[k], v = acc[GRAD ? 1 + k : 0];
-                            zsum[GRAD ? 1 + k : 0] += fma(h, rs, v);
-                            if (k < NS2) zsum[GRAD ? 1 + D + k : 0] += fma(h * h, rs, fma(2.0 * h, v, acc[GRAD ? 1 + D + (k < NS2 ? k : 0) : 0]));
+                            const double h = (0.5 / GPMPC_EXP_NEG_INV_C) * hi2[k], v = acc[q][GRAD ? 1 + k : 0];
+                            add(GRAD ? 1 + k : 0, fma(h, rs, v));
+                            if (k < NS2) add(GRAD ? 1 + D + k : 0, fma(h * h, rs, fma(2.0 * h, v, acc[q][GRAD ? 1 + D + (k < NS2 ? k : 0) : 0])));
                         }
                     }
                 }
@@ -462,7 +401,6 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
 #if GPMPC_PERSIST_ROTPRIO
             __builtin_amdgcn_s_setprio(0);
 #endif
-            if (r_lo < r_hi) flush(slot);
             GPMPC_PSTW(48);
         }
         GPMPC_PST(7);
@@ -523,10 +461,10 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
         GPMPC_PST(9);
         GPMPC_LDS_BARRIER();                                           // every reader of s_uin / s_sin of step t is done
         GPMPC_PST(10);
-        if (tid < DS) {
-            const double mu = s_cm[tid] * s_ms[tid * NV];
-            s_uin[tid] = mu;
-            s_sin[tid] = s_sf2[tid] - s_c[tid] * s_z[tid * NM] - mu * mu;
+        if (tiz < DS) {
+            const double mu = s_cm[tiz] * s_ms[tiz * NV];
+            s_uin[tiz] = mu;
+            s_sin[tiz] = s_sf2[tiz] - s_c[tiz] * s_z[tiz * NM] - mu * mu;
         }
     }
 }
@@ -535,13 +473,23 @@ template <int D, int NS2, bool GRAD, int NG = 1>
 static int launch_persist_one(const PersistArgs& a, int waves, hipStream_t s) {
     const size_t lds = sizeof(double) * ((size_t)D * a.Np + (size_t)a.H * (D - NS2));
     if (a.Np > GPMPC_PERSIST_MAXNP || a.Np % 64 != 0 || (waves != 8 && waves != 16) || a.H * (D - NS2) > 2 * 512) return GPMPC_E_ARG;
-    if (lds > 32 * 1024) {                         // static + dynamic LDS beyond the default 64 KB of a launch: opt in (160 KB per CU on gfx950)
-        static bool raised = false;                 // (per instance; a benign race: the attribute is idempotent)
-        if (!raised) {
-            if (hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_traj_persist<D, NS2, GRAD, NG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * (D * GPMPC_PERSIST_MAXNP + 2 * 512)));
+    // static + dynamic LDS beyond the default 64 KB of a launch needs an opt-in (160 KB per CU on gfx950).  The attribute belongs to the
+    // function object of the CURRENT device: tracked per device, and the bound uses the instance's own static LDS (NG = 2 / GRAD
+    // instances carry ~36 KB of it) -- a shape that cannot fit is refused here, not at the launch.
+    {
+        static int static_lds[GPMPC_PERSIST_MAXDEV];           // 0: not asked yet on that device; else static LDS bytes + 1
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= GPMPC_PERSIST_MAXDEV) return GPMPC_E_DEVICE;
+        const void* fn = reinterpret_cast<const void*>(&k_traj_persist<D, NS2, GRAD, NG>);
+        if (!static_lds[dev]) {                                // (a benign race: both writers store the same value)
+            hipFuncAttributes fa;
+            if (hipError_t ea = hipFuncGetAttributes(&fa, fn); ea != hipSuccess) { gpmpc_set_error("trajectory-persistent kernel: attributes", ea); return GPMPC_E_LAUNCH; }
+            const int dyn_max = 160 * 1024 - (int)fa.sharedSizeBytes;
+            if (hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, dyn_max);
                 ea != hipSuccess) { gpmpc_set_error("trajectory-persistent kernel: LDS attribute", ea); return GPMPC_E_LAUNCH; }
-            raised = true;
+            static_lds[dev] = (int)fa.sharedSizeBytes + 1;
         }
+        if (lds + (size_t)(static_lds[dev] - 1) > 160 * 1024) return GPMPC_E_ARG;
     }
     hipLaunchKernelGGL((k_traj_persist<D, NS2, GRAD, NG>), dim3(a.B), dim3(64 * waves), lds, s, a);
     hipError_t e = hipGetLastError();

@@ -218,9 +218,16 @@ class GaussianProcessRegression(object):
         return "incremental" if inc else "full"
 
     def _adopt(self, other):
-        """Share the matrices of `other`, a GP with bit-identical training inputs and hyper-parameters (the tensors are
-        never modified in place: every update assigns new ones)."""
+        """Share the matrices of `other`, a GP with bit-identical training inputs and hyper-parameters.  Invariant for sharers
+        (src/gpr.py:159-171 assigns fresh tensors on every update): a matrix a GP holds is never modified under it.  The
+        incremental append writes into two REUSED capacity-padded buffer sets, so the leader keeps weak references to the GPs
+        that hold views of them and, before it overwrites a set that one of them still aliases -- a leader fed on its own through
+        the public ``append_train_data`` instead of ``update_many`` --, gives that GP its own copies
+        (`_append_one_incremental`); user code that keeps ``gp.Ky_inv`` across TWO later appends must clone it itself."""
+        import weakref
         self.Kf, self.Ky, self.Ky_inv = other.Kf, other.Ky, other.Ky_inv
+        sh = other.__dict__.setdefault("_sharers", weakref.WeakSet())
+        sh.add(self)
         self._beta = None
         self.version += 1
         self._built_hypers = other._built_hypers
@@ -304,6 +311,16 @@ class GaussianProcessRegression(object):
             if any(d.untyped_storage().data_ptr() in base for d in dst):
                 raise RuntimeError("incremental append: both buffer sets alias the current matrices")
             self._cur = 1 - self._cur
+        # a GP that adopted views of the set about to be overwritten (and was not re-fed together with this one) keeps its
+        # n-point matrices: it gets copies first
+        targets = {d.untyped_storage().data_ptr() for d in dst}
+        for f in list(getattr(self, "_sharers", ())):
+            if f is self:
+                continue
+            for name in ("Kf", "Ky", "Ky_inv"):
+                t = getattr(f, name)
+                if t is not None and t.untyped_storage().data_ptr() in targets:
+                    setattr(f, name, t.clone())
         X_old = self.X_train[:n]
         if not X_old.is_contiguous():
             X_old = X_old.contiguous()

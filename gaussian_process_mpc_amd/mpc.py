@@ -10,6 +10,10 @@ forced by moving the rollout into one fused HIP call:
 * ``objective_batch`` / ``evaluate_batch`` evaluate many candidate action sequences at once (the
   trajectory-sharded batch the multi-GPU path consumes) -- an extension, the reference has no batch API.
 * ``gamma == 0`` is accepted and means the analytic risk-neutral limit.
+* ``get_optimal_trajectory(curr_state, n_starts=K)`` (or ``mpc.n_starts = K``) with K > 1 runs K bounded quasi-Newton searches in
+  lock-step (multistart.py): every solver iteration is ONE ``evaluate_batch`` call of K candidate plans -- sharded over the
+  ranks when ``torch.distributed`` is initialised -- and the best local optimum is returned.  ``n_starts = 1`` (the default)
+  is the reference's single zero-start solve (src/mpc.py:292-326).
 """
 import numpy as np
 import torch
@@ -57,6 +61,11 @@ class RiskSensitiveMPC:
         self.lb = [-1e16 for _ in range(self.input_dim)]
         self.train_empty = True
         self.solver_used = None
+        # lock-step multi-start solve (extension; multistart.py): K starts, tick budget, seed of the sampled starts
+        self.n_starts = 1
+        self.multistart_options = {"max_ticks": 150, "history": 8, "gtol": 1e-4, "ftol": 1e-10, "spread": 1.0, "seed": 0, "warm": True}
+        self.last_solve_info = None
+        self._solve_count = 0
 
     # -- setters (src/mpc.py:72-116)
     def set_ub(self, ub):
@@ -182,7 +191,7 @@ class RiskSensitiveMPC:
         return r["cost"].cpu().numpy(), r["grad"].cpu().numpy()
 
     # -- solve (src/mpc.py:269-330)
-    def get_optimal_trajectory(self, curr_state):
+    def get_optimal_trajectory(self, curr_state, n_starts=None):
         if self.train_empty:
             if self.dynamics.gpr_err[0].num_train > 0:
                 self.train_empty = False
@@ -192,6 +201,11 @@ class RiskSensitiveMPC:
         self._cache_key = None
         x0 = np.zeros(shape=len(self.last_traj))          # warm start deliberately off, src/mpc.py:292-293
         lb, ub = self.horizon * list(self.lb), self.horizon * list(self.ub)
+        K = self.n_starts if n_starts is None else n_starts
+        if K > 1:
+            x = self._solve_multistart(K, lb, ub)
+            self.last_traj = x
+            return np.reshape(x, (self.horizon, self.input_dim))
         if HAVE_CYIPOPT:
             nlp = cyipopt.Problem(n=len(x0), m=0, problem_obj=self, lb=lb, ub=ub, cl=[0], cu=[0])
             for k, v in (("mu_strategy", "adaptive"), ("accept_every_trial_step", "yes"), ("max_iter", 300),
@@ -216,3 +230,50 @@ class RiskSensitiveMPC:
                        method="L-BFGS-B", bounds=bounds, options={"maxiter": 300, "ftol": 1e-10, "gtol": 1e-4})
         self.solver_used = "scipy-lbfgsb"
         return res.x
+
+    def _solve_multistart(self, K, lb, ub):
+        """K starts advanced together (multistart.lockstep_lbfgs): one batched rollout of K plans per solver iteration, replayed as
+        one hipGraph; with torch.distributed initialised the K plans are sharded over the ranks (parallel.sharded_rollout) and every
+        rank takes the same decisions from the same gathered [cost | grad].  Optimiser results unpinned, like the Ipopt stand-in."""
+        from .multistart import lockstep_lbfgs, make_starts
+        opt = self.multistart_options
+        n, H, da = self.horizon * self.input_dim, self.horizon, self.input_dim
+        pack, cp, cs = self.dynamics.pack(), self._cost_params(), self.curr_state
+        warm = None
+        if opt.get("warm", True) and self.solver_used is not None:        # the previous plan shifted by one step, last input repeated
+            prev = np.asarray(self.last_traj, dtype=np.float64).reshape(H, da)
+            warm = np.concatenate((prev[1:], prev[-1:]), axis=0).reshape(-1)
+        rng = np.random.default_rng([int(opt.get("seed", 0)), self._solve_count])
+        self._solve_count += 1
+        X0 = make_starts(K, n, lb, ub, rng, warm=warm, spread=float(opt.get("spread", 1.0)))
+        dist = None
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            dist = torch.distributed
+
+        def run(x0b, Ub, graph):
+            if self.full_covariance:
+                return rollout_fullcov(pack, x0b, Ub, cp, want_grad=True)
+            return rollout(pack, x0b, Ub, cp, want_grad=True, want_traj=False, graph=graph)
+
+        def evaluate(X):
+            U = np.ascontiguousarray(X.reshape(K, H, da))
+            if dist is not None:
+                from .parallel import sharded_rollout
+                Ud = torch.as_tensor(U, device=self.device)
+                c, g = sharded_rollout(lambda x0b, Ub: run(x0b, Ub, False), cs, Ud, dist)
+                return c.cpu().numpy(), g.cpu().numpy().reshape(K, n)
+            r = run(cs, U, True)
+            if "cost_grad" in r:                                          # cost and gradient in ONE device-to-host copy
+                cg = r["cost_grad"].cpu().numpy()
+                return cg[:K], cg[K:].reshape(K, n)
+            return r["cost"].cpu().numpy(), r["grad"].cpu().numpy().reshape(K, n)
+
+        x, info = lockstep_lbfgs(evaluate, X0, np.asarray(lb, dtype=np.float64), np.asarray(ub, dtype=np.float64),
+                                 max_ticks=int(opt.get("max_ticks", 150)), history=int(opt.get("history", 8)),
+                                 gtol=float(opt.get("gtol", 1e-4)), ftol=float(opt.get("ftol", 1e-10)))
+        info["starts"] = K
+        info["sharded_over"] = dist.get_world_size() if dist is not None else 1
+        self.last_solve_info = info
+        self.solver_used = f"lockstep-lbfgs x{K}"
+        self._cache_key = None
+        return x

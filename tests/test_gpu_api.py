@@ -292,6 +292,45 @@ def test_closed_loop_simulator(G):
     assert all(np.isfinite(h[2]) for h in hist) and all(abs(h[1][0]) <= 2.0 + 1e-9 for h in hist)
 
 
+def test_closed_loop_simulator_multistart(G):
+    """get_optimal_trajectory(n_starts = 16) (multistart.py; the solve of src/mpc.py:269-330 with K starts advanced in lock-step):
+    every solver iteration is ONE batched rollout of 16 candidate plans; the plan returned costs no more than the single-start
+    plan from the same state on the same seeds (start 0 IS the single start's zero start), and Simulator.run works unchanged.
+    Optimiser results are unpinned (no Ipopt in the image); the bound is against this build's own single-start solve."""
+    rng = np.random.default_rng(3)
+    S = np.stack((rng.uniform(-1, 1, 40), rng.uniform(-2, 2, 40)), axis=1)
+    A = rng.uniform(-2, 2, (40, 1))
+    nxt = np.array([G.PendulumPlant(init_state=s).step(a)[0] for s, a in zip(S, A)])
+
+    def make():
+        mpc = G.RiskSensitiveMPC(-1.0, 5, 2, 1, 0.5 * np.eye(2), 0.01 * np.eye(1))
+        for g in mpc.dynamics.gpr_err:
+            g.set_lambdas(np.array([1.0, 4.0, 4.0]))
+            g.set_sigma_n(np.array(1e-2))
+        mpc.dynamics.append_train_data(S, A, nxt)
+        mpc.set_lb([-2.0]); mpc.set_ub([2.0])
+        return mpc
+    m1, m16 = make(), make()
+    for state in ((0.3, 0.0), (-0.6, 1.2), (0.9, -1.5)):
+        u1 = m1.get_optimal_trajectory(np.array(state))
+        c1 = m1.objective(u1.reshape(-1))
+        u16 = m16.get_optimal_trajectory(np.array(state), n_starts=16)
+        info = m16.last_solve_info
+        c16 = m16.objective(u16.reshape(-1))
+        assert m16.solver_used == "lockstep-lbfgs x16" and info["starts"] == 16 and info["alive"][0]
+        assert info["evaluations"] == info["ticks"] + 1 <= m16.multistart_options["max_ticks"] + 1
+        np.testing.assert_allclose(c16, info["f"].min(), rtol=1e-9)          # the reported best IS the plan returned
+        assert np.all(np.abs(u16) <= 2.0 + 1e-12)
+        assert c16 <= c1 + 1e-6 * max(1.0, abs(c1)), (state, c16, c1)
+        # the batched evaluation the search consumed equals the solver-callback entry, start by start
+        cb, gb = m16.objective_batch(info["x"].reshape(16, 5, 1), curr_state=m16.curr_state)
+        for k in (0, 7, 15):
+            np.testing.assert_allclose(cb[k], m16.objective(info["x"][k]), rtol=1e-9)
+    m16.n_starts = 16
+    hist = G.Simulator(m16, G.PendulumPlant(init_state=(0.3, 0.0)), num_iters=3).run()
+    assert len(hist) == 3 and m16.dynamics.gpr_err[0].num_train == 43 and all(abs(h[1][0]) <= 2.0 + 1e-9 for h in hist)
+
+
 def test_integration_md_stub_runs_verbatim(G, golden, monkeypatch):
     """INTEGRATION.md section B documents the ctypes binding a maintainer of the reference would add.  Extract that code
     block from the file and execute it AS WRITTEN (only GPMPC_LIB points it at the in-tree library), with the mirror's
@@ -428,6 +467,33 @@ def test_incremental_append_drift_and_hyper_change(G):
     new.append_train_data(np.vstack((X, [[0.1, 0.2, 0.3]])), np.append(y, 0.5))
     assert inc._appends_since_rebuild == 0
     assert torch.equal(inc.Ky, new.Ky) and torch.equal(inc.Ky_inv, new.Ky_inv)
+
+
+def test_gps_that_shared_matrices_and_are_then_fed_separately(G):
+    """Two GPs with identical hyper-parameters fed through Dynamics share ONE set of matrices (update_many / _adopt); the leader's
+    incremental append writes into two REUSED buffer sets.  Feeding the leader ON ITS OWN twice afterwards (public
+    append_train_data) must not change what the follower holds: its n-point inverse stays the n-point inverse
+    (src/gpr.py:159-171 assigns fresh tensors on every update, so in the reference nothing is ever modified under a holder)."""
+    rng = np.random.default_rng(5)
+    dyn = G.Dynamics(2, 1)
+    for gp in dyn.gpr_err:
+        gp.set_lambdas(np.array([1.0, 2.0, 3.0])); gp.set_sigma_n(np.array(1e-2))
+    S, A = rng.uniform(-1, 1, (30, 2)), rng.uniform(-1, 1, (30, 1))
+    dyn.append_train_data(S, A, S + 0.1 * np.tanh(S))
+    for _ in range(3):                                       # incremental: the GPs now hold views of the leader's ping-pong buffers
+        s, a = rng.uniform(-1, 1, 2), rng.uniform(-1, 1, 1)
+        dyn.append_train_data(s, a, s + 0.1 * np.tanh(s), incremental=True)
+    lead, foll = dyn.gpr_err
+    assert foll.Ky_inv.untyped_storage().data_ptr() == lead.Ky_inv.untyped_storage().data_ptr()      # shared
+    held = {k: getattr(foll, k).clone() for k in ("Kf", "Ky", "Ky_inv")}
+    for _ in range(3):                                       # the leader alone: every buffer set gets rewritten
+        x = rng.uniform(-1, 1, 3)
+        lead.append_train_data(x, float(np.sin(x).sum()), incremental=True)
+    assert lead.num_train == 36 and foll.num_train == 33 and foll.Ky_inv.shape == (33, 33)
+    for k, v in held.items():
+        assert torch.equal(getattr(foll, k), v), k
+    f, _ = foll.predict_latent_vars(np.concatenate((S[:5], A[:5]), axis=1))
+    assert np.all(np.isfinite(f))
 
 
 # ---- hyper-parameter training (SURVEY 8f-4): src/gpr.py:173-251, 334-370 -------------------------------------------

@@ -283,3 +283,146 @@ def test_plants_match_the_reference_environments(golden):
     assert np.array_equal(np.array(states), z["pd_chain"])
     np.testing.assert_allclose(rewards, z["pd_chain_reward"], rtol=1e-15)
     assert np.array_equal(PendulumPlant.step_static(z["pd_chain"][3], z["pd_chain_actions"][3], pd.options()), z["pd_chain"][4])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# round 5: lock-step multi-start driver (host logic; the GPU variant is tests/test_gpu_api.py::test_closed_loop_simulator_multistart)
+# ------------------------------------------------------------------------------------------------------------------
+def _rosen_batch(X):
+    f = np.sum(100 * (X[:, 1:] - X[:, :-1] ** 2) ** 2 + (1 - X[:, :-1]) ** 2, axis=1)
+    g = np.zeros_like(X)
+    g[:, :-1] += -400 * X[:, :-1] * (X[:, 1:] - X[:, :-1] ** 2) - 2 * (1 - X[:, :-1])
+    g[:, 1:] += 200 * (X[:, 1:] - X[:, :-1] ** 2)
+    return f, g
+
+
+def test_lockstep_multistart_reaches_the_bounded_optima_scipy_finds():
+    """K projected L-BFGS searches advanced together, ONE batched evaluation per tick (multistart.py: the consumer of the
+    trajectory batch inside a solve, src/mpc.py:269-330): on a bounded Rosenbrock every start ends where scipy's L-BFGS-B ends from
+    the same point; evaluations = ticks + 1 (never one call per start); a region that returns NaN (the risk-sensitive cost's
+    log det of a non-positive matrix, src/mpc.py:183) rejects trial points and drops starts that begin inside it."""
+    from scipy.optimize import minimize
+    from gaussian_process_mpc_amd.multistart import lockstep_lbfgs, make_starts
+    n = 8
+    lb, ub = -2 * np.ones(n), 0.8 * np.ones(n)
+    X0 = make_starts(12, n, lb, ub, np.random.default_rng(1), warm=np.full(n, 0.5))
+    assert np.array_equal(X0[0], np.zeros(n)) and np.array_equal(X0[1], np.full(n, 0.5)) and (X0 >= lb).all() and (X0 <= ub).all()
+    calls = []
+
+    def ev(X):
+        calls.append(X.shape)
+        return _rosen_batch(X)
+    x, info = lockstep_lbfgs(ev, X0, lb, ub, max_ticks=2000, gtol=1e-6)
+    assert info["converged"].all() and len(calls) == info["evaluations"] == info["ticks"] + 1
+    assert all(c == (12, n) for c in calls)
+    for k in (0, 1, 5):
+        r = minimize(lambda v: _rosen_batch(v[None])[0][0], X0[k], jac=lambda v: _rosen_batch(v[None])[1][0], method="L-BFGS-B",
+                     bounds=list(zip(lb, ub)), options={"gtol": 1e-6, "ftol": 1e-14})
+        assert abs(info["f"][k] - r.fun) <= 1e-6 * max(1.0, abs(r.fun))
+    assert np.isclose(_rosen_batch(x[None])[0][0], info["f"].min()) and (x <= ub + 1e-15).all()
+    x2, info2 = lockstep_lbfgs(_rosen_batch, X0, lb, ub, max_ticks=2000, gtol=1e-6)      # deterministic: same bits
+    assert np.array_equal(x, x2) and np.array_equal(info["f"], info2["f"])
+
+    def with_nan(X):
+        f, g = np.sum((X - 0.3) ** 2, axis=1), 2 * (X - 0.3)
+        return np.where(X[:, 0] > 0.9, np.nan, f), g
+    x, info = lockstep_lbfgs(with_nan, np.array([[0.95, 0, 0], [0.0, 0, 0], [-1, 1, 1.0]]), -np.ones(3), np.ones(3))
+    assert list(info["alive"]) == [False, True, True] and np.allclose(x, 0.3) and info["best"] in (1, 2)
+
+
+def _gloo_multistart_worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from gaussian_process_mpc_amd.multistart import lockstep_lbfgs, make_starts
+    from gaussian_process_mpc_amd.parallel import sharded_rollout
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    K, H, da = 5, 4, 2                                   # ragged: 3 + 2 starts
+    n = H * da
+    lb, ub = -2 * np.ones(n), 0.8 * np.ones(n)
+    X0 = make_starts(K, n, lb, ub, np.random.default_rng(7))
+    blocks = []
+
+    def fake_rollout(x0b, Ub):                            # stands in for the device rollout of this rank's block of plans
+        blocks.append(Ub.shape[0])
+        f, g = _rosen_batch(Ub.reshape(Ub.shape[0], n).numpy())
+        return {"cost": torch.as_tensor(f), "grad": torch.as_tensor(g).reshape(-1, H, da)}
+
+    def evaluate(X):
+        c, g = sharded_rollout(fake_rollout, torch.zeros(3), torch.as_tensor(X.reshape(K, H, da)), dist)
+        return c.numpy(), g.numpy().reshape(K, n)
+    x, info = lockstep_lbfgs(evaluate, X0, lb, ub, max_ticks=1500, gtol=1e-6)
+    xs, infos = lockstep_lbfgs(_rosen_batch, X0, lb, ub, max_ticks=1500, gtol=1e-6)          # the same solve in one process
+    ok = bool(np.array_equal(x, xs) and np.array_equal(info["f"], infos["f"]) and info["ticks"] == infos["ticks"]
+              and set(blocks) == {3 if rank == 0 else 2})
+    q.put((rank, ok, x.tobytes()))
+    dist.destroy_process_group()
+
+
+def test_lockstep_multistart_sharded_over_two_gloo_ranks():
+    """The sharded variant of the multi-start solve (RiskSensitiveMPC._solve_multistart with torch.distributed initialised): each rank
+    evaluates ITS block of the K trial plans, one fused all_gather returns every [cost | grad] to every rank, and both ranks run
+    the same deterministic host loop -- identical plans on both ranks, bit-equal to the single-process solve."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 400) + 170
+    procs = [ctx.Process(target=_gloo_multistart_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert [(r, ok) for r, ok, _ in res] == [(0, True), (1, True)] and res[0][2] == res[1][2]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# round 5: build-time spill guard, compact bench record
+# ------------------------------------------------------------------------------------------------------------------
+def test_spill_guard_passes_on_the_shipped_build_and_fails_on_a_new_spill(built, tmp_path):
+    """`make check` (tools/spill_guard.py over the <object>.res files the build writes): every shipped kernel within its VGPR-spill /
+    scratch budget -- the whole-horizon instances for D <= 7 at ZERO spills --, and a kernel that starts to spill fails the check."""
+    import subprocess
+    build = os.path.join(PKG, "csrc", "build")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "spill_guard.py"), build, "--all"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rows = [ln for ln in r.stdout.splitlines() if ln.startswith("k_traj_persist<")]
+    assert len(rows) >= 40
+    for ln in rows:
+        if not re.match(r"k_traj_persist<8, ", ln):
+            assert " spill v  0 " in ln and ln.rstrip().endswith(" ok"), ln
+    bad = tmp_path / "b"
+    bad.mkdir()
+    (bad / "x.o.res").write_text(
+        "f.h:1:1: remark: Function Name: _Z14k_traj_persistILi5ELi4ELb1ELi1EEv11PersistArgs [-Rpass-analysis=kernel-resource-usage]\n"
+        "f.h:1:1: remark:     VGPRs: 128 [-Rpass-analysis=kernel-resource-usage]\n"
+        "f.h:1:1: remark:     ScratchSize [bytes/lane]: 48 [-Rpass-analysis=kernel-resource-usage]\n"
+        "f.h:1:1: remark:     VGPRs Spill: 11 [-Rpass-analysis=kernel-resource-usage]\n")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "spill_guard.py"), str(bad)], capture_output=True, text=True)
+    assert r.returncode == 1 and "OVER BUDGET" in r.stderr
+
+
+def test_bench_stdout_record_is_compact():
+    """The driver keeps an 8 KB tail of stdout: the default line (headline + roofline + cpu_baseline + every leg) must fit in 6 KB,
+    each leg in ~250 bytes with value / ms_per_step / kernel / bound / frac / avg_launch_ms."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04", "bench_C3.json")))      # a full record of the previous format
+    legs = {}
+    for name, _ in bench.LEGS:
+        legs[name] = {"value": 12345.678, "unit": "rollouts/s", "ms_per_step": 1.2345678, "kernel": "gpmpc_pair_kernel_sbs<5,4,4,true,false>",
+                      "bound": "valu_fp64", "frac": 0.5021, "avg_launch_ms": 1.30712}
+    full["extras"] = legs
+    full["extras_full"] = {"x": "y" * 5000}
+    line = json.dumps(bench.compact_record(full), separators=(",", ":"))
+    assert len(line) < 6000, len(line)
+    d = json.loads(line)
+    assert "extras_full" not in d and set(d["extras"]) == {n for n, _ in bench.LEGS}
+    assert all(len(json.dumps(v, separators=(",", ":"))) <= 250 for v in d["extras"].values())
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in d["cpu_baseline"]
+    assert bench.short_kernel("k_step_fused<5,4,true,32,1> (one launch per horizon step: ...)") == "k_step_fused<5,4,true,32,1>"

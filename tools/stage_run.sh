@@ -17,7 +17,10 @@ find .stage/$NAME -name __pycache__ -prune -exec rm -rf {} + 2>/dev/null || true
 ln -s ../../gpurun_out .stage/$NAME/gpurun_out
 ln -s gaussian_process_mpc_amd ".stage/$NAME/gaussian-process-mpc_amd" 2>/dev/null || true
 # only the newest stage travels: drop the others (finished jobs)
-for d in .stage/*; do [ "$d" != ".stage/$NAME" ] && [ -z "$(/usr/local/graft/bin/gpurun --status 2>/dev/null | grep '"in_flight": 1')" ] && rm -rf "$d"; done
+# (only when gpurun reports NO call queued or in flight: a job launched earlier still needs its own stage)
+if ! /usr/local/graft/bin/gpurun --status 2>/dev/null | grep -Eq '"in_flight": *[1-9]'; then
+    for d in .stage/*; do [ "$d" != ".stage/$NAME" ] && rm -rf "$d"; done
+fi
 CMD="cd .stage/$NAME && $*"
 ( timeout $((TMO + 1500)) /usr/local/graft/bin/gpurun --timeout $TMO -- "$CMD" > gpurun_out/$NAME.log 2>&1 & )
 echo "launched $NAME: $CMD"
