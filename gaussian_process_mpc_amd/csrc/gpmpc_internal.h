@@ -123,6 +123,7 @@ struct PairSbArgs {
     int rgroup;           // work items interleaved per trajectory in dispatch order (1 = item-major), see pair_kernel_sb.h
     int first_step;       // horizon step 1: derivatives w.r.t. the (constant) state inputs are not needed
     int colunroll;        // 4: four columns per loop iteration (the 256x64 tiling of mid-size batches, TB = 1); else one
+    const int* ncol;      // device: columns that carry weight (N rounded up to 8, <= Np; gpmpc_pack::ncol_dev): the column loop ends there
 };
 static inline int gpmpc_sb_gw(int D, int ns2) { return (D + 1 + ns2 + 1) & ~1; }
 int gpmpc_launch_pair_sb(int D, bool grad, int tb, int ns2, int waves, const PairSbArgs& a, hipStream_t s);
@@ -154,6 +155,7 @@ struct PairSbsArgs {
     const int* work;      // [nwork][4] = {GP group, i0, j0, tile index within a GP}
     int Np, B, ds, nwork, tiles, jt, pps, nm;
     int rgroup, first_step;
+    const int* ncol;      // as PairSbArgs
 };
 // GPs per workgroup of the shared-lambda kernel: as many as keep the accumulators (NG x (1 + D + ds) doubles) within ~48,
 // then balanced over the groups.
@@ -185,6 +187,7 @@ struct FusedArgs {
     double* gscr;                          // mid-size form (q = 0 / 32 / 16): [B][ntile][columns][gw] column rows, one slot per tile workgroup
     int ntile;                             // tile workgroups per trajectory (= nwork, except with one lambda for all GPs: groups x tiles)
     int tiles;                             // one lambda for all GPs: tiles per GP (partial sums are laid out [GP][tile], nwork = ds * tiles)
+    const int* ncol;                       // device: columns that carry weight (N rounded up to 8, <= Np; gpmpc_pack::ncol_dev): tile column loops end there
 };
 template <int D> int gpmpc_launch_step_fused_D(bool grad, int ns2, int q, int ng, const FusedArgs& a, int t, hipStream_t s);
 

@@ -91,7 +91,11 @@ __global__ __launch_bounds__(256, (TB == 2 && D <= 5) ? GPMPC_SB_TB2_WAVES : 1) 
             wi = ((t / groups) * R + ir) * 8 + (L & 7);
         } else { const int Lt = L - full * groups; wi = full + Lt / groups; bg = Lt % groups; }
     }
-    const int unit = A.work[wi * 4 + 0], i0 = A.work[wi * 4 + 1], j0 = A.work[wi * 4 + 2], j1 = A.work[wi * 4 + 3];
+    const int unit = A.work[wi * 4 + 0], i0 = A.work[wi * 4 + 1], j0 = A.work[wi * 4 + 2], j1w = A.work[wi * 4 + 3];
+    // columns >= N carry zero weight: the tile's column loop ends at N rounded up to 8 (round 5; read from the pack in device memory, so a
+    // captured launch stays valid while the training set grows within its padded size) -- N = 200: 56 of the 256 columns of a row
+    const int ncw = *(const int __attribute__((address_space(4)))*)A.ncol;
+    const int j1 = j1w < ncw ? j1w : ncw;
     const int tid = threadIdx.x, lane = tid & 63;
     // the wave index is uniform across the wave: tell the compiler, so that everything indexed by the column loop
     // below is provably wave-uniform and the G rows are fetched by scalar loads

@@ -56,7 +56,8 @@ void gpmpc_pair_kernel_sbs(PairSbsArgs A) {
     }
     const int grp = A.work[wi * 4 + 0], i0 = A.work[wi * 4 + 1], j0 = A.work[wi * 4 + 2], tile = A.work[wi * 4 + 3];
     const int Np = A.Np;
-    const int j1 = j0 + A.jt < Np ? j0 + A.jt : Np;
+    const int ncw = *(const int __attribute__((address_space(4)))*)A.ncol;      // columns that carry weight (N rounded up to 8): pair_kernel_sb.h
+    const int j1 = j0 + A.jt < ncw ? j0 + A.jt : ncw;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int iw0 = i0 + w * 64;                          // first row of this wave (wave-uniform)

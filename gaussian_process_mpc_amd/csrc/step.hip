@@ -888,11 +888,21 @@ struct RollPlan { int tiling, tb, waves, nwork, nm, pps, sps, sb, gw, rgroup, fu
 #define GPMPC_TUNED_SLOTS 16
 struct gpmpc_tuned_entry { int B, H, grad, graph, S, valid; RollPlan plan; double ms_default, ms_best; };
 struct gpmpc_tuned_table { gpmpc_tuned_entry e[GPMPC_TUNED_SLOTS]; int next; };
+// How the calling entry point will launch (captured graph replay = 1, plain launches = 0, unknown = -1): a plan and split count
+// measured as graph replays -- launch overhead hidden, up to four parallel branches -- must not be applied to eager calls of the same
+// shape, nor the reverse.  Set by the entry points for the duration of their planning (thread-local: the library is re-entrant).
+static thread_local int tl_graph_mode = -1;
+struct GraphModeGuard {
+    int prev;
+    explicit GraphModeGuard(int m) : prev(tl_graph_mode) { tl_graph_mode = m; }
+    ~GraphModeGuard() { tl_graph_mode = prev; }
+};
 static const gpmpc_tuned_entry* tuned_lookup(const gpmpc_pack* p, int B, int H, bool grad) {
     const gpmpc_tuned_table* t = (const gpmpc_tuned_table*)p->tuned;
     if (!t) return nullptr;
     for (int k = 0; k < GPMPC_TUNED_SLOTS; ++k)
-        if (t->e[k].valid && t->e[k].B == B && t->e[k].H == H && t->e[k].grad == (grad ? 1 : 0)) return &t->e[k];
+        if (t->e[k].valid && t->e[k].B == B && t->e[k].H == H && t->e[k].grad == (grad ? 1 : 0) &&
+            (tl_graph_mode < 0 || t->e[k].graph == tl_graph_mode)) return &t->e[k];
     return nullptr;
 }
 void gpmpc_tuned_free(void* t) { free(t); }
@@ -1097,13 +1107,16 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
         // N = 512, ds = 3, H = 20 1.94 | 2.06 (not taken: up to Np = 448 with one lambda).  D = 7 loses with distinct lambdas too
         // (N = 300, ds = 6: 2.19 | 2.32; ds = 5, da = 2: 1.69 | 1.98 -- the accumulators leave the column loop one chain and two loads in
         // flight): taken up to D = 6.
+        // an explicit kernel-form override (GPMPC_FUSED=0, GPMPC_PAIR_SB, GPMPC_TILING, GPMPC_FUSED_SB) asks for a step-per-launch form: an A/B
+        // with those variables must not silently run this kernel instead (GPMPC_PERSIST=8|16 still forces it)
+        const bool form_forced = tn.fused == 0 || tn.pair_sb >= 0 || tn.tiling >= 0 || tn.fused_sb >= 0;
         const bool pshared = shared_on && p->ds >= 2 && D >= 3 && D <= 6;
         const bool shared_ahead = shared_on && !pshared && p->ds >= 3;
         r->png = 1;
         // (never for the sub-batches of a split call: they run the launches of the WHOLE batch's plan -- a sub-batch that happened to fit
         // this kernel used to come back with this branch's work-list fields and the whole batch's form: an empty grid)
         if (!shape && diag && !lowprec && p->da >= 1 && p->da <= 2 && p->Np <= GPMPC_PERSIST_MAXNP_HOST && H * p->da <= 1024 && tn.persist != 0 &&
-            pw && (tn.persist > 0 || (p->Np <= (pshared ? 448 : 512) && D <= 6 && !shared_ahead))) {
+            pw && (tn.persist > 0 || (p->Np <= (pshared ? 448 : 512) && D <= 6 && !shared_ahead && !form_forced))) {
             r->fused = 3; r->sb = 0; r->shared = 0; r->tb = 1; r->rgroup = 1; r->colunroll = 1; r->fq = 1;
             r->pwaves = pw;
             r->png = pshared ? 2 : 1;
@@ -1205,6 +1218,7 @@ extern "C" size_t gpmpc_rollout_workspace_bytes(const gpmpc_pack* p, int B, int 
     if (!p || B < 1 || H < 1) return 0;
     RollPlan r;
     const bool grad = (flags & GPMPC_WANT_GRAD) != 0, lowprec = (flags & (GPMPC_FP32_ACCUM | GPMPC_FP32_ALL)) != 0;
+    GraphModeGuard mode((flags & GPMPC_USE_GRAPH) ? 1 : 0);
     plan_rollout(p, B, H, grad, true, &r, lowprec);
     size_t need = r.total;
     const int S = split_count(p, r, B, lowprec, false, 0, H, grad ? 1 : 0);     // mid-size batches run as S concurrent sub-batches, each with its own slice
@@ -1218,6 +1232,7 @@ extern "C" int gpmpc_plan_describe(const gpmpc_pack* p, int B, int H, unsigned f
     if (!p || !out || out_bytes < 64 || B < 1 || H < 1) return GPMPC_E_ARG;
     const bool grad = (flags & GPMPC_WANT_GRAD) != 0, lowprec = (flags & (GPMPC_FP32_ACCUM | GPMPC_FP32_ALL)) != 0;
     RollPlan r;
+    GraphModeGuard mode((flags & GPMPC_USE_GRAPH) ? 1 : 0);
     plan_rollout(p, B, H, grad, true, &r, lowprec);
     const int S = split_count(p, r, B, lowprec, (flags & GPMPC_USE_GRAPH) == 0, 0, H, grad ? 1 : 0);
     static const int cfg[7][2] = {{256, 256}, {64, 64}, {256, 64}, {64, 128}, {256, 128}, {256, 32}, {256, 16}};
@@ -1367,6 +1382,7 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
         F.sp = A.sp; F.part = A.part; F.partz = (double*)(ws + r.off_partz);
         F.sps = r.sps; F.nm = r.nm;
         F.gscr = r.fused == 2 ? (double*)(ws + r.off_G) : nullptr;
+        F.ncol = p->ncol_dev;
         for (int t = 1; t <= H; ++t) {
             const int rc = timed_launch(GPMPC_TIME_FUSED, s, [&] { return launch_step_fused(p->D, grad, p->ds, r.fused == 2 ? (r.tiling == 2 ? 0 : wl.jt) : r.fq, fsh ? r.fng : 1, F, t, s); });
             if (rc != GPMPC_OK) return rc;
@@ -1395,6 +1411,7 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
             Q.Np = p->Np; Q.B = B; Q.ds = p->ds; Q.nwork = wl.nwork; Q.tiles = p->sh_tiles[r.sh_list]; Q.jt = wl.jt;
             Q.pps = r.pps; Q.nm = r.nm; Q.rgroup = r.rgroup;
             Q.first_step = (t == 1 && !p->tune.no_first && !full_first) ? 1 : 0;
+            Q.ncol = p->ncol_dev;
             rc = gpmpc_timed_pair_sbs(p->D, grad, p->sh_ng, p->ds, Q, s);
         } else if (r.sb) {
             PairSbArgs Q;
@@ -1402,6 +1419,7 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
             Q.Np = p->Np; Q.B = B; Q.ds = p->ds; Q.nwork = r.nwork; Q.pps = r.pps; Q.nm = r.nm; Q.rgroup = r.rgroup;
             Q.first_step = (t == 1 && !p->tune.no_first && !full_first) ? 1 : 0;
             Q.colunroll = r.colunroll;
+            Q.ncol = p->ncol_dev;
             rc = gpmpc_timed_pair_sb(p->D, grad, r.tb, p->ds, r.waves, Q, s);
         } else {
             rc = gpmpc_timed_pair(p->D, true, grad, r.tb, P.colsplit ? 4 : r.waves, P, s);
@@ -1662,6 +1680,7 @@ extern "C" int gpmpc_objective_gradient(gpmpc_pack* p, int H, const double* x0_h
     PackGuard lock(p);                                      // the entry owns per-pack staging buffers and is synchronous: one caller at a time
     // per-kernel events cannot be recorded inside a captured graph: with timing on the same work is enqueued uncaptured
     const bool eager = timing_on();
+    GraphModeGuard mode(eager ? 0 : 1);
     flags &= GPMPC_WANT_GRAD;
     const bool grad = (flags & GPMPC_WANT_GRAD) != 0;
     const int nin = p->ds + H * p->da, nout = 1 + (grad ? H * p->da : 0);
@@ -1761,6 +1780,7 @@ extern "C" int gpmpc_rollout(const gpmpc_pack* p, int B, int H, const double* x0
                              double* out_cost, double* out_grad, void* workspace, size_t workspace_bytes, void* stream) {
     if (!p || !cost) return GPMPC_E_ARG;
     if (int rc_dev = gpmpc_check_device(p)) return rc_dev;
+    GraphModeGuard mode(((flags & GPMPC_USE_GRAPH) && !timing_on()) ? 1 : 0);
     if ((flags & GPMPC_USE_GRAPH) && !timing_on() && p->built && x0 && U && out_cost && workspace && B >= 1 && H >= 1)
         return graph_rollout(const_cast<gpmpc_pack*>(p), B, H, x0, U, cost, flags, out_means, out_vars, out_cost, out_grad,
                              workspace, workspace_bytes, (hipStream_t)stream);
@@ -1803,7 +1823,7 @@ extern "C" int gpmpc_pack_autotune(gpmpc_pack* p, int B, int H, unsigned flags, 
     gpmpc_tuned_table* tab = (gpmpc_tuned_table*)p->tuned;
     if (!tab) { tab = (gpmpc_tuned_table*)calloc(1, sizeof(gpmpc_tuned_table)); if (!tab) return GPMPC_E_ALLOC; p->tuned = tab; }
     for (int k = 0; k < GPMPC_TUNED_SLOTS; ++k)                   // re-tuning a shape replaces its entry
-        if (tab->e[k].valid && tab->e[k].B == B && tab->e[k].H == H && tab->e[k].grad == (grad ? 1 : 0)) tab->e[k].valid = 0;
+        if (tab->e[k].valid && tab->e[k].B == B && tab->e[k].H == H && tab->e[k].grad == (grad ? 1 : 0) && tab->e[k].graph == (use_graph ? 1 : 0)) tab->e[k].valid = 0;
     // ---- candidates: the default plan, then the plans the GPMPC_* overrides would force, de-duplicated -------------------------
     struct Cand { RollPlan r; int S; double ms; const char* why; };
     Cand cand[40]; int nc = 0;

@@ -88,6 +88,12 @@ static __device__ unsigned long long g_fused_wg[2 * 8192];         // [start | e
 #ifndef GPMPC_FUSED_MEAN_UNROLL
 #define GPMPC_FUSED_MEAN_UNROLL 2   // points per round trip of the mean-sum workgroups of the 256-row forms
 #endif
+#ifndef GPMPC_FUSED_STAGED
+#define GPMPC_FUSED_STAGED 1      // the 256-row forms' column loop in staged batches with the next weight group in flight (round 5); 0: the four-column body
+#endif
+#ifndef GPMPC_FUSED_MGS
+#define GPMPC_FUSED_MGS 2         // columns per group of weight loads of the staged loop (two groups in flight)
+#endif
 #ifndef GPMPC_FUSED_PIPE
 // 256-row forms (Q = 0 / 32 / 16, one GP per tile workgroup): the weight stream M_ij is software-pipelined -- the first group of
 // columns is requested in phase 0, behind every load the prologue waits for (vector-memory results return in order, so the prologue's
@@ -152,6 +158,14 @@ void k_step_fused(FusedArgs A, int t) {
     asm volatile("" ::"s"(A.XT), "s"(A.beta), "s"(A.lam), "s"(A.sf), "s"(A.M), "s"(A.work), "s"(A.x0), "s"(A.U));
     asm volatile("" ::"s"(A.means), "s"(A.vars), "s"(A.jac), "s"(A.sp), "s"(A.part), "s"(A.partz), "s"(A.Np), "s"(A.nwork),
                  "s"(A.tri64), "s"(A.B), "s"(A.H), "s"(A.sps), "s"(A.nm));
+    // columns >= N carry zero weight: tile column loops end at N rounded up to 8 (round 5, as traj_persist.h; the count lives in the pack's
+    // device memory: a captured launch stays valid while the training set grows within its padded size)
+    // The count is fetched with the phase-0 loads below (a VECTOR load through an opaque zero offset: issued there, waited for at the
+    // column loops).  As a scalar load the compiler either waits for it at once -- its round trip, ~2.5 k cycles after a bandwidth-bound
+    // launch has swept the L2, in front of every phase-0 load: N = 2048, B = 1 0.48 -> 0.54 ms per rollout -- or sinks it to its use.
+    int zoff = 0;
+    asm volatile("" : "+v"(zoff));
+    const int ncw_v = A.ncol[zoff];
     int ust[DS + 1];
 #pragma unroll
     for (int a = 0; a <= DS; ++a) { ust[a] = A.ustart[a]; asm volatile("" ::"s"(ust[a])); }
@@ -420,7 +434,9 @@ void k_step_fused(FusedArgs A, int t) {
                 }
                 const int lane8 = lane * 8;
                 constexpr int CU = NG >= 3 ? 1 : 2;
-                for (int jc = 0; jc < NC; jc += CU) {
+                const int ncw = __builtin_amdgcn_readfirstlane(ncw_v);
+                const int ncl = ncw - j0 < NC ? ncw - j0 : NC;               // columns of this tile that carry weight (a multiple of 8, or <= 0)
+                for (int jc = 0; jc < ncl; jc += CU) {
                     double mij[CU][NG];
 #pragma unroll
                     for (int c = 0; c < CU; ++c)
@@ -550,8 +566,76 @@ void k_step_fused(FusedArgs A, int t) {
                     }
                 }
             } else {
+            const int ncw = __builtin_amdgcn_readfirstlane(ncw_v);
+            const int ncl = ncw - j0 < NC ? ncw - j0 : NC;                   // columns of this tile that carry weight (a multiple of 8, or <= 0)
+#if GPMPC_FUSED_STAGED
+            // Round 5 (as traj_persist.h): a wave of this loop is bound by its own latency chain, not by issue -- the compiler's schedule
+            // of the four-column body waited for the G rows twice, for the exp table four times and for the weights of the SAME
+            // iteration (no load in flight across iterations) per four columns; at D = 7 (C4, one trajectory: 834 cycles per column
+            // against 145 of issue).  Columns are evaluated in batches of KC with the stages pinned: all G rows of the batch (one
+            // scalar-load wait), all exponents and table reads (one LDS wait), then weights x exp and the moment sums, while the weight
+            // loads of the next group of columns are in flight (unconditional refill, two register sets in alternation).
+            constexpr int MGS = GPMPC_FUSED_MGS, KC = (D >= 8 || (MGS > 2 && D >= 7)) ? 1 : 2;     // (MGS = 4: an A/B option, more weight loads in flight)
+            static_assert(8 % (2 * MGS) == 0 && MGS % KC == 0, "tiles carry multiples of 8 columns");
+            double wa[MGS], wb[MGS];
+#pragma unroll
+            for (int q = 0; q < MGS; ++q) wa[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, q * Np * 8, 0));
+            auto batch = [&](int j, const double* mw) {
+                double g[KC][GW];
+#pragma unroll
+                for (int c = 0; c < KC; ++c) {
+                    const gpmpc_cdouble* __restrict__ gp = (const gpmpc_cdouble*)(Gl + (size_t)(j + c) * GW);
+#pragma unroll
+                    for (int k = 0; k < D + 1 + NS2; ++k) g[c][k] = gp[k];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                double fr[KC], pq[KC], Tv[KC];
+                int ni[KC];
+#pragma unroll
+                for (int c = 0; c < KC; ++c) {
+                    double sx = qi + g[c][D];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) sx = fma(hi2[k], g[c][k], sx);
+                    const double ax = __builtin_fabs(sx);            // gpmpc_exp_neg_scaled (fast_exp.h), split around the table read
+                    ni[c] = (int)(-ax);
+                    fr[c] = __builtin_amdgcn_fract(ax);
+                    Tv[c] = s_tab[ni[c] & (GPMPC_EXP_N - 1)];
+                    pq[c] = fma(fr[c], fma(fr[c], GPMPC_EXP_A3, GPMPC_EXP_A2), GPMPC_EXP_A1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < KC; ++c) {
+                    const double P = mw[c] * ldexp(fma(Tv[c] * fr[c], pq[c], Tv[c]), ni[c] >> GPMPC_EXP_BITS);
+                    acc[0] += P;
+                    if (GRAD) {
+#pragma unroll
+                        for (int k = 0; k < D; ++k) acc[GRAD ? 1 + k : 0] = fma(P, g[c][k], acc[GRAD ? 1 + k : 0]);
+#pragma unroll
+                        for (int k = 0; k < NS2; ++k) acc[GRAD ? 1 + D + k : 0] = fma(P, g[c][D + 1 + k], acc[GRAD ? 1 + D + k : 0]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            for (int jc = 0; jc < ncl; jc += 2 * MGS) {
+#pragma unroll
+                for (int q = 0; q < MGS; ++q)
+                    wb[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, (jc + MGS + q) * Np * 8, 0));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < MGS; q += KC) batch(jc + q, &wa[q]);
+                {
+                    const int jn = jc + 2 * MGS < ncl ? jc + 2 * MGS : jc;
+#pragma unroll
+                    for (int q = 0; q < MGS; ++q)
+                        wa[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, (jn + q) * Np * 8, 0));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < MGS; q += KC) batch(jc + MGS + q, &wb[q]);
+            }
+#else
             constexpr int CU = 4;
-            for (int jc = 0; jc < NC; jc += CU) {
+            for (int jc = 0; jc < ncl; jc += CU) {
                 double mij[CU];
 #pragma unroll
                 for (int q = 0; q < CU; ++q)
@@ -560,6 +644,7 @@ void k_step_fused(FusedArgs A, int t) {
 #pragma unroll
                 for (int q = 0; q < CU; ++q) column(jc + q, mij[q]);
             }
+#endif
             }
         }
         GPMPC_STAMP(5);
@@ -612,7 +697,7 @@ void k_step_fused(FusedArgs A, int t) {
         const double* __restrict__ Ma = A.M + (size_t)unit * Np * Np;
         bool first = true;
         for (int jc = j0; jc < j1; jc += 64) {
-            if (jc + 63 < i0) continue;                               // upper-triangular M: nothing left of the diagonal chunk
+            if (jc + 63 < i0 || jc + jq >= __builtin_amdgcn_readfirstlane(ncw_v)) continue;      // upper-triangular M: nothing left of the diagonal chunk; nothing beyond N
             if (!first) __syncthreads();                              // the previous chunk's s_hj has been consumed
             if (tid < NCOL) {
                 double x[D];

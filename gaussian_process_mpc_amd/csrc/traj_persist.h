@@ -53,11 +53,20 @@ static __device__ unsigned long long g_persist_stamps[64];
 #else
 #define GPMPC_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 #endif
+#ifndef GPMPC_PERSIST_CSEG
+#define GPMPC_PERSIST_CSEG 16       // overhead of one (unit, row block) segment of a wave's range, in columns (range balancing)
+#endif
+#ifndef GPMPC_PERSIST_AGEW
+#define GPMPC_PERSIST_AGEW 4        // range weights by wave age, per cent per age group (see the range table)
+#endif
 #ifndef GPMPC_PERSIST_PRIO_SHIFT
 #define GPMPC_PERSIST_PRIO_SHIFT 5  // the issue priority rotates every 2^shift columns
 #endif
 #ifndef GPMPC_PERSIST_ROTPRIO
-#define GPMPC_PERSIST_ROTPRIO 1
+#define GPMPC_PERSIST_ROTPRIO 2     // 0: none; 1: by the wave's column count; 2: by the shader clock
+#endif
+#ifndef GPMPC_PERSIST_CLK_SHIFT
+#define GPMPC_PERSIST_CLK_SHIFT 14  // the issue priority rotates every 2^shift cycles (measured: 12 x1.19, 14 x1.23-1.28 over the round-4 kernel at N = 300, ds = 4)
 #endif
 #define GPMPC_PERSIST_MAXDEV 64
 #ifndef GPMPC_PERSIST_MAXNP
@@ -108,11 +117,43 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
     gpmpc_exp_table_to_lds(s_tab);
     for (int e = tid; e < D * Np; e += nthr) s_X[e] = A.XT[e];
     for (int e = tid; e < A.H * DA; e += nthr) s_U[e] = A.U[(size_t)b * A.H * DA + e];
-    // boundaries on multiples of 8 columns (row blocks start on multiples of 64); computed once (64-bit divisions)
+    // Range boundaries of the waves, on multiples of 8 columns (row blocks start on multiples of 64); computed once.  Round 5: equal
+    // COST, not equal columns -- every (unit, row block) segment a wave touches costs it a fixed overhead on top of its columns (row
+    // side, first weight loads and G rows with nothing in flight, the moment flush: the staged loop's timeline had the waves with
+    // three segments finish 30 % after those with one, profiles/r05/persist_stamps_staged_loop.txt), priced as CSEG columns per
+    // row-block start: boundary k is where the cumulative cost pos + CSEG x (row blocks started before pos) reaches k / NW of its total.
     if (tid <= NW) {
-        const int lo = tid == NW ? total : (int)(((long)total * tid / NW + 4) & ~7L);
+        const int nun = (DS + NG - 1) / NG, nblk = nun * T;
+        const long ctot = (long)total + (long)GPMPC_PERSIST_CSEG * nblk;
+        // ... and equal TIME, not equal cost: the four waves a SIMD holds are served oldest first whatever their priority rotation --
+        // with equal ranges wave w finished after (116, 120, 125, 132) k cycles for w / 4 = 0 ... 3 (profiles/r05/persist_stamps_phase2.txt)
+        // -- so the older waves take proportionally more: weights 1 + AGEW (1.5 - w / 4) / 100 per wave, cumulative below.
+        long target = 0;
+        {
+            long wsum = 0, wacc = 0;
+            for (int k = 0; k < NW; ++k) {
+                const long wk = 200 + GPMPC_PERSIST_AGEW * ((NW / 4 - 1) - 2 * (k >> 2));       // 2 (100 + AGEW ((NW / 4 - 1) / 2 - group)), group = k / 4: the wave's age rank on its SIMD
+                wsum += wk;
+                if (k < tid) wacc += wk;
+            }
+            target = ctot * wacc / wsum;
+        }
+        int lo = total;
+        if (tid < NW) {
+            long before = 0;                                // cost of everything before block (u, r)
+            lo = 0;
+            for (int k = 0; k < nblk; ++k) {
+                const int u = k / T, r = k - u * T;
+                const int start = u * per_gp + r * Nc - 32 * r * (r - 1), len = Nc - 64 * r;
+                if (target <= before + GPMPC_PERSIST_CSEG) { lo = start; break; }
+                if (target < before + GPMPC_PERSIST_CSEG + len) { lo = start + (int)((target - before - GPMPC_PERSIST_CSEG + 4) & ~7L); break; }
+                before += GPMPC_PERSIST_CSEG + len;
+                lo = total;
+            }
+            if (tid == 0) lo = 0;
+        }
         s_rng[tid] = lo;
-        if (tid < NW) s_ga[tid] = lo / per_gp;
+        if (tid < NW) s_ga[tid] = lo < total ? lo / per_gp : nun;
     }
     if (tid == 0) s_avar = GPMPC_ACTION_VAR;                   // (a constant read from LDS per step: held in a register pair it was a spill)
     if (tid < DS * D) s_lam[tid] = A.lam[tid];             // (read per step from LDS: a register held across the step loop is a spill)
@@ -121,12 +162,6 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
         A.means[((size_t)b * (A.H + 1)) * DS + tid] = s_uin[tid];
         A.vars[((size_t)b * (A.H + 1)) * DS + tid] = GPMPC_INIT_VAR;
     }
-    // this wave's range of the flattened column space
-    const int r_lo = (int)(((long)total * w / NW + 4) & ~7L), r_hi = w == NW - 1 ? total : (int)(((long)total * (w + 1) / NW + 4) & ~7L);
-    const int gp_first = r_lo < total ? r_lo / per_gp : DS;     // the unit (GP, or group of NG GPs) the range starts in (slot 0 of s_part; slot 1 = the next)
-    // mean sums: a group of wpg waves per GP
-    const int wpg = NW / DS > 0 ? NW / DS : 1;
-    const int am = w / wpg, tgw = (w - am * wpg) * 64;             // GP of this wave in phase 2, first thread index of the wave within the group
     double* __restrict__ Gs = A.gscr + (size_t)b * DS * Np * GW;
 
     for (int t = 1; t <= A.H; ++t) {
@@ -159,64 +194,82 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
         }
         GPMPC_LDS_BARRIER();
         GPMPC_PST(1);
-        // weights of this thread's points in the mean sums of GP am: requested now, used in 2b
-        constexpr int PT = 4;
-        double bpre[PT];
-        const int tgz = tgw + ln;
-#pragma unroll
-        for (int q = 0; q < PT; ++q) {
-            const int i = tgz + q * 64 * wpg;
-            const double bv = A.beta[(size_t)(am < DS ? am : 0) * Np + (i < Np ? i : 0)];
-            bpre[q] = (am < DS && i < Np) ? bv : 0.0;
-        }
-        // ---- 2a: column rows of every (GP, point) -> scratch (stores in flight while the mean sums run) --------------------------
-        for (int e = tiz; e < (SH ? 1 : DS) * Np; e += nthr) {      // one set of rows per trajectory when the GPs share lambda
-            const int a = SH ? 0 : e / Np, j = e - a * Np;
-            double g[GW], qh = 0.0;
-#pragma unroll
-            for (int k = 0; k < GW; ++k) g[k] = 0.0;
-#pragma unroll
-            for (int k = 0; k < D; ++k) {
-                const double h = fma(-s_sc[a * D + k], s_X[k * Np + j], s_cv[a * D + k]);
-                g[k] = h;
-                qh = fma(h, h, qh);
-                if (k < NS2) g[D + 1 + k] = h * h;
-            }
-            g[D] = GPMPC_EXP_NEG_INV_C * qh;
-            double2* dst = reinterpret_cast<double2*>(Gs + (size_t)e * GW);
-#pragma unroll
-            for (int k = 0; k < GW / 2; ++k) dst[k] = make_double2(g[2 * k], g[2 * k + 1]);
-        }
+        // ---- 2: the first DS waves take the O(N) mean sums, ONE wave per GP (step.hip::prep_step); the other waves write the column rows.
+        // Round 5.  (a) The mean sums used to run on all waves, wpg per GP: every wave then paid the NV wave reductions (~130 of its
+        // ~330 instructions, 16 waves x 4.4 cycles x 4 per SIMD = 5.8 k cycles of VALU per step); one wave per GP strides the points
+        // with 64 lanes, reduces once, and the reductions of the DS waves run on different SIMDs beside the row writers.  The weights'
+        // exp is the table exp of the pair loop (fast_exp.h: 1.3 ulp).  (b) The rows are laid out in 16-byte CHUNKS,
+        // G[a][c][j] = (g_2c, g_2c+1) of column j: lane = column makes every store instruction one contiguous kilobyte (row-major rows
+        // scattered 64 x 16 bytes at an 80-byte stride: ~5 k cycles of partial-line writes per step), and a batch of two columns still
+        // reads 32 contiguous bytes per chunk through scalar loads.
         GPMPC_PST(2);
-        // ---- 2b: mean sums of GP am over the N points (step.hip::prep_step) -------------------------------------------------------
-        {
+        // (two waves per GP when the workgroup has the waves to spare: the mean sums are the longer of the two roles)
+        const int MW = (NW >= 16 && 2 * DS <= NW / 2) ? 2 : 1;
+        if (w < MW * DS) {
+            const int a = w / MW, wsub = w - a * MW, lstr = 64 * MW, l0 = wsub * 64 + ln;      // this wave's points: l0, l0 + lstr, ...
             double v[NV];
 #pragma unroll
             for (int m = 0; m < NV; ++m) v[m] = 0.0;
-            if (am < DS) {
-                double u[D], Bk[D];
+            double u[D], Bk[D];
 #pragma unroll
-                for (int k = 0; k < D; ++k) { u[k] = s_uin[k]; Bk[k] = s_B[am * D + k]; }
-                int it = 0;
-                for (int i = tgz; i < Np; i += 64 * wpg, ++it) {
-                    double d[D], q = 0.0;
+            for (int k = 0; k < D; ++k) { u[k] = s_uin[k]; Bk[k] = s_B[a * D + k]; }
+            constexpr int PT = 8;                                  // weights of up to 512 (1024) points requested before the first is used
+            double bpre[PT];
 #pragma unroll
-                    for (int k = 0; k < D; ++k) { d[k] = u[k] - s_X[k * Np + i]; q = fma(Bk[k] * d[k], d[k], q); }
-                    double bw = bpre[0];                            // (static indices: the array stays in registers)
-                    if (it == 1) bw = bpre[1];
-                    if (it == 2) bw = bpre[2];
-                    if (it == 3) bw = bpre[3];
-                    if (it >= PT) bw = A.beta[(size_t)am * Np + i];
-                    const double p = bw * exp(-0.5 * q);
+            for (int q = 0; q < PT; ++q) {
+                const int i = l0 + lstr * q;
+                const double bv = A.beta[(size_t)a * Np + (i < Np ? i : 0)];
+                bpre[q] = i < Np ? bv : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < PT; ++q) {
+                const int i = l0 + lstr * q;
+                if (wsub * 64 + lstr * q < Np) {                   // (wave-uniform)
+                    double d[D], qq = 0.0;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) { d[k] = u[k] - s_X[k * Np + (i < Np ? i : 0)]; qq = fma(Bk[k] * d[k], d[k], qq); }
+                    const double p = bpre[q] * gpmpc_exp_neg(0.5 * qq, s_tab);
                     v[0] += p;
 #pragma unroll
                     for (int k = 0; k < D; ++k) { v[1 + k] = fma(p, d[k], v[1 + k]); v[1 + D + k] = fma(p * d[k], d[k], v[1 + D + k]); }
                 }
             }
+            for (int i = l0 + lstr * PT; i < Np; i += lstr) {      // larger training sets
+                double d[D], qq = 0.0;
 #pragma unroll
-            for (int m = 0; m < NV; ++m) {
+                for (int k = 0; k < D; ++k) { d[k] = u[k] - s_X[k * Np + i]; qq = fma(Bk[k] * d[k], d[k], qq); }
+                const double p = A.beta[(size_t)a * Np + i] * gpmpc_exp_neg(0.5 * qq, s_tab);
+                v[0] += p;
+#pragma unroll
+                for (int k = 0; k < D; ++k) { v[1 + k] = fma(p, d[k], v[1 + k]); v[1 + D + k] = fma(p * d[k], d[k], v[1 + D + k]); }
+            }
+#pragma unroll
+            for (int m = 0; m < NV; ++m) {                         // fixed order: rows of 16 lanes, then (0 + 1) + (2 + 3)
                 const double sr = wave_row_sum(v[m]);
                 if ((ln & 15) == 0) s_mred[(w * 4 + (ln >> 4)) * NV + m] = sr;
+            }
+            if (MW == 1 && ln < NV) {                              // (a wave's LDS operations execute in order)
+                const double* r4 = &s_mred[w * 4 * NV + ln];
+                s_ms[a * NV + ln] = (r4[0] + r4[NV]) + (r4[2 * NV] + r4[3 * NV]);
+            }
+        } else {
+            const int nrw = (NW - MW * DS) * 64;                   // row-writing threads
+            for (int e = (w - MW * DS) * 64 + ln; e < (SH ? 1 : DS) * Np; e += nrw) {     // one set of rows per trajectory when the GPs share lambda
+                const int a = SH ? 0 : e / Np, j = e - a * Np;
+                double g[GW], qh = 0.0;
+#pragma unroll
+                for (int k = 0; k < GW; ++k) g[k] = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    const double h = fma(-s_sc[a * D + k], s_X[k * Np + j], s_cv[a * D + k]);
+                    g[k] = h;
+                    qh = fma(h, h, qh);
+                    if (k < NS2) g[D + 1 + k] = h * h;
+                }
+                g[D] = GPMPC_EXP_NEG_INV_C * qh;
+#pragma unroll
+                for (int c = 0; c < GW / 2; ++c)
+                    reinterpret_cast<double2*>(Gs)[((size_t)a * (GW / 2) + c) * Np + j] = make_double2(g[2 * c], g[2 * c + 1]);
             }
         }
         GPMPC_PST(3);
@@ -226,14 +279,11 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
         GPMPC_PST(5);
         __builtin_amdgcn_s_dcache_inv();                           // the scalar cache may hold the previous step's rows
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (tiz < DS * NV) {                                       // combine the mean sums: waves of the GP's group, rows in fixed order
+        if (MW == 2 && tiz < DS * NV) {                            // two waves per GP: their row sums in fixed order (read in phase 4, two barriers on)
             const int a = tiz / NV, m = tiz - a * NV;
-            double sum = 0.0;
-            for (int ww = a * wpg; ww < (a + 1) * wpg; ++ww) {
-                const double* r4 = &s_mred[ww * 4 * NV + m];
-                sum += (r4[0] + r4[NV]) + (r4[2 * NV] + r4[3 * NV]);
-            }
-            s_ms[tiz] = sum;
+            const double* r0 = &s_mred[(2 * a) * 4 * NV + m];
+            const double* r1 = r0 + 4 * NV;
+            s_ms[tiz] = ((r0[0] + r0[NV]) + (r0[2 * NV] + r0[3 * NV])) + ((r1[0] + r1[NV]) + (r1[2 * NV] + r1[3 * NV]));
         }
         GPMPC_PST(6);
         GPMPC_PSTW(16);
@@ -252,18 +302,17 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
             constexpr int KC = (D >= 7 || (NG > 1 && D >= 6)) ? 1 : 2;
             constexpr int MGc = GPMPC_PERSIST_MG ? GPMPC_PERSIST_MG : ((NG > 1 || D >= 6) ? 2 : 4);
             static_assert(MGc % KC == 0 && 8 % (2 * MGc) == 0, "segment lengths are multiples of 8 columns");
-            int pos = r_lo, slot = 0, u_cur = gp_first;
+            // this wave's range [r_lo, r_hi) and the unit it starts in (slot 0 of s_part; slot 1 = the next unit), from the table
+            const int r_lo = __builtin_amdgcn_readfirstlane(s_rng[w]), r_hi = __builtin_amdgcn_readfirstlane(s_rng[w + 1]);
+            int pos = r_lo, slot = 0, u = __builtin_amdgcn_readfirstlane(s_ga[w]);
+            int rem = pos - u * per_gp, r = 0;                      // position within the unit; row block: the largest r with start(r) <= rem
+            while (r + 1 < T && (r + 1) * Nc - 32 * (r + 1) * r <= rem) ++r;
             for (int e = ln; e < 2 * NG * 4 * NM; e += 64) s_part[w * (2 * NG * 4 * NM) + e] = 0.0;   // (a wave's LDS operations execute in order)
             const double* Gl = Gs;
             asm volatile("" : "+s"(Gl) :: "memory");               // rows written a moment ago: keep the scalar loads behind the barrier
             typedef const double __attribute__((address_space(4))) gpmpc_cdouble;
             while (pos < r_hi) {
-                const int u = pos / per_gp, rem = pos - u * per_gp;
-                if (u != u_cur) { slot = 1; u_cur = u; }
-                // row block r: the largest r with start(r) = r Nc - 32 r (r - 1) <= rem
-                int r = 0;
-                while (r + 1 < T && (r + 1) * Nc - 32 * (r + 1) * r <= rem) ++r;
-                const int bstart = r * Nc - 32 * r * (r - 1);
+                const int bstart = r * Nc - 32 * r * (r - 1);      // start(r) = r Nc - 32 r (r - 1)
                 const int j0 = 64 * r + (rem - bstart);            // first column of the segment
                 const int blen = Nc - 64 * r;                      // columns of the row block
                 int n = bstart + blen - rem;                       // ... left in it
@@ -297,16 +346,19 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
                 for (int q = 0; q < NG; ++q)
 #pragma unroll
                     for (int m = 0; m < NA; ++m) acc[q][m] = 0.0;
-                const double* Ga = Gl + ((size_t)at * Np + j0) * GW;
+                const double* Ga = Gl + ((size_t)at * (GW / 2) * Np + j0) * 2;      // chunk 0 of the segment's first column
                 // KC columns: rows -> exponents + table reads -> weights x exp, moment sums
                 auto batch = [&](int j, const double (*mw)[NG]) {
                     double g[KC][GW];
+                    // (the base goes through an opaque asm per batch: left to see that consecutive batches are adjacent in memory the
+                    // compiler merges their loads into 64-byte ones -- 80 SGPRs of rows, the loop's other scalars spilled to VGPR lanes
+                    // and read back with 18 v_readlane per iteration)
+                    const double* gb = Ga + (size_t)j * 2;
+                    asm volatile("" : "+s"(gb));
 #pragma unroll
-                    for (int c = 0; c < KC; ++c) {
-                        const gpmpc_cdouble* __restrict__ gp = (const gpmpc_cdouble*)(Ga + (size_t)(j + c) * GW);
+                    for (int k = 0; k < D + 1 + NS2; ++k)             // chunk k / 2 of columns j ... j + KC - 1: 16 KC contiguous bytes
 #pragma unroll
-                        for (int k = 0; k < D + 1 + NS2; ++k) g[c][k] = gp[k];
-                    }
+                        for (int c = 0; c < KC; ++c) g[c][k] = ((const gpmpc_cdouble*)(gb + ((size_t)(k >> 1) * Np + c) * 2))[k & 1];
                     __builtin_amdgcn_sched_barrier(0);
                     double fr[KC], pq[KC], Tv[KC];
                     int ni[KC];
@@ -340,12 +392,25 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 };
+#if GPMPC_PERSIST_ROTPRIO == 2
+                unsigned long long clk = __builtin_amdgcn_s_memtime();
+#endif
                 for (int jc = 0; jc < n; jc += 2 * MGc) {          // n is a multiple of 8
 #if GPMPC_PERSIST_ROTPRIO
                     // The four waves a SIMD holds of this workgroup are arbitrated by age: left alone the oldest runs ahead and the
                     // youngest finishes 40 % later, the SIMD half empty at the end (stamps: wave 2 109 k cycles, wave 15 165 k for
-                    // equal ranges).  Rotating the issue priority every few iterations lets them advance together.
+                    // equal ranges).  Rotating the issue priority lets them advance together.  Round 5: the rotation follows the
+                    // shader CLOCK, not the wave's own column count -- positions within segments differ from wave to wave, priorities
+                    // then coincide and ties go to the older wave again (waves 12-15 finished 15-20 % after the others); with a common
+                    // clock the four waves of a SIMD hold four distinct priorities at every instant.  The counter read is issued one
+                    // iteration ahead (a scalar memory instruction: consumed after waits that happen anyway).
+#if GPMPC_PERSIST_ROTPRIO == 2
+                    const unsigned tick = (unsigned)(clk >> GPMPC_PERSIST_CLK_SHIFT);
+                    clk = __builtin_amdgcn_s_memtime();
+                    switch ((tick + (w >> 2)) & 3) {
+#else
                     switch (((jc >> GPMPC_PERSIST_PRIO_SHIFT) + (w >> 2)) & 3) {
+#endif
                         case 0: __builtin_amdgcn_s_setprio(0); break;
                         case 1: __builtin_amdgcn_s_setprio(1); break;
                         case 2: __builtin_amdgcn_s_setprio(2); break;
@@ -396,6 +461,10 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
                     }
                 }
                 pos += n;
+                rem += n;
+                if (rem >= bstart + blen) {                        // the row block is done: next block, or the next unit's first
+                    if (++r == T) { r = 0; rem = 0; ++u; slot = 1; }
+                }
             }
             GPMPC_PSTW(32);
 #if GPMPC_PERSIST_ROTPRIO
@@ -414,19 +483,23 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
             const double sf = A.sf[a], sf2 = sf * sf;
             s_sf2[a] = sf2; s_cm[a] = sf2 / sqrt(detm); s_c[a] = 1.0 / sqrt(detv);
         }
-        if (tiz < DS * NM) {
-            const int a = tiz / NM, m = tiz - a * NM;
-            double sum = 0.0;
-            for (int ww = 0; ww < NW; ++ww) {                      // fixed order: waves, their (at most two) GPs, rows as (0 + 1) + (2 + 3)
+        // every (GP, moment) sum by a ROW of 16 lanes, one lane per wave of the workgroup (round 5: one thread per sum walked the 16
+        // waves in a chain of dependent LDS reads, ~3 k cycles of a 9.5 k phase); fixed order: rows as (0 + 1) + (2 + 3), then the
+        // 16-lane row sum's tree over the waves
+        for (int o = tiz >> 4; o < DS * NM; o += nthr >> 4) {
+            const int ww = tiz & 15, a = o / NM, m = o - a * NM;
+            double v = 0.0;
+            if (ww < NW) {
                 const int lo = s_rng[ww], hi = s_rng[ww + 1];
-                if (lo >= hi) continue;
                 const int a0 = s_ga[ww];                           // the range ends in unit a0 or a0 + 1: hi <= (a0 + 2) per_gp
                 const int un = a / NG, qn = a - un * NG;           // unit of GP a and its place in it
-                if (un != a0 && !(un == a0 + 1 && hi > (a0 + 1) * per_gp)) continue;
-                const double* r4 = &s_part[(((ww * 2 + (un - a0)) * NG + qn) * 4) * NM + m];
-                sum += (r4[0] + r4[NM]) + (r4[2 * NM] + r4[3 * NM]);
+                if (lo < hi && (un == a0 || (un == a0 + 1 && hi > (a0 + 1) * per_gp))) {
+                    const double* r4 = &s_part[(((ww * 2 + (un - a0)) * NG + qn) * 4) * NM + m];
+                    v = (r4[0] + r4[NM]) + (r4[2 * NM] + r4[3 * NM]);
+                }
             }
-            s_z[tiz] = sum;
+            v = wave_row_sum(v);
+            if (ww == 0) s_z[o] = v;
         }
         GPMPC_LDS_BARRIER();
         if (tiz < DS * D) {

@@ -63,7 +63,8 @@ class RiskSensitiveMPC:
         self.solver_used = None
         # lock-step multi-start solve (extension; multistart.py): K starts, tick budget, seed of the sampled starts
         self.n_starts = 1
-        self.multistart_options = {"max_ticks": 150, "history": 8, "gtol": 1e-4, "ftol": 1e-10, "spread": 1.0, "seed": 0, "warm": True}
+        self.multistart_options = {"max_ticks": 150, "history": 6, "gtol": 1e-4, "ftol": 1e-10, "spread": 1.0, "seed": 0, "warm": True,
+                                   "patience": 8}
         self.last_solve_info = None
         self._solve_count = 0
 
@@ -270,7 +271,7 @@ class RiskSensitiveMPC:
 
         x, info = lockstep_lbfgs(evaluate, X0, np.asarray(lb, dtype=np.float64), np.asarray(ub, dtype=np.float64),
                                  max_ticks=int(opt.get("max_ticks", 150)), history=int(opt.get("history", 8)),
-                                 gtol=float(opt.get("gtol", 1e-4)), ftol=float(opt.get("ftol", 1e-10)))
+                                 gtol=float(opt.get("gtol", 1e-4)), ftol=float(opt.get("ftol", 1e-10)), patience=opt.get("patience"))
         info["starts"] = K
         info["sharded_over"] = dist.get_world_size() if dist is not None else 1
         self.last_solve_info = info

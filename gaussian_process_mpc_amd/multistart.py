@@ -37,8 +37,10 @@ def make_starts(n_starts, n, lb, ub, rng, warm=None, spread=1.0):
 def _two_loop(g, S, Y, rho, cnt):
     """-H g for every start at once: L-BFGS two-loop recursion over the (K, m, n) histories, NEWEST pair at index 0 (plain
     slices, no gather); starts with fewer stored pairs skip the missing ones through `cnt`."""
-    m = S.shape[1]
+    m = min(S.shape[1], int(cnt.max())) if len(cnt) else 0      # pairs stored by the start with the longest history
     q = g.copy()
+    if m == 0:
+        return -q
     alpha = []
     for j in range(m):                                      # newest pair first
         a = np.where(j < cnt, rho[:, j] * np.einsum("kn,kn->k", S[:, j], q), 0.0)
@@ -53,12 +55,14 @@ def _two_loop(g, S, Y, rho, cnt):
     return -q
 
 
-def lockstep_lbfgs(evaluate, X0, lb, ub, max_ticks=300, history=8, gtol=1e-4, ftol=1e-10, c1=1e-4, min_step=1e-12):
+def lockstep_lbfgs(evaluate, X0, lb, ub, max_ticks=300, history=8, gtol=1e-4, ftol=1e-10, c1=1e-4, min_step=1e-12, patience=None):
     """Minimise K copies of a bounded problem from the rows of X0, one ``evaluate`` per tick.
 
     evaluate(X (K, n)) -> (f (K,), g (K, n)); non-finite values are allowed (a plan whose risk-sensitive log-determinant
     does not exist returns NaN, src/mpc.py:183): such a trial point is rejected like a failed Armijo test, a start whose FIRST
-    point is non-finite is dropped.  Returns (x_best, info) with info = {f (K,), x (K, n), ticks, evaluations, converged (K,),
+    point is non-finite is dropped.  ``patience`` (ticks, optional): once the start that currently holds the lowest value has
+    converged AND row 0 (the reference's own start) has finished, the others get this many more ticks before the search ends (a receding-horizon controller re-solves at the next
+    step: the stragglers of a lock-step search are the starts least likely to matter).  Returns (x_best, info) with info = {f (K,), x (K, n), ticks, evaluations, converged (K,),
     alive (K,), best}."""
     X = np.clip(np.asarray(X0, dtype=np.float64), lb, ub)
     K, n = X.shape
@@ -95,8 +99,15 @@ def lockstep_lbfgs(evaluate, X0, lb, ub, max_ticks=300, history=8, gtol=1e-4, ft
     done |= pg <= gtol
     converged = done & alive
     XT = np.clip(X + A[:, None] * D, lb, ub)
-    ticks = 0
+    ticks, best_done_at = 0, None
     while ticks < max_ticks and not done.all():
+        if patience is not None:
+            if converged[int(np.argmin(F))] and done[0]:          # (row 0, the reference's own zero start, always runs to its end)
+                best_done_at = ticks if best_done_at is None else best_done_at
+                if ticks - best_done_at >= patience:
+                    break
+            else:
+                best_done_at = None
         ft, gt = evaluate(np.where(done[:, None], X, XT))
         ft, gt = np.asarray(ft, dtype=np.float64).reshape(K), np.asarray(gt, dtype=np.float64).reshape(K, n)
         ticks += 1

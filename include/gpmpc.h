@@ -336,7 +336,8 @@ int gpmpc_kinv_append(int n, const double* Ky_inv_dev, const double* k_dev, doub
  * Ky_inv of the n + 1 points -- the Schur step of gpmpc_kinv_append -- written into the OUTPUT buffers (row stride ld_out >= n + 1)
  * from the INPUT buffers (row strides ld_k_in of Kf / Ky and ld_in of Ky_inv, >= n).  Inputs and outputs must not alias: the caller ping-pongs two buffer sets, so the
  * n-point matrices stay valid for whoever still reads them.  X dev [n][D] (the n OLD rows), x_new dev [D], lambdas host [D].
- * Four kernel launches, no allocation, no host-side concatenation. */
+ * Two kernel launches (k_append_vw2: k, v = Ky_inv k and the Schur scalar; k_append_fill2: the three (n + 1)-point matrices), no allocation,
+ * no host-side concatenation. */
 size_t gpmpc_gp_append_workspace_bytes(int n, int D);
 int gpmpc_gp_append(int n, int D, const double* X_dev, const double* x_new_dev, const double* lambdas_host, double sigma_f,
                     double noise_var, const double* Kf_in, const double* Ky_in, size_t ld_k_in, const double* Ky_inv_in, size_t ld_in,

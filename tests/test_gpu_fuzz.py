@@ -103,13 +103,17 @@ def test_split_call_whose_sub_batches_fit_the_whole_horizon_kernel(G, monkeypatc
     kinv = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"]).Ky_inv.numpy()
     cost = G.CostParams(1e-5, pb["Q"], pb["R"])
     out = {}
+    # (round 5: an explicit kernel-form override -- GPMPC_PAIR_SB, GPMPC_TILING, ... -- now switches the whole-horizon kernel off, so the
+    # whole batch is put on a step-per-launch form with GPMPC_PERSIST=0 and "what a sub-batch would be on its own" is read from a pack
+    # under default tuning)
+    alone = G.GPPack(pb["X"], pb["Y"], kinv, pb["lambdas"], pb["sigma_f"]).plan(B // 2, H, graph=graph)["form"]
+    assert alone == "persist", alone                                           # what a sub-batch would be on its own
     for split in ("1", "2"):
-        for k, v in (("GPMPC_PAIR_SB", "1"), ("GPMPC_TILING", "2"), ("GPMPC_SPLIT", split)):
+        for k, v in (("GPMPC_PERSIST", "0"), ("GPMPC_SPLIT", split)):
             monkeypatch.setenv(k, v)
         pack = G.GPPack(pb["X"], pb["Y"], kinv, pb["lambdas"], pb["sigma_f"])
         plan = pack.plan(B, H, graph=graph)
         assert plan["form"] != "persist" and plan["split"] == int(split), plan
-        assert pack.plan(B // 2, H, graph=graph)["form"] == "persist"          # what a sub-batch would be on its own
         out[split] = G.rollout(pack, pb["x0"], pb["U"], cost, graph=graph)
         del pack
     for k in out["1"]:
