@@ -1119,7 +1119,9 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
             pw && (tn.persist > 0 || (p->Np <= (pshared ? 448 : 512) && D <= 6 && !shared_ahead && !form_forced))) {
             r->fused = 3; r->sb = 0; r->shared = 0; r->tb = 1; r->rgroup = 1; r->colunroll = 1; r->fq = 1;
             r->pwaves = pw;
-            r->png = pshared ? 2 : 1;
+            // units of two GPs; ALL GPs of the pack in one unit where that instance exists (traj_persist.h: ds = 4 at D = 5, ds = 3 at D <= 5;
+            // 16-wave workgroups only: two 8-wave workgroups per CU do not fit their static LDS)
+            r->png = pshared ? ((pw == 16 && ((p->ds == 4 && D == 5) || (p->ds == 3 && D <= 5))) ? p->ds : 2) : 1;
             r->nwork = 0;
         }
     }

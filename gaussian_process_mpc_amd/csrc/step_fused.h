@@ -119,6 +119,9 @@ static __device__ unsigned long long g_fused_wg[2 * 8192];         // [start | e
 // stored to a scratch slot of its own, and read back after s_waitcnt vmcnt(0) (the stores have reached L2), an s_dcache_inv
 // (the scalar cache may hold the slot's previous contents) and the workgroup barrier.
 // layout of sp (doubles), as step.hip: 0 c | 1 mu | 2 sf2 | 3 A[D] | 3+D scale[D] | 3+2D dmu_du[D] | 3+3D dmu_ds[D]
+#ifndef GPMPC_FUSED_SB_W4_FROM
+#define GPMPC_FUSED_SB_W4_FROM 6    /* input dimension from which the 256-row forms are compiled for 4 waves per SIMD (A/B knob) */
+#endif
 #ifndef GPMPC_FUSED_SB_WAVES
 #define GPMPC_FUSED_SB_WAVES 5      /* waves per SIMD the mid-size form is compiled for up to D = 5 (A/B knob; 4 from D = 6: 21 spilled registers at 96) */
 #endif
@@ -126,7 +129,7 @@ static __device__ unsigned long long g_fused_wg[2 * 8192];         // [start | e
 // exponent and the exp ONCE per pair and applies them to NG weight loads; work list wl_sh[1] (items {group, i0, j0, tile}),
 // partial sums laid out [GP][tile], one row of column data per trajectory instead of one per GP.
 template <int D, int NS2, bool GRAD, int Q, int NG = 1>
-__global__ __launch_bounds__(256, (Q == 0 || Q == 32 || Q == 16) ? (NG >= 3 ? 3 : ((NG == 2 || D >= 6) ? 4 : GPMPC_FUSED_SB_WAVES)) : 1)
+__global__ __launch_bounds__(256, (Q == 0 || Q == 32 || Q == 16) ? (NG >= 3 ? 3 : ((NG == 2 || D >= GPMPC_FUSED_SB_W4_FROM) ? 4 : GPMPC_FUSED_SB_WAVES)) : 1)
 void k_step_fused(FusedArgs A, int t) {
     constexpr bool SB = Q == 0 || Q == 32 || Q == 16;
     constexpr bool SH = NG > 1;

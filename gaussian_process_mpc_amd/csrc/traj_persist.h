@@ -26,6 +26,7 @@
 #pragma once
 #include "gpmpc_internal.h"
 #include "fast_exp.h"
+#include <type_traits>
 
 
 // Diagnostic build (-DGPMPC_PERSIST_STAMPS, D = GPMPC_STAMP_D instances): s_memtime stamps of workgroup 0 at horizon step 3 -- per
@@ -56,6 +57,12 @@ static __device__ unsigned long long g_persist_stamps[64];
 #ifndef GPMPC_PERSIST_CSEG
 #define GPMPC_PERSIST_CSEG 16       // overhead of one (unit, row block) segment of a wave's range, in columns (range balancing)
 #endif
+#ifndef GPMPC_PERSIST_KC3
+#define GPMPC_PERSIST_KC3 1         // batches of three columns where the rows fit the SGPR file (see KC)
+#endif
+#ifndef GPMPC_PERSIST_TOUCH
+#define GPMPC_PERSIST_TOUCH 0       // 1: request the next batch's G-row cache lines with this batch's rows (scalar-cache warm-up; A/B)
+#endif
 #ifndef GPMPC_PERSIST_AGEW
 #define GPMPC_PERSIST_AGEW 4        // range weights by wave age, per cent per age group (see the range table)
 #endif
@@ -83,6 +90,19 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
     constexpr bool SH = NG > 1;
     constexpr int DS = NS2, DA = D - NS2, NM = GRAD ? 1 + 2 * D : 1, NA = GRAD ? 1 + D + NS2 : 1, NV = 1 + 2 * D;
     constexpr int GW = (D + 1 + NS2 + 1) & ~1;     // doubles per G row, as PairSbTraits
+    // columns per batch of the column loop (KC (D + 1 + ds) doubles of G rows in SGPRs, KC sets of exp temporaries in VGPRs) and per group of
+    // weight loads (two groups in flight): what fits the 128 registers of four waves per SIMD WITHOUT a spill (tools/spill_guard.py).
+    // Range boundaries fall on multiples of GR = 2 MGc columns (the loop's step): 8 for NG = 1, down to 2 for units of four GPs, whose
+    // flattened space is a quarter as long (N = 300: 55 columns per wave).
+    // KC = 3 (one GP per unit, D <= 5: 3 (D + 1 + ds) <= 30 doubles of rows in SGPRs): with batches of two a wave waits ~650 cycles (rows + table)
+    // per 230 cycles of its own arithmetic and its three neighbours on the SIMD have 690 to fill them with -- just enough only when
+    // perfectly staggered (VALU busy ~78 % of the loop phase); batches of three leave 1035.  Six columns per iteration, a tail of batches of
+    // two (segment lengths are even, not multiples of six).
+    constexpr int KC = (D >= 7 || (NG > 1 && D >= 6) || NG >= 4 || (NG == 3 && D >= 5)) ? 1 : ((NG == 1 && D <= 5 && GPMPC_PERSIST_KC3) ? 3 : 2);
+    constexpr int MGc = KC == 3 ? 3 : (GPMPC_PERSIST_MG ? GPMPC_PERSIST_MG : (NG >= 4 ? 1 : ((NG > 1 || D >= 6) ? 2 : 4)));
+    constexpr int GR = KC == 3 ? 2 : 2 * MGc;
+    constexpr bool GPAIR = KC != 3;                // column rows laid out per pair of columns (batches of two read them as one block); batches of three: row-major
+    static_assert(MGc % KC == 0 && 8 % GR == 0, "segment lengths are multiples of GR columns; row blocks and N (rounded up) of 8");
     // weight columns per group (two groups in flight) and columns whose dependency chains may interleave: 4 and 2 up to D = 6; from D = 7
     // the accumulators alone (2 (1 + D + ds) + 2 (1 + 2 D) registers) leave room for 2 and 1 (D = 7: 68 -> 6 VGPR spills, D = 8: 94 -> 18).
     // Not only speed: the D = 8, ds = 7 instance with 94 VGPR + 80 SGPR spills returned means with the low mantissa word of some
@@ -113,6 +133,8 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
     const int total = ((DS + NG - 1) / NG) * per_gp;
     double* __restrict__ s_X = s_dyn;
     double* __restrict__ s_U = s_dyn + (size_t)D * Np;       // the trajectory's actions, [H][da]
+    double* __restrict__ s_stage = s_U + ((A.H * DA + 1) & ~1);     // row-major column rows: a staging block of 64 rows per row-writing wave (16-byte aligned)
+    (void)s_stage;
 
     gpmpc_exp_table_to_lds(s_tab);
     for (int e = tid; e < D * Np; e += nthr) s_X[e] = A.XT[e];
@@ -146,7 +168,7 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
                 const int u = k / T, r = k - u * T;
                 const int start = u * per_gp + r * Nc - 32 * r * (r - 1), len = Nc - 64 * r;
                 if (target <= before + GPMPC_PERSIST_CSEG) { lo = start; break; }
-                if (target < before + GPMPC_PERSIST_CSEG + len) { lo = start + (int)((target - before - GPMPC_PERSIST_CSEG + 4) & ~7L); break; }
+                if (target < before + GPMPC_PERSIST_CSEG + len) { lo = start + (int)((target - before - GPMPC_PERSIST_CSEG + GR / 2) & ~(long)(GR - 1)); break; }
                 before += GPMPC_PERSIST_CSEG + len;
                 lo = total;
             }
@@ -198,10 +220,11 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
         // Round 5.  (a) The mean sums used to run on all waves, wpg per GP: every wave then paid the NV wave reductions (~130 of its
         // ~330 instructions, 16 waves x 4.4 cycles x 4 per SIMD = 5.8 k cycles of VALU per step); one wave per GP strides the points
         // with 64 lanes, reduces once, and the reductions of the DS waves run on different SIMDs beside the row writers.  The weights'
-        // exp is the table exp of the pair loop (fast_exp.h: 1.3 ulp).  (b) The rows are laid out in 16-byte CHUNKS,
-        // G[a][c][j] = (g_2c, g_2c+1) of column j: lane = column makes every store instruction one contiguous kilobyte (row-major rows
-        // scattered 64 x 16 bytes at an 80-byte stride: ~5 k cycles of partial-line writes per step), and a batch of two columns still
-        // reads 32 contiguous bytes per chunk through scalar loads.
+        // exp is the table exp of the pair loop (fast_exp.h: 1.3 ulp).  (b) The rows are laid out per PAIR of columns in 16-byte chunks,
+        // G[a][j / 2][c][j % 2] = (g_2c, g_2c+1) of column j: two neighbouring lanes write one aligned 32-byte sector per store (row-major
+        // rows scattered 64 x 16 bytes at an 80-byte stride -- partial sectors, ~5 k cycles per step), and the batch of two columns the
+        // loop evaluates reads its 2 GW doubles as ONE contiguous block through scalar loads (a fully chunked layout G[a][c][j] made the
+        // stores one contiguous kilobyte but cost the loop five 32-byte loads from five cache lines per batch: +6 % loop time).
         GPMPC_PST(2);
         // (two waves per GP when the workgroup has the waves to spare: the mean sums are the longer of the two roles)
         const int MW = (NW >= 16 && 2 * DS <= NW / 2) ? 2 : 1;
@@ -252,9 +275,40 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
                 const double* r4 = &s_mred[w * 4 * NV + ln];
                 s_ms[a * NV + ln] = (r4[0] + r4[NV]) + (r4[2 * NV] + r4[3 * NV]);
             }
+        } else if constexpr (!GPAIR) {
+            // row-major rows (batches of three columns read 3 GW contiguous doubles): written THROUGH LDS -- a lane's row goes to the wave's
+            // staging block, the block (64 consecutive rows = 64 GW contiguous doubles in global memory) leaves as GW / 2 fully coalesced
+            // kilobyte stores.  (Stored directly, a row is five 16-byte pieces at an 80-byte stride: partial sectors, +9 k cycles per step.)
+            const int nrw = (NW - MW * DS) * 64, nrows = (SH ? 1 : DS) * Np;
+            double2* stg = reinterpret_cast<double2*>(s_stage) + (size_t)(w - MW * DS) * 64 * (GW / 2);
+            for (int e0 = (w - MW * DS) * 64; e0 < nrows; e0 += nrw) {               // (wave-uniform)
+                const int e = e0 + ln;
+                if (e < nrows) {
+                    const int a = SH ? 0 : e / Np, j = e - a * Np;
+                    double g[GW], qh = 0.0;
+#pragma unroll
+                    for (int k = 0; k < GW; ++k) g[k] = 0.0;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) {
+                        const double h = fma(-s_sc[a * D + k], s_X[k * Np + j], s_cv[a * D + k]);
+                        g[k] = h;
+                        qh = fma(h, h, qh);
+                        if (k < NS2) g[D + 1 + k] = h * h;
+                    }
+                    g[D] = GPMPC_EXP_NEG_INV_C * qh;
+#pragma unroll
+                    for (int c = 0; c < GW / 2; ++c) stg[ln * (GW / 2) + c] = make_double2(g[2 * c], g[2 * c + 1]);
+                }
+                const int valid = (nrows - e0 < 64 ? nrows - e0 : 64) * (GW / 2);    // 16-byte chunks of the block (a wave's LDS operations execute in order)
+#pragma unroll
+                for (int c = 0; c < GW / 2; ++c) {
+                    const int idx = c * 64 + ln;
+                    if (idx < valid) reinterpret_cast<double2*>(Gs)[(size_t)e0 * (GW / 2) + idx] = stg[idx];
+                }
+            }
         } else {
             const int nrw = (NW - MW * DS) * 64;                   // row-writing threads
-            for (int e = (w - MW * DS) * 64 + ln; e < (SH ? 1 : DS) * Np; e += nrw) {     // one set of rows per trajectory when the GPs share lambda
+            for (int e = tiz - MW * DS * 64; e < (SH ? 1 : DS) * Np; e += nrw) {     // one set of rows per trajectory when the GPs share lambda
                 const int a = SH ? 0 : e / Np, j = e - a * Np;
                 double g[GW], qh = 0.0;
 #pragma unroll
@@ -269,7 +323,7 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
                 g[D] = GPMPC_EXP_NEG_INV_C * qh;
 #pragma unroll
                 for (int c = 0; c < GW / 2; ++c)
-                    reinterpret_cast<double2*>(Gs)[((size_t)a * (GW / 2) + c) * Np + j] = make_double2(g[2 * c], g[2 * c + 1]);
+                    reinterpret_cast<double2*>(Gs)[(((size_t)a * (Np >> 1) + (j >> 1)) * (GW / 2) + c) * 2 + (j & 1)] = make_double2(g[2 * c], g[2 * c + 1]);
             }
         }
         GPMPC_PST(3);
@@ -297,11 +351,6 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
         // (unit, row block) segment are reduced and ADDED to the wave's LDS slot at the end of the segment instead of living in
         // 2 NG (1 + 2 D) registers across the whole range: that was what spilled (k_traj_persist<5,4,true,2>: 40 VGPR spills).
         {
-            // columns per batch (KC (D + 1 + ds) doubles of G rows in SGPRs, KC sets of exp temporaries in VGPRs) and per group of
-            // weight loads (two groups in flight): what fits the 128 registers of four waves per SIMD WITHOUT a spill (tools/spill_guard.py)
-            constexpr int KC = (D >= 7 || (NG > 1 && D >= 6)) ? 1 : 2;
-            constexpr int MGc = GPMPC_PERSIST_MG ? GPMPC_PERSIST_MG : ((NG > 1 || D >= 6) ? 2 : 4);
-            static_assert(MGc % KC == 0 && 8 % (2 * MGc) == 0, "segment lengths are multiples of 8 columns");
             // this wave's range [r_lo, r_hi) and the unit it starts in (slot 0 of s_part; slot 1 = the next unit), from the table
             const int r_lo = __builtin_amdgcn_readfirstlane(s_rng[w]), r_hi = __builtin_amdgcn_readfirstlane(s_rng[w + 1]);
             int pos = r_lo, slot = 0, u = __builtin_amdgcn_readfirstlane(s_ga[w]);
@@ -328,7 +377,7 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
 #pragma unroll
                 for (int c = 0; c < MGc; ++c)
 #pragma unroll
-                    for (int q = 0; q < NG; ++q) mga[c][q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs[q], l8, c * Np * 8, 0));
+                    for (int q = 0; q < NG; ++q) mga[c][q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs[q], l8, (c < n ? c : 0) * Np * 8, 0));
                 const int at = SH ? 0 : u;                         // the transform of GP 0 is that of every GP when lambda is shared
                 double hi2[D], qi;
                 {
@@ -346,20 +395,39 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
                 for (int q = 0; q < NG; ++q)
 #pragma unroll
                     for (int m = 0; m < NA; ++m) acc[q][m] = 0.0;
-                const double* Ga = Gl + ((size_t)at * (GW / 2) * Np + j0) * 2;      // chunk 0 of the segment's first column
+                const double* Ga = Gl + ((size_t)at * Np + j0) * GW;                 // the segment's first column pair (j0 is even)
                 // KC columns: rows -> exponents + table reads -> weights x exp, moment sums
-                auto batch = [&](int j, const double (*mw)[NG]) {
+                auto batch = [&](auto kc_tag, int j, const double (*mw)[NG]) {
+                    constexpr int KC = decltype(kc_tag)::value;     // (shadows the kernel's: the tail of a KC = 3 loop runs batches of two)
                     double g[KC][GW];
+#if GPMPC_PERSIST_TOUCH   /* (pair layout only; measured SLOWER: profiles/r05/persist_stamps_touch.txt) */
+                    // Scalar-cache warm-up: one dword of every 64-byte line of the NEXT batch's rows is requested together with this batch's
+                    // rows (same wait), so that the next batch's loads hit the scalar cache (~90 cycles) instead of the L2 (~550: the
+                    // latency four waves per SIMD do not hide, tools/ubench/latency_probe.hip).  Within the segment only (the last batch
+                    // touches itself): nothing is read beyond the trajectory's rows.
+                    unsigned touch[(KC * GW * 8 + 63) / 64];
+                    {
+                        const double* gn = Ga + (size_t)((j + KC < n ? j + KC : j) >> 1) * (2 * GW) + ((j + KC) & 1) * 2;
+                        asm volatile("" : "+s"(gn));
+#pragma unroll
+                        for (int q = 0; q < (KC * GW * 8 + 63) / 64; ++q) touch[q] = ((const unsigned __attribute__((address_space(4)))*)gn)[16 * q];
+                    }
+#endif
                     // (the base goes through an opaque asm per batch: left to see that consecutive batches are adjacent in memory the
                     // compiler merges their loads into 64-byte ones -- 80 SGPRs of rows, the loop's other scalars spilled to VGPR lanes
                     // and read back with 18 v_readlane per iteration)
-                    const double* gb = Ga + (size_t)j * 2;
+                    const double* gb = GPAIR ? Ga + (size_t)(j >> 1) * (2 * GW) + (j & 1) * 2 : Ga + (size_t)j * GW;       // (j is even with KC = 2)
                     asm volatile("" : "+s"(gb));
 #pragma unroll
-                    for (int k = 0; k < D + 1 + NS2; ++k)             // chunk k / 2 of columns j ... j + KC - 1: 16 KC contiguous bytes
+                    for (int k = 0; k < D + 1 + NS2; ++k)             // pair layout: chunk k / 2 of the pair is [column j | column j + 1], 16 bytes each
 #pragma unroll
-                        for (int c = 0; c < KC; ++c) g[c][k] = ((const gpmpc_cdouble*)(gb + ((size_t)(k >> 1) * Np + c) * 2))[k & 1];
+                        for (int c = 0; c < KC; ++c)
+                            g[c][k] = GPAIR ? ((const gpmpc_cdouble*)(gb + (size_t)(k >> 1) * 4 + c * 2))[k & 1] : ((const gpmpc_cdouble*)(gb + (size_t)c * GW))[k];
                     __builtin_amdgcn_sched_barrier(0);
+#if GPMPC_PERSIST_TOUCH
+#pragma unroll
+                    for (int q = 0; q < (KC * GW * 8 + 63) / 64; ++q) asm volatile("" :: "s"(touch[q]));
+#endif
                     double fr[KC], pq[KC], Tv[KC];
                     int ni[KC];
 #pragma unroll
@@ -395,7 +463,8 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
 #if GPMPC_PERSIST_ROTPRIO == 2
                 unsigned long long clk = __builtin_amdgcn_s_memtime();
 #endif
-                for (int jc = 0; jc < n; jc += 2 * MGc) {          // n is a multiple of 8
+                int jc = 0;
+                for (; jc + 2 * MGc <= n; jc += 2 * MGc) {         // n is a multiple of GR (= 2 MGc, or 2 with a tail below)
 #if GPMPC_PERSIST_ROTPRIO
                     // The four waves a SIMD holds of this workgroup are arbitrated by age: left alone the oldest runs ahead and the
                     // youngest finishes 40 % later, the SIMD half empty at the end (stamps: wave 2 109 k cycles, wave 15 165 k for
@@ -424,10 +493,10 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
                             mgb[c][q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs[q], l8, (jc + MGc + c) * Np * 8, 0));
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int c = 0; c < MGc; c += KC) batch(jc + c, &mga[c]);
+                    for (int c = 0; c < MGc; c += KC) batch(std::integral_constant<int, KC>{}, jc + c, &mga[c]);
                     {   // unconditional (the last iteration re-requests its own first group, unused): under a branch the compiler's
                         // wait counts merge both paths and every wait below becomes "all loads done"
-                        const int jn = jc + 2 * MGc < n ? jc + 2 * MGc : jc;
+                        const int jn = jc + 4 * MGc <= n ? jc + 2 * MGc : jc;
 #pragma unroll
                         for (int c = 0; c < MGc; ++c)
 #pragma unroll
@@ -436,7 +505,18 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int c = 0; c < MGc; c += KC) batch(jc + MGc + c, &mgb[c]);
+                    for (int c = 0; c < MGc; c += KC) batch(std::integral_constant<int, KC>{}, jc + MGc + c, &mgb[c]);
+                }
+                if constexpr (KC == 3) {                           // 2 or 4 columns left (their weights are not prefetched: ~2 such tails per wave and step)
+                    for (; jc < n; jc += 2) {
+                        double mt[2][NG];
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+#pragma unroll
+                            for (int q = 0; q < NG; ++q) mt[c][q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs[q], l8, (jc + c) * Np * 8, 0));
+                        __builtin_amdgcn_sched_barrier(0);
+                        batch(std::integral_constant<int, 2>{}, jc, mt);
+                    }
                 }
                 // per-ln combination into the m-moments of this (unit, row block) segment (pair_kernel_sb.h), reduced over rows of 16
                 // lanes and added to the wave's slot of the unit: segments in program order, rows as (0 + 1) + (2 + 3) in the combine
@@ -486,8 +566,10 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
         // every (GP, moment) sum by a ROW of 16 lanes, one lane per wave of the workgroup (round 5: one thread per sum walked the 16
         // waves in a chain of dependent LDS reads, ~3 k cycles of a 9.5 k phase); fixed order: rows as (0 + 1) + (2 + 3), then the
         // 16-lane row sum's tree over the waves
-        for (int o = tiz >> 4; o < DS * NM; o += nthr >> 4) {
-            const int ww = tiz & 15, a = o / NM, m = o - a * NM;
+        int tiz4 = tiz;                                            // (opaque: index arithmetic of this phase is not computed ahead of the column loop and held across it)
+        asm volatile("" : "+v"(tiz4));
+        for (int o = tiz4 >> 4; o < DS * NM; o += nthr >> 4) {
+            const int ww = tiz4 & 15, a = o / NM, m = o - a * NM;
             double v = 0.0;
             if (ww < NW) {
                 const int lo = s_rng[ww], hi = s_rng[ww + 1];
@@ -502,8 +584,8 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
             if (ww == 0) s_z[o] = v;
         }
         GPMPC_LDS_BARRIER();
-        if (tiz < DS * D) {
-            const int a = tiz / D, k = tiz - a * D, nc = 2 * DS + DA;
+        if (tiz4 < DS * D) {
+            const int a = tiz4 / D, k = tiz4 - a * D, nc = 2 * DS + DA;
             const double c = s_c[a], cm = s_cm[a], sf2 = s_sf2[a];
             const double mu = cm * s_ms[a * NV];
             const double Tt = c * s_z[a * NM];
@@ -513,7 +595,7 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
                 A.vars[((size_t)b * (A.H + 1) + t) * DS + a] = var;
             }
             if (GRAD) {
-                const double Bq = s_B[tiz], Ak = s_Ak[tiz], sc = s_sc[tiz];
+                const double Bq = s_B[tiz4], Ak = s_Ak[tiz4], sc = s_sc[tiz4];
                 const double dmu_du = -Bq * cm * s_ms[a * NV + 1 + k];
                 const double dmu_ds = -0.5 * mu * Bq + 0.5 * Bq * Bq * cm * s_ms[a * NV + 1 + D + k];
                 const double dT_du = -4.0 * sc * c * s_z[a * NM + (GRAD ? 1 + k : 0)];
@@ -544,7 +626,11 @@ __global__ __launch_bounds__(1024, 4) void k_traj_persist(PersistArgs A) {
 
 template <int D, int NS2, bool GRAD, int NG = 1>
 static int launch_persist_one(const PersistArgs& a, int waves, hipStream_t s) {
-    const size_t lds = sizeof(double) * ((size_t)D * a.Np + (size_t)a.H * (D - NS2));
+    // dynamic LDS: X, the actions, and -- instances whose column loop runs batches of three (row-major rows) -- the row writers' staging blocks
+    constexpr int DSh = NS2, GWh = (D + 1 + NS2 + 1) & ~1;
+    constexpr bool kc3 = !(D >= 7 || (NG > 1 && D >= 6) || NG >= 4 || (NG == 3 && D >= 5)) && NG == 1 && D <= 5 && GPMPC_PERSIST_KC3;
+    const int mw = (waves >= 16 && 2 * DSh <= waves / 2) ? 2 : 1;
+    const size_t lds = sizeof(double) * ((size_t)D * a.Np + (size_t)((a.H * (D - NS2) + 1) & ~1) + (kc3 ? (size_t)(waves - mw * DSh) * 64 * GWh : 0));
     if (a.Np > GPMPC_PERSIST_MAXNP || a.Np % 64 != 0 || (waves != 8 && waves != 16) || a.H * (D - NS2) > 2 * 512) return GPMPC_E_ARG;
     // static + dynamic LDS beyond the default 64 KB of a launch needs an opt-in (160 KB per CU on gfx950).  The attribute belongs to the
     // function object of the CURRENT device: tracked per device, and the bound uses the instance's own static LDS (NG = 2 / GRAD
@@ -574,7 +660,18 @@ static int launch_persist_one(const PersistArgs& a, int waves, hipStream_t s) {
 // (instantiated up to D = 6: beyond, two GPs' accumulators and lane sums do not fit the 128 registers of four waves per SIMD)
 template <int D>
 int gpmpc_launch_persist_D(bool grad, int ns2, int waves, int ng, const PersistArgs& a, hipStream_t s) {
-    if (ng != 1 && ng != 2) return GPMPC_E_ARG;
+    if (ng < 1 || ng > 4) return GPMPC_E_ARG;
+    // units of THREE / FOUR GPs (round 5: all GPs of a ds = 3 / ds = 4 pack with one lambda in ONE unit -- exponent and exp once per pair for
+    // all of them, 14.25 instead of 17.5 fp64 instructions per pair and GP at D = 5, ds = 4): the instances whose accumulators fit the 128
+    // registers of four waves per SIMD without a spill (tools/spill_guard.py); 16-wave workgroups only (69 KB of static LDS at NG = 4)
+    if constexpr (D == 5) {
+        if (ng == 4 && ns2 == 4) return grad ? launch_persist_one<5, 4, true, 4>(a, waves, s) : launch_persist_one<5, 4, false, 4>(a, waves, s);
+        if (ng == 3 && ns2 == 3) return grad ? launch_persist_one<5, 3, true, 3>(a, waves, s) : launch_persist_one<5, 3, false, 3>(a, waves, s);
+    }
+    if constexpr (D == 4) {
+        if (ng == 3 && ns2 == 3) return grad ? launch_persist_one<4, 3, true, 3>(a, waves, s) : launch_persist_one<4, 3, false, 3>(a, waves, s);
+    }
+    if (ng > 2) return GPMPC_E_ARG;
     if constexpr (D >= 3 && D <= 6) {
         if (ng == 2 && ns2 >= 2) {
             if (ns2 == D - 1) return grad ? launch_persist_one<D, D - 1, true, 2>(a, waves, s) : launch_persist_one<D, D - 1, false, 2>(a, waves, s);

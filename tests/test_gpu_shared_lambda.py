@@ -86,14 +86,16 @@ def test_every_shape_vs_cport_and_vs_distinct_kernels(G, ds, da, monkeypatch):
     np.testing.assert_allclose(of["cost"].cpu().numpy(), o["cost"].cpu().numpy(), rtol=1e-9)
     monkeypatch.delenv("GPMPC_FUSED_SB")
     pack.reload_tuning()
-    # the whole-horizon kernel over units of TWO GPs (traj_persist.h, NG = 2: the plan for ~one trajectory per CU and more of a training
+    # the whole-horizon kernel over units of TWO (or all three / four) GPs (traj_persist.h, NG = 2 ... 4: the plan for ~one trajectory per CU and more of a training
     # set of up to 512 points; instantiated up to D = 6 -- beyond, and for a single GP, the distinct-lambda instance runs), forced onto a
     # small batch, 16 and 8 waves per workgroup: against the C port and, tightly, against the step-per-launch result
     for pw in ("16", "8"):
         monkeypatch.setenv("GPMPC_PERSIST", pw)
         pack.reload_tuning()
         pl = pack.plan(9, H)
-        assert pl["form"] == "persist" and (("," + ("2" if 3 <= ds + da <= 6 else "1") + ">") in pl["kernel"]), pl
+        # GPs per unit: all of them where that instance exists (ds = 4 at D = 5, ds = 3 at D <= 5; 16-wave workgroups), else two
+        ng = 1 if not 3 <= ds + da <= 6 else ((ds if pw == "16" and ((ds == 4 and ds + da == 5) or (ds == 3 and ds + da <= 5)) else 2))
+        assert pl["form"] == "persist" and (f",{ng}>" in pl["kernel"]), pl
         w = G.rollout(pack, pb["x0"][:9], pb["U"][:9], cost)
         _check_vs_cport(w, pb, kinv, [0, 4, 8], f"whole-horizon form ds={ds} da={da} waves={pw}")
         np.testing.assert_allclose(w["means"].cpu().numpy(), res[b_mid]["means"][:9].cpu().numpy(), rtol=1e-9, atol=1e-12)
