@@ -207,6 +207,47 @@ static int build_worklist(int Np, int it, int jt, int ds, int npairs, bool xcd_s
     return e == hipSuccess ? 0 : -1;
 }
 
+// Work list 7: the 256x64 list (unit-contiguous, natural order) whose last K tiles are split into four 256x16 tiles each.  One
+// trajectory of a large training set (the B = 1 solver callbacks) launches n tile workgroups of equal length on `slots` workgroup
+// slots: n = 3264 at N = 4096, ds = 6 on 1024 slots is 3.19 generations -- the last 192 workgroups run alone for a whole workgroup
+// lifetime (30 of 120 us, profiles/r04/fused_stamps_c4_b1.txt).  Split four ways the same columns are 768 workgroups a quarter as long.
+// Built when the tail is a partial generation of at most 60 % (else the list would only add workgroups); same kernel (step_fused.h,
+// Q = 0: a tile's column count is read from its work item).
+static int build_worklist_split_tail(int Np, int ds, int slots, gpmpc_worklist* w) {
+    const int it = 256, jt = 64;
+    int n0 = 0;
+    for (int u = 0; u < ds; ++u)
+        for (int i0 = 0; i0 < Np; i0 += it)
+            for (int j0 = 0; j0 < Np; j0 += jt) { const int j1 = j0 + jt < Np ? j0 + jt : Np; if (j1 > i0) ++n0; }
+    const int K = slots > 0 ? n0 % slots : 0;
+    if (n0 <= slots || K == 0 || K > (slots * 3) / 5) return 1;                  // nothing to gain: not built
+    int* h = (int*)malloc(sizeof(int) * 4 * ((size_t)n0 + 3 * (size_t)K));
+    if (!h) return -1;
+    int n = 0, k0 = 0;
+    for (int u = 0; u < ds; ++u) {
+        w->ustart_host[u] = n;
+        for (int i0 = 0; i0 < Np; i0 += it)
+            for (int j0 = 0; j0 < Np; j0 += jt) {
+                const int j1 = j0 + jt < Np ? j0 + jt : Np;
+                if (j1 <= i0) continue;
+                if (k0 >= n0 - K) {
+                    for (int q = 0; q < 4; ++q) { h[4 * n] = u; h[4 * n + 1] = i0; h[4 * n + 2] = j0 + 16 * q; h[4 * n + 3] = j0 + 16 * q + 16; ++n; }
+                } else { h[4 * n] = u; h[4 * n + 1] = i0; h[4 * n + 2] = j0; h[4 * n + 3] = j1; ++n; }
+                ++k0;
+            }
+    }
+    w->ustart_host[ds] = n;
+    w->contiguous = 1;
+    w->it = it; w->waves = 4; w->jt = jt; w->nunits = ds; w->nwork = n;
+    w->perm_dev = nullptr;
+    hipError_t e = hipMalloc(&w->work_dev, sizeof(int) * 4 * (size_t)n);
+    if (e == hipSuccess) e = hipMemcpy(w->work_dev, h, sizeof(int) * 4 * (size_t)n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&w->ustart_dev, sizeof(int) * (ds + 1));
+    if (e == hipSuccess) e = hipMemcpy(w->ustart_dev, w->ustart_host, sizeof(int) * (ds + 1), hipMemcpyHostToDevice);
+    free(h);
+    return e == hipSuccess ? 0 : -1;
+}
+
 void gpmpc_read_tuning(gpmpc_tuning* t) {
     auto geti = [](const char* name, int unset) { const char* ev = getenv(name); return ev ? atoi(ev) : unset; };
     t->pair_sb = geti("GPMPC_PAIR_SB", -1);
@@ -288,6 +329,13 @@ extern "C" int gpmpc_pack_create(gpmpc_pack** out, int n_train, int state_dim, i
             ok = build_worklist(p->Np, cfg[k][0], cfg[k][1], state_dim, mode ? p->npairs : 0,
                                 mode == 0 && (k == 0 || k == 4) && !p->tune.no_xcd_sort, &p->wl[mode][k]) == 0;
         }
+    // MEASURED NEGATIVE and therefore opt-in (GPMPC_SPLIT_TAIL=1, A/B only): N = 4096, ds = 6, one trajectory 3.65 -> 4.23 ms per rollout (launch 119 -> 138 us on
+    // 3840 tile workgroups, profiles/r05/ab15_split_tail.txt): the 768 narrow workgroups pay a whole prologue each and every workgroup re-reduces 18 % more partial sums.
+    if (ok && action_dim >= 1 && action_dim <= 2 && getenv("GPMPC_SPLIT_TAIL")) {
+        // (workgroup slots of the one-launch form on 256-row tiles: 4 waves per SIMD from D = 6, 5 below -- step_fused.h's launch bounds)
+        const int occ = D >= 6 ? 4 : 5;
+        if (build_worklist_split_tail(p->Np, state_dim, p->num_cu * occ, &p->wl[0][7]) < 0) ok = false;
+    }
     // shared-lambda work lists (pair_kernel_sbs.h): "units" are groups of sh_ng GPs
     if (ok && state_dim >= 2 && action_dim >= 1 && action_dim <= 2) {
         p->sh_ng = gpmpc_sbs_group(state_dim, D);
@@ -334,7 +382,7 @@ extern "C" int gpmpc_pack_destroy(gpmpc_pack* p) {
     gpmpc_lock_destroy(p->lock);
     if (p->pair_ab_dev) (void)hipFree(p->pair_ab_dev);
     for (int mode = 0; mode < 2; ++mode)
-        for (int k = 0; k < 7; ++k) {
+        for (int k = 0; k < 8; ++k) {
             if (p->wl[mode][k].work_dev) (void)hipFree(p->wl[mode][k].work_dev);
             if (p->wl[mode][k].perm_dev) (void)hipFree(p->wl[mode][k].perm_dev);
             if (p->wl[mode][k].ustart_dev) (void)hipFree(p->wl[mode][k].ustart_dev);

@@ -29,9 +29,13 @@ struct PairSbsTraits {
 
 // waves per SIMD the instance is compiled for: 2 VGPRs per accumulator + ~48 for everything else, out of 512
 constexpr int gpmpc_sbs_waves(int NG, int NA) {
-    const int r0 = 2 * NG * NA + 48, regs = r0 < 80 ? 80 : r0;     // (row transform, weights and exp temporaries alone take ~70)
-    const int w = 512 / regs;
-    return w > 8 ? 8 : (w < 1 ? 1 : w);
+    // (row transform and exp temporaries alone take ~50; the two-column batches of round 5 hold 2 NG weights + two sets of exp temporaries,
+    // groups of four GPs the next batch's weights too -- they run at three waves per SIMD: at four the row transform spilled into the loop)
+    const int staged = NA > 1 ? 2 * NG + 12 + (NG >= 4 ? 4 * NG : 0) : 0;
+    const int r0 = 2 * NG * NA + 48 + staged, regs = r0 < 80 ? 80 : r0;
+    int w = 8;
+    while (w > 1 && ((512 / w) / 8) * 8 < regs) --w;              // registers come in blocks of 8: the cap at w waves per SIMD is 8 floor(64 / w)
+    return w;
 }
 
 template <int D, int NG, int NS2, bool GRAD, bool FIRST = false>
@@ -105,6 +109,84 @@ void gpmpc_pair_kernel_sbs(PairSbsArgs A) {
                                     114 VGPRs, still 4 waves per SIMD).  Measured -2...-4 % (C3 sizes with one lambda, B = 256: 26.5 -> 27.4 ms per batch;
                                     N = 1024, B = 256: 7.31 -> 7.60 ms; profiles/r04/ab_shared_prefetch.txt): A/B build only */
 #endif
+#ifndef GPMPC_SBS_STAGED
+#define GPMPC_SBS_STAGED 1       /* round 5: columns in batches of two with the stages pinned (see below); 0: the one-column loop */
+#endif
+        if constexpr (GPMPC_SBS_STAGED && GRAD && !FIRST) {
+            // Round 5 (as traj_persist.h / step_fused.h).  At 3-4 waves per SIMD a wave of the one-column loop -- weights requested, G row
+            // requested, both waited for, exponent, table read, waited for, ~57 instructions of arithmetic -- leaves its SIMD to the others
+            // for ~900 cycles per column, and they have 750 of arithmetic to fill them with: VALU issue 0.61 of its bound at C3 sizes with
+            // one lambda (frac 0.49).  Two columns per batch: the 2 NG weights and both G rows requested together (one vector-memory and one
+            // scalar-memory wait, overlapping), both exponents and table reads (one LDS wait), then 2 NG (2 + D + ds) accumulations.
+            constexpr int KC = 2;
+            typedef const double __attribute__((address_space(4))) gpmpc_cdouble;
+            // one batch of KC columns: G rows -> exponents + table reads -> weights x exp, moment sums
+            auto batch = [&](int jc, const double (*mij)[NG]) {
+                double gr[KC][GW];
+#pragma unroll
+                for (int c = 0; c < KC; ++c) {
+                    const gpmpc_cdouble* __restrict__ gp = (const gpmpc_cdouble*)(Gt + (size_t)(jc + c) * GW);
+#pragma unroll
+                    for (int k = 0; k < D + 1 + NS2; ++k) gr[c][k] = gp[k];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                double fr[KC], Tv[KC];
+                int ni[KC];
+#pragma unroll
+                for (int c = 0; c < KC; ++c) {
+                    double sx = qi + gr[c][D];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) sx = fma(hi2[k], gr[c][k], sx);
+                    const double ax = __builtin_fabs(sx);          // gpmpc_exp_neg_scaled (fast_exp.h), split around the table read
+                    ni[c] = (int)(-ax);
+                    fr[c] = __builtin_amdgcn_fract(ax);
+                    Tv[c] = s_tab[ni[c] & (GPMPC_EXP_N - 1)];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < KC; ++c) {
+                    const double pq = fma(fr[c], fma(fr[c], GPMPC_EXP_A3, GPMPC_EXP_A2), GPMPC_EXP_A1);
+                    const double e = ldexp(fma(Tv[c] * fr[c], pq, Tv[c]), ni[c] >> GPMPC_EXP_BITS);
+#pragma unroll
+                    for (int q = 0; q < NG; ++q) {
+                        const double P = mij[c][q] * e;
+                        acc[q][0] += P;
+#pragma unroll
+                        for (int k = 0; k < D; ++k) acc[q][1 + k] = fma(P, gr[c][k], acc[q][1 + k]);
+#pragma unroll
+                        for (int k = 0; k < NS2; ++k) acc[q][1 + D + k] = fma(P, gr[c][D + 1 + k], acc[q][1 + D + k]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto wload = [&](double (*m)[NG], int jrel) {
+#pragma unroll
+                for (int c = 0; c < KC; ++c)
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) m[c][g] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs[g], lane8, (jrel + c) * Np * 8, 0));
+            };
+            // groups of four GPs (three waves per SIMD: registers to spare): the weights of the NEXT batch are requested before this one is
+            // evaluated -- two register sets in alternation, unconditional refill (the last batch re-requests itself)
+            constexpr bool MPRE = NG >= 4;
+            if constexpr (MPRE) {
+                double ma[KC][NG], mb[KC][NG];
+                wload(ma, 0);
+                for (int jc = jstart; jc < j1; jc += 2 * KC) {    // (j1 - jstart is a multiple of 4: tile widths and N rounded up to 8)
+                    wload(mb, jc - jstart + KC);
+                    __builtin_amdgcn_sched_barrier(0);
+                    batch(jc, ma);
+                    wload(ma, (jc + 2 * KC < j1 ? jc + 2 * KC : jc) - jstart);
+                    __builtin_amdgcn_sched_barrier(0);
+                    batch(jc + KC, mb);
+                }
+            } else {
+                for (int jc = jstart; jc < j1; jc += KC) {
+                    double mij[KC][NG];
+                    wload(mij, jc - jstart);
+                    batch(jc, mij);
+                }
+            }
+        } else {
         constexpr bool PRE = GPMPC_SBS_PREFETCH && CU == 1;
         double mnext[NG];
         if (PRE) {
@@ -152,6 +234,7 @@ void gpmpc_pair_kernel_sbs(PairSbsArgs A) {
                     }
                 }
             }
+        }
         }
     }
 

@@ -975,17 +975,22 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     // N = 768, B = 72 2.35 vs 2.58; N = 600, B = 96 2.36 vs 2.64)
     const long fsb_max = shared_on ? 7000 : (p->wl[0][2].nwork <= 200 ? 7000 : 4700);
     const bool fsb_take = fsb_can && tn.fused_sb != 0 && wg2 <= fsb_max;
-    const bool big128 = !big && !fsb_take && sb_ok && tb2 && p->Np > 512 && (long)((B + 1) / 2) * p->wl[0][4].nwork >= 1600;
+    // (Np = 512 -- two row tiles -- runs its mid range on the 256x128 tiling too: B = 288 / 320 / 384 / 640 x1.14 / 1.10 / 1.09 / 1.15 over 256x256,
+    // profiles/r05/autotune_grid_second.txt)
+    const bool mid512 = p->Np == 512 && B < 768 && !fsb_take && sb_ok && tb2 && (long)((B + 1) / 2) * p->wl[0][4].nwork >= 1600;
+    const bool big128 = (!big || mid512) && !fsb_take && sb_ok && tb2 && (p->Np > 512 || mid512) && (long)((B + 1) / 2) * p->wl[0][4].nwork >= 1600;
     r->sb = (sb_ok && (big || mid)) ? 1 : 0;
     const bool many = (long)p->wl[0][1].nwork > 256L * p->ds;        // > 256 one-wave tiles per GP (N >= 1472)
-    r->tiling = big ? 0 : (big128 ? 4 : (mid ? 2 : (many ? 3 : 1)));
+    r->tiling = (big && !(mid512 && big128)) ? 0 : (big128 ? 4 : (mid ? 2 : (many ? 3 : 1)));
     if (r->tiling == 2 && narrow_ok && wg2 < 1000)           // 32 columns from ~300 workgroups of 64, 16 below (while the partial sums
         r->tiling = (wg2 >= 300 || p->wl[0][6].nwork > 1300) ? 5 : 6;      // of a trajectory stay within ~1300)
     // A training set whose LAST row tile is a quarter or half tile (Np = 320, 384: N = 257...384): its 256x64 workgroups carry one or
     // two waves of four; on 32 columns there are twice as many, half as long -- measured with gpmpc_pack_autotune (round 4,
     // profiles/r04/autotune_small_n.txt): N = 300, ds = 4, B = 48 / 64 / 96 / 128 / 160 x1.07 / 1.08 / 1.09 / 1.10 / 1.07, ds = 2,
     // B = 128 / 160 x1.06; N = 400 (Np = 448) and N = 512: level, N = 200 (one row tile): level.
-    if (r->tiling == 2 && fsb_take && p->Np > 256 && p->Np <= 384 && wg2 >= 1000) r->tiling = 5;
+    // (not with one lambda for all GPs: there the 64-column tiles are ahead -- round 5 grid, profiles/r05/autotune_grid_first_shared.txt:
+    // N = 300, ds = 4, B = 128 0.58 | 0.38 ms, ds = 2, B = 320 0.49 | 0.33)
+    if (r->tiling == 2 && fsb_take && p->Np > 256 && p->Np <= 384 && wg2 >= 1000 && !shared_on) r->tiling = 5;
     if (tn.pair_sb >= 0) {                                   // 0 = staged kernel, 1 = scalar broadcast
         r->sb = (tn.pair_sb != 0 && sb_ok) ? 1 : 0;
         r->tiling = r->sb ? (big ? 0 : (big128 ? 4 : 2)) : (big ? 0 : (many ? 3 : 1));
@@ -1042,7 +1047,8 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     // B = 8 1.51 | 1.38 | 1.91; N = 768, B = 16 0.64 | 0.73 | 0.72 (profiles/r03/ab_fused_shared.txt)
     r->fng = p->sh_ng;
     if (p->sh_ng > 2 && p->ds % 2 == 0 && p->wl_sh[3].work_dev && wg2 < 4200) r->fng = 2;
-    if (r->sb && r->fused == 2 && r->tiling == 2 && shared_on && (wg2 >= (r->fng == 2 ? 1000 : 2200) || tn.fused_sb == 1)) {
+    // (two GPs: from ~700 tile workgroups -- N = 300, ds = 2, B = 64 / 128 0.195 / 0.205 -> 0.155 / 0.183 ms, profiles/r05/autotune_grid_second_shared.txt)
+    if (r->sb && r->fused == 2 && r->tiling == 2 && shared_on && (wg2 >= (r->fng == 2 ? (p->ds == 2 ? 700 : 1000) : 2200) || tn.fused_sb == 1)) {
         // one lambda for all GPs AND the one-launch form: its tile workgroups take groups of sh_ng GPs (step_fused.h, NG > 1) on the
         // shared 256x64 list.  Three forms compete for such a pack (profiles/r03/ab_fused_shared.txt, ms per batch: groups of GPs in one
         // launch | one GP per tile workgroup in one launch | shared-lambda pair kernel, two launches): N = 1024, B = 8 0.81 | 0.67 | -,
@@ -1065,6 +1071,11 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
         r->nwork = p->ds * p->sh_tiles[r->sh_list];           // partial sums per trajectory: [GP][tile]
         r->rgroup = r->sh_list != 1 ? ((tn.rgroup >= 1 && tn.rgroup <= 16) ? tn.rgroup : 4) : 1;
     }
+    // ONE trajectory on 256x64 tiles whose last workgroup generation would be mostly empty: the list with the split tail (pack.hip, work list 7)
+    if (r->fused == 2 && r->tiling == 2 && !r->shared && B == 1 && !shape && tn.tiling < 0 && p->wl[0][7].work_dev) {
+        r->tiling = 7;
+        r->nwork = p->wl[0][7].nwork;
+    }
     // Columns per iteration of the scalar-broadcast kernel: 4 on the 256x64 tiling (mid-size batches: latency tolerance of
     // the partly filled generations, pair_kernel_sb.h), 1 on full launches.
     // (tools/env_ab.py --var GPMPC_SB_UNROLL: +8...14 % up to ~2 generations of workgroups, -4 % from ~4 on)
@@ -1083,18 +1094,35 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     // B = 512 2.11 | 1.93 | 1.80; N = 300, ds = 2, B = 256 0.57 | 0.43 | 0.47; N = 200, ds = 2, B = 1024 0.58 | 0.57 | 0.48; N = 400, ds = 3,
     // da = 2, B = 256 2.11 | 1.68 | 2.54; N = 512, ds = 3, H = 20, B = 256 3.01 | 2.49 | 4.11; N = 640, B = 256 2.75 | 3.03; N = 1024,
     // H = 20, B = 256 10.9 | 14.4 (every workgroup streams all of M from L2 / Infinity Cache each step: 6.5 TB/s at N = 1024).
-    // One 16-wave workgroup per CU, so the cost goes in generations of num_cu trajectories: taken while the last generation is
-    // at least ~0.7 (one generation) / ~0.9 full; 8-wave workgroups (two per CU) from two full sets on.
+    // Round 5 (the kernel is x1.3-1.6 faster than the one the round-4 thresholds were fitted to; re-measured with gpmpc_pack_autotune over
+    // N = 200 ... 640, B = 64 ... 1024: profiles/r05/autotune_grid_first*.txt, autotune_grid.txt): a COST comparison instead of fill thresholds.
+    // One 16-wave workgroup per CU (or two of 8 waves), so the kernel's time goes in generations of num_cu (2 num_cu) trajectories; a partly
+    // filled generation is shorter (less contention for the L2: N = 300, ds = 4: B = 128 / 192 / 256 0.56 / 0.59 / 0.69 ms): 0.64 + 0.36 fill of
+    // a full one.  In units of a full 16-wave generation: cost16 = generations (last one discounted), cost8 = r8 x the same over 2 num_cu slots,
+    // r8 = 1.6 (light trajectories) ... 2.0; the step-per-launch forms cost (B / num_cu) x inv_e(Np), inv_e = how much less efficient per
+    // trajectory they are than a full generation of this kernel: 2.15 at Np = 256 (break-even B ~ 96), 1.55 at 320 (~140), 1.36 at 448 (~175),
+    // 1.16 at 512 (~200), 1.05 at 640 (full generations only); with one lambda x1.25 (units of 3 / 4 GPs).  Np >= 512 beyond two generations:
+    // never (every workgroup streams all of M each step; the 256x128 / 256x256 pair kernels are ahead: N = 512, B = 640 6.2 | 5.4 ms).
     {
         const int cu = p->num_cu > 0 ? p->num_cu : 256;
-        const int g16 = (B + cu - 1) / cu, g8 = (B + 2 * cu - 1) / (2 * cu);
-        const double fill16 = (double)B / ((double)g16 * cu), fill8 = (double)B / ((double)g8 * 2 * cu);
+        auto gens_cost = [](int Bn, int slots) {
+            const int full = Bn / slots, rem = Bn - full * slots;
+            return (double)full + (rem > 0 ? 0.64 + 0.36 * (double)rem / slots : 0.0);
+        };
+        const bool psh = shared_on && p->ds >= 2 && D >= 3 && D <= 6;                   // (= pshared below)
+        const bool all_in_one = psh && ((p->ds == 4 && D == 5) || (p->ds == 3 && D <= 5));   // 16-wave workgroups run ALL GPs of the pack in one unit
+        const double work = (double)p->ds * p->Np * p->Np;
+        double r8 = 1.4 + 4.0e-12 * work * work;                                         // (grid: 1.46 at N = 200, ds = 2; 1.53 at 300 / 2; ~1.7 at 200 / 4; > 2.05 at 300 / 4)
+        if (r8 > 2.2) r8 = 2.2;
+        if (all_in_one) r8 *= 1.25;                                                      // (8-wave workgroups fall back to units of two GPs)
+        const double cost16 = gens_cost(B, cu), cost8 = r8 * gens_cost(B, 2 * cu);
+        const int Npq = p->Np;
+        double inv_e = Npq <= 256 ? (p->ds <= 2 ? 2.15 : 1.95) : (Npq <= 320 ? 1.55 : (Npq <= 384 ? 1.50 : (Npq <= 448 ? 1.45 : (Npq <= 512 ? 1.16 : (Npq <= 576 ? 1.10 : 1.05)))));
+        if (psh) inv_e *= p->ds <= 2 ? 1.0 : (Npq <= 448 ? 1.25 : 1.10);
+        if (Npq >= 512 && B > 2 * cu && !psh) inv_e = 0.9;
+        const double cost_spl = (double)B / cu * inv_e;
         int pw = 0;
-        // thresholds re-measured with gpmpc_pack_autotune on the column-clipped kernel (profiles/r04/autotune_persist_threshold.txt): one
-        // generation of 16-wave workgroups from 0.6 (Np <= 256: B = 160 x1.13) / 0.7 (Np <= 448) / 0.9 (Np = 512: B = 192 was x0.87)
-        // trajectories per CU; two generations and more from 0.75 (N = 300, B = 384 x1.15), 8-wave workgroups from 0.85 (B = 448 x1.20)
-        if (fill8 >= 0.85) pw = 8;
-        else if (fill16 >= (g16 == 1 ? (p->Np <= 256 ? 0.6 : (p->Np <= 448 ? 0.7 : 0.9)) : 0.75)) pw = 16;
+        if ((cost16 <= cost8 ? cost16 : cost8) < 0.97 * cost_spl) pw = cost8 < cost16 ? 8 : 16;
         if (tn.persist == 8 || tn.persist == 16) pw = tn.persist;
         // With ONE lambda for all GPs the step-per-launch forms share exponent and exp across the GPs of a pair, this kernel does not
         // (yet): from three GPs on they are ahead of it (shared packs, ms per batch, step-per-launch | 16 waves | 8 waves: N = 300, ds = 4,
@@ -1116,7 +1144,7 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
         // (never for the sub-batches of a split call: they run the launches of the WHOLE batch's plan -- a sub-batch that happened to fit
         // this kernel used to come back with this branch's work-list fields and the whole batch's form: an empty grid)
         if (!shape && diag && !lowprec && p->da >= 1 && p->da <= 2 && p->Np <= GPMPC_PERSIST_MAXNP_HOST && H * p->da <= 1024 && tn.persist != 0 &&
-            pw && (tn.persist > 0 || (p->Np <= (pshared ? 448 : 512) && D <= 6 && !shared_ahead && !form_forced))) {
+            pw && (tn.persist > 0 || (p->Np <= 640 && D <= 6 && !shared_ahead && !form_forced))) {
             r->fused = 3; r->sb = 0; r->shared = 0; r->tb = 1; r->rgroup = 1; r->colunroll = 1; r->fq = 1;
             r->pwaves = pw;
             // units of two GPs; ALL GPs of the pack in one unit where that instance exists (traj_persist.h: ds = 4 at D = 5, ds = 3 at D <= 5;
@@ -1182,7 +1210,9 @@ static int split_count(const gpmpc_pack* p, const RollPlan& r, int B, bool lowpr
         // ... but only from ~800 tile workgroups per launch on (gpmpc_pack_autotune, round 4: N = 200, ds = 2, B = 64 and ds = 4, B = 32
         // -- 512 tile workgroups -- run x1.21 faster unsplit; N = 200, ds = 4, B = 64 and everything larger keeps two), and a pair of
         // trajectories of a large training set splits too (N = 2048, B = 2: x1.04)
-        const long wgs = (long)B * r.nwork;
+        // (groups of GPs per tile workgroup: count the workgroups, not the partial sums -- N = 300, ds = 2 with one lambda, B = 128: 768 workgroups,
+        // 0.210 ms in two branches, 0.184 in one)
+        const long wgs = (long)B * (r.shared && r.fng > 1 ? r.nwork / r.fng : r.nwork);
         S = ((B >= 4 && wgs >= 800) || (B >= 2 && wgs >= 1000 && wgs <= 2500)) ? 2 : 1;
     } else if (mid && B >= 4) {
         S = B / 2 < GPMPC_MAX_SPLIT ? B / 2 : GPMPC_MAX_SPLIT;
@@ -1237,7 +1267,7 @@ extern "C" int gpmpc_plan_describe(const gpmpc_pack* p, int B, int H, unsigned f
     GraphModeGuard mode((flags & GPMPC_USE_GRAPH) ? 1 : 0);
     plan_rollout(p, B, H, grad, true, &r, lowprec);
     const int S = split_count(p, r, B, lowprec, (flags & GPMPC_USE_GRAPH) == 0, 0, H, grad ? 1 : 0);
-    static const int cfg[7][2] = {{256, 256}, {64, 64}, {256, 64}, {64, 128}, {256, 128}, {256, 32}, {256, 16}};
+    static const int cfg[8][2] = {{256, 256}, {64, 64}, {256, 64}, {64, 128}, {256, 128}, {256, 32}, {256, 16}, {256, 64}};
     const int D = p->D, ds = p->ds;
     char kern[160];
     const char* form;
@@ -1247,7 +1277,7 @@ extern "C" int gpmpc_plan_describe(const gpmpc_pack* p, int B, int H, unsigned f
         snprintf(kern, sizeof(kern), "k_traj_persist<%d,%d,%s,%d>x%dwaves", D, ds, grad ? "true" : "false", r.png, r.pwaves);
         wgs = B;
     } else if (r.fused == 2) {
-        const int q = r.tiling == 2 ? 0 : cfg[r.tiling][1], ng = r.shared ? r.fng : 1;
+        const int q = (r.tiling == 2 || r.tiling == 7) ? 0 : cfg[r.tiling][1], ng = r.shared ? r.fng : 1;
         const gpmpc_worklist& wsh = p->wl_sh[(r.fng == 2 && p->sh_ng != 2) ? 3 : 1];
         form = r.shared ? "fused_sb_shared" : "fused_sb";
         snprintf(kern, sizeof(kern), "k_step_fused<%d,%d,%s,%d,%d>", D, ds, grad ? "true" : "false", q, ng);
@@ -1386,7 +1416,7 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
         F.gscr = r.fused == 2 ? (double*)(ws + r.off_G) : nullptr;
         F.ncol = p->ncol_dev;
         for (int t = 1; t <= H; ++t) {
-            const int rc = timed_launch(GPMPC_TIME_FUSED, s, [&] { return launch_step_fused(p->D, grad, p->ds, r.fused == 2 ? (r.tiling == 2 ? 0 : wl.jt) : r.fq, fsh ? r.fng : 1, F, t, s); });
+            const int rc = timed_launch(GPMPC_TIME_FUSED, s, [&] { return launch_step_fused(p->D, grad, p->ds, r.fused == 2 ? ((r.tiling == 2 || r.tiling == 7) ? 0 : wl.jt) : r.fq, fsh ? r.fng : 1, F, t, s); });
             if (rc != GPMPC_OK) return rc;
         }
         A.part += (size_t)(H & 1) * B * nwg * r.nm;          // the tail finishes step H from the parity the last launch wrote

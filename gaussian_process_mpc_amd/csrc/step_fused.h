@@ -255,7 +255,7 @@ void k_step_fused(FusedArgs A, int t) {
         for (int k = 0; k < D; ++k) xrow[k] = A.XT[(size_t)k * Np + (ir < Np ? ir : Np - 1)];
         if (w == 0) {
 #pragma unroll
-            for (int k = 0; k < D; ++k) xcol[k] = A.XT[(size_t)k * Np + j0 + (lane & (NC - 1))];
+            for (int k = 0; k < D; ++k) xcol[k] = A.XT[(size_t)k * Np + (j0 + (lane & (NC - 1)) < Np ? j0 + (lane & (NC - 1)) : Np - 1)];      // (clamped: a narrow tile of list 7 may start within NC columns of the end)
         }
     }
     if (role == 0 && !SB) {
@@ -570,7 +570,8 @@ void k_step_fused(FusedArgs A, int t) {
                 }
             } else {
             const int ncw = __builtin_amdgcn_readfirstlane(ncw_v);
-            const int ncl = ncw - j0 < NC ? ncw - j0 : NC;                   // columns of this tile that carry weight (a multiple of 8, or <= 0)
+            const int nct = j1 - j0 < NC ? j1 - j0 : NC;                      // (work list 7: the last tiles of the list are 16 columns wide)
+            const int ncl = ncw - j0 < nct ? ncw - j0 : nct;                  // columns of this tile that carry weight (a multiple of 8, or <= 0)
 #if GPMPC_FUSED_STAGED
             // Round 5 (as traj_persist.h): a wave of this loop is bound by its own latency chain, not by issue -- the compiler's schedule
             // of the four-column body waited for the G rows twice, for the exp table four times and for the weights of the SAME

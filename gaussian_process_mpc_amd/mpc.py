@@ -64,7 +64,7 @@ class RiskSensitiveMPC:
         # lock-step multi-start solve (extension; multistart.py): K starts, tick budget, seed of the sampled starts
         self.n_starts = 1
         self.multistart_options = {"max_ticks": 150, "history": 6, "gtol": 1e-4, "ftol": 1e-10, "spread": 1.0, "seed": 0, "warm": True,
-                                   "patience": 8}
+                                   "patience": 8, "line_points": 4}      # 4 step lengths per start and tick: one batch of 4 K plans
         self.last_solve_info = None
         self._solve_count = 0
 
@@ -256,22 +256,24 @@ class RiskSensitiveMPC:
                 return rollout_fullcov(pack, x0b, Ub, cp, want_grad=True)
             return rollout(pack, x0b, Ub, cp, want_grad=True, want_traj=False, graph=graph)
 
-        def evaluate(X):
-            U = np.ascontiguousarray(X.reshape(K, H, da))
+        def evaluate(X):                                                  # (K, n), or (S K, n): S step lengths per start
+            nb = X.shape[0]
+            U = np.ascontiguousarray(X.reshape(nb, H, da))
             if dist is not None:
                 from .parallel import sharded_rollout
                 Ud = torch.as_tensor(U, device=self.device)
                 c, g = sharded_rollout(lambda x0b, Ub: run(x0b, Ub, False), cs, Ud, dist)
-                return c.cpu().numpy(), g.cpu().numpy().reshape(K, n)
+                return c.cpu().numpy(), g.cpu().numpy().reshape(nb, n)
             r = run(cs, U, True)
             if "cost_grad" in r:                                          # cost and gradient in ONE device-to-host copy
                 cg = r["cost_grad"].cpu().numpy()
-                return cg[:K], cg[K:].reshape(K, n)
-            return r["cost"].cpu().numpy(), r["grad"].cpu().numpy().reshape(K, n)
+                return cg[:nb], cg[nb:].reshape(nb, n)
+            return r["cost"].cpu().numpy(), r["grad"].cpu().numpy().reshape(nb, n)
 
         x, info = lockstep_lbfgs(evaluate, X0, np.asarray(lb, dtype=np.float64), np.asarray(ub, dtype=np.float64),
                                  max_ticks=int(opt.get("max_ticks", 150)), history=int(opt.get("history", 8)),
-                                 gtol=float(opt.get("gtol", 1e-4)), ftol=float(opt.get("ftol", 1e-10)), patience=opt.get("patience"))
+                                 gtol=float(opt.get("gtol", 1e-4)), ftol=float(opt.get("ftol", 1e-10)), patience=opt.get("patience"),
+                                 line_points=int(opt.get("line_points", 1)))
         info["starts"] = K
         info["sharded_over"] = dist.get_world_size() if dist is not None else 1
         self.last_solve_info = info

@@ -55,14 +55,17 @@ def _two_loop(g, S, Y, rho, cnt):
     return -q
 
 
-def lockstep_lbfgs(evaluate, X0, lb, ub, max_ticks=300, history=8, gtol=1e-4, ftol=1e-10, c1=1e-4, min_step=1e-12, patience=None):
+def lockstep_lbfgs(evaluate, X0, lb, ub, max_ticks=300, history=8, gtol=1e-4, ftol=1e-10, c1=1e-4, min_step=1e-12, patience=None,
+                   line_points=1):
     """Minimise K copies of a bounded problem from the rows of X0, one ``evaluate`` per tick.
 
     evaluate(X (K, n)) -> (f (K,), g (K, n)); non-finite values are allowed (a plan whose risk-sensitive log-determinant
     does not exist returns NaN, src/mpc.py:183): such a trial point is rejected like a failed Armijo test, a start whose FIRST
     point is non-finite is dropped.  ``patience`` (ticks, optional): once the start that currently holds the lowest value has
     converged AND row 0 (the reference's own start) has finished, the others get this many more ticks before the search ends (a receding-horizon controller re-solves at the next
-    step: the stragglers of a lock-step search are the starts least likely to matter).  Returns (x_best, info) with info = {f (K,), x (K, n), ticks, evaluations, converged (K,),
+    step: the stragglers of a lock-step search are the starts least likely to matter).  ``line_points`` = S > 1: every tick evaluates S
+    step lengths per start at once (alpha, alpha / 2, ... -- the line-search evaluations of a solver iteration as ONE batch of K S
+    plans) and takes the lowest value that passes the Armijo test: fewer ticks, each a larger batch.  Returns (x_best, info) with info = {f (K,), x (K, n), ticks, evaluations, converged (K,),
     alive (K,), best}."""
     X = np.clip(np.asarray(X0, dtype=np.float64), lb, ub)
     K, n = X.shape
@@ -108,12 +111,29 @@ def lockstep_lbfgs(evaluate, X0, lb, ub, max_ticks=300, history=8, gtol=1e-4, ft
                     break
             else:
                 best_done_at = None
-        ft, gt = evaluate(np.where(done[:, None], X, XT))
-        ft, gt = np.asarray(ft, dtype=np.float64).reshape(K), np.asarray(gt, dtype=np.float64).reshape(K, n)
+        S_ = int(line_points)
+        if S_ <= 1:
+            ft, gt = evaluate(np.where(done[:, None], X, XT))
+            ft, gt = np.asarray(ft, dtype=np.float64).reshape(K), np.asarray(gt, dtype=np.float64).reshape(K, n)
+            step = XT - X
+            ok = np.isfinite(ft) & np.isfinite(gt).all(axis=1) & ~done
+            ok &= ft <= F + c1 * np.einsum("kn,kn->k", G, step)
+        else:
+            # S step lengths per start in one batch of K S plans, row s K + k = start k at alpha_k / 2^s
+            scale = 0.5 ** np.arange(S_)
+            XS = np.clip(X[None] + (A[None, :, None] * scale[:, None, None]) * D[None], lb, ub)
+            XS = np.where(done[None, :, None], X[None], XS)
+            fs, gs = evaluate(XS.reshape(S_ * K, n))
+            fs, gs = np.asarray(fs, dtype=np.float64).reshape(S_, K), np.asarray(gs, dtype=np.float64).reshape(S_, K, n)
+            steps = XS - X[None]
+            good = np.isfinite(fs) & np.isfinite(gs).all(axis=2) & (fs <= F[None] + c1 * np.einsum("kn,skn->sk", G, steps))
+            pick = np.argmin(np.where(good, fs, np.inf), axis=0)          # the lowest value among the step lengths that pass
+            rows = np.arange(K)
+            ok = good[pick, rows] & ~done
+            ft, gt, XT = fs[pick, rows], gs[pick, rows], XS[pick, rows]
+            step = XT - X
+            A = np.where(ok, A * scale[pick], A * scale[-1])              # (a failing start continues below its smallest trial)
         ticks += 1
-        step = XT - X
-        ok = np.isfinite(ft) & np.isfinite(gt).all(axis=1) & ~done
-        ok &= ft <= F + c1 * np.einsum("kn,kn->k", G, step)
         shrink = ~ok & ~done
         if ok.any():
             i = np.where(ok)[0]

@@ -68,7 +68,9 @@ def test_fuzz_whole_horizon_form_vs_cport(G, seed):
     H = int(rng.integers(1, 12))
     B = int(rng.choice([200, 256, 500, 512, 1024]))      # ~0.7-1 and ~2, 4 trajectories per CU (256 CUs): the sizes the plan takes this form at
     if N > 448 and B == 200:
-        B = 256                                           # (padded size 512: taken from ~0.9 trajectories per CU on)
+        B = 256                                           # (padded size 512: taken from ~0.8 trajectories per CU on)
+    if N > 448 and B > 512:
+        B = 512                                           # (... and up to two generations: beyond, the wide pair kernels are ahead -- plan_rollout, round 5)
     gamma = float(rng.choice([-1.0, 1e-5, 0.0, 0.5]))
     pb = synth_problem(600 + seed, N, ds, da, H, B)
     kinv = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"]).Ky_inv.numpy()

@@ -322,6 +322,15 @@ def test_lockstep_multistart_reaches_the_bounded_optima_scipy_finds():
     assert np.isclose(_rosen_batch(x[None])[0][0], info["f"].min()) and (x <= ub + 1e-15).all()
     x2, info2 = lockstep_lbfgs(_rosen_batch, X0, lb, ub, max_ticks=2000, gtol=1e-6)      # deterministic: same bits
     assert np.array_equal(x, x2) and np.array_equal(info["f"], info2["f"])
+    # four step lengths per start and tick (the line-search evaluations of an iteration as ONE batch of 4 K plans): fewer ticks, same optima
+    shapes = []
+
+    def ev4(X):
+        shapes.append(X.shape)
+        return _rosen_batch(X)
+    x4, info4 = lockstep_lbfgs(ev4, X0, lb, ub, max_ticks=2000, gtol=1e-6, line_points=4)
+    assert info4["converged"].all() and info4["ticks"] < info["ticks"] and set(shapes[1:]) == {(48, n)} and shapes[0] == (12, n)
+    np.testing.assert_allclose(info4["f"], info["f"], rtol=1e-6)
 
     def with_nan(X):
         f, g = np.sum((X - 0.3) ** 2, axis=1), 2 * (X - 0.3)
