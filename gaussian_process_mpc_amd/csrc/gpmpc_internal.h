@@ -83,7 +83,7 @@ struct gpmpc_pack {
     void* lock;                // host lock of the pack's own streams / events / caches (std::recursive_mutex, step.hip::PackGuard)
     // [0: variance units only | 1: + cross units][0: 256x256 tiles | 1: 64x64 | 2: 256x64 | 3: 64x128 | 4: 256x128 | 5: 256x32 | 6: 256x16
     //  (4...6: mode 0 only)]
-    gpmpc_worklist wl[2][8];   // [7] (diagonal rollout only): the 256x64 list with its LAST tiles split into 256x16 ones (one trajectory of a large training set, pack.hip)
+    gpmpc_worklist wl[2][8];   // [7] (diagonal rollout only, D >= 6): balanced runs of up to 256 columns, one workgroup generation per trajectory (pack.hip)
     // shared-lambda path (pair_kernel_sbs.h): every GP has bit-identical length-scales (detected at gpmpc_pack_build)
     int shared_lambda;
     int sh_ng;                 // GPs per workgroup

@@ -207,41 +207,49 @@ static int build_worklist(int Np, int it, int jt, int ds, int npairs, bool xcd_s
     return e == hipSuccess ? 0 : -1;
 }
 
-// Work list 7: the 256x64 list (unit-contiguous, natural order) whose last K tiles are split into four 256x16 tiles each.  One
-// trajectory of a large training set (the B = 1 solver callbacks) launches n tile workgroups of equal length on `slots` workgroup
-// slots: n = 3264 at N = 4096, ds = 6 on 1024 slots is 3.19 generations -- the last 192 workgroups run alone for a whole workgroup
-// lifetime (30 of 120 us, profiles/r04/fused_stamps_c4_b1.txt).  Split four ways the same columns are 768 workgroups a quarter as long.
-// Built when the tail is a partial generation of at most 60 % (else the list would only add workgroups); same kernel (step_fused.h,
-// Q = 0: a tile's column count is read from its work item).
-static int build_worklist_split_tail(int Np, int ds, int slots, gpmpc_worklist* w) {
-    const int it = 256, jt = 64;
-    int n0 = 0;
-    for (int u = 0; u < ds; ++u)
-        for (int i0 = 0; i0 < Np; i0 += it)
-            for (int j0 = 0; j0 < Np; j0 += jt) { const int j1 = j0 + jt < Np ? j0 + jt : Np; if (j1 > i0) ++n0; }
-    const int K = slots > 0 ? n0 % slots : 0;
-    if (n0 <= slots || K == 0 || K > (slots * 3) / 5) return 1;                  // nothing to gain: not built
-    int* h = (int*)malloc(sizeof(int) * 4 * ((size_t)n0 + 3 * (size_t)K));
+// Work list 7, "balanced runs" (round 5): one trajectory of a large training set (the B = 1 solver callbacks) on 256x64 tiles launches
+// n equal workgroups on `slots` workgroup slots -- N = 4096, ds = 6: 3264 on 1024, i.e. 3.19 generations of 30 us workgroups, the last one
+// a fifth full (30 of 120 us, profiles/r04/fused_stamps_c4_b1.txt), and every workgroup pays a 7 us prologue for 23 us of columns.
+// Here every 256-row tile row of every GP is cut into RUNS of up to 256 columns -- the longest run length L for which the whole
+// list still fits ONE generation: sum over (GP, tile row) of ceil(span / L) <= slots -- each run its own work item {unit, i0, j0, j1}
+// (multiples of 8 columns; step_fused.h, Q = 256, reads a run's length from its item): one generation per trajectory, a third of the
+// prologues.  (A first attempt that only split the LAST partial generation into 256x16 tiles was slower: 3.65 -> 4.23 ms,
+// profiles/r05/ab15_split_tail.txt.)  Returns 1 when the list is not worth building (the plain list is about one generation already).
+static int build_worklist_runs(int Np, int ds, int slots, gpmpc_worklist* w) {
+    const int it = 256;
+    int n64 = 0;
+    for (int i0 = 0; i0 < Np; i0 += it) n64 += (Np - (i0 / 64) * 64 + 63) / 64;
+    n64 *= ds;
+    if (slots < 64 || n64 <= slots + slots / 10) return 1;
+    auto count = [&](int L) { int c = 0; for (int i0 = 0; i0 < Np; i0 += it) { const int span = Np - i0; c += (span + L - 1) / L; } return c * ds; };
+    int L = 8;
+    while (L < 256 && count(L) > slots) L += 8;
+    if (count(L) > slots) return 1;                                      // more than one generation even with the longest runs
+    const int n = count(L);
+    int* h = (int*)malloc(sizeof(int) * 4 * (size_t)n);
     if (!h) return -1;
-    int n = 0, k0 = 0;
+    int k = 0;
     for (int u = 0; u < ds; ++u) {
-        w->ustart_host[u] = n;
-        for (int i0 = 0; i0 < Np; i0 += it)
-            for (int j0 = 0; j0 < Np; j0 += jt) {
-                const int j1 = j0 + jt < Np ? j0 + jt : Np;
-                if (j1 <= i0) continue;
-                if (k0 >= n0 - K) {
-                    for (int q = 0; q < 4; ++q) { h[4 * n] = u; h[4 * n + 1] = i0; h[4 * n + 2] = j0 + 16 * q; h[4 * n + 3] = j0 + 16 * q + 16; ++n; }
-                } else { h[4 * n] = u; h[4 * n + 1] = i0; h[4 * n + 2] = j0; h[4 * n + 3] = j1; ++n; }
-                ++k0;
+        w->ustart_host[u] = k;
+        for (int i0 = 0; i0 < Np; i0 += it) {
+            const int span = Np - i0, runs = (span + L - 1) / L;
+            int j = i0;
+            for (int q = 0; q < runs; ++q) {                            // equal runs, multiples of 8 columns, the remainder spread over the first ones
+                int len = ((span / runs) / 8) * 8;
+                const int extra = (span - len * runs) / 8;              // runs that take 8 more columns
+                if (q < extra) len += 8;
+                if (q == runs - 1) len = Np - j;
+                h[4 * k] = u; h[4 * k + 1] = i0; h[4 * k + 2] = j; h[4 * k + 3] = j + len; ++k;
+                j += len;
             }
+        }
     }
-    w->ustart_host[ds] = n;
+    w->ustart_host[ds] = k;
     w->contiguous = 1;
-    w->it = it; w->waves = 4; w->jt = jt; w->nunits = ds; w->nwork = n;
+    w->it = it; w->waves = 4; w->jt = 256; w->nunits = ds; w->nwork = k;
     w->perm_dev = nullptr;
-    hipError_t e = hipMalloc(&w->work_dev, sizeof(int) * 4 * (size_t)n);
-    if (e == hipSuccess) e = hipMemcpy(w->work_dev, h, sizeof(int) * 4 * (size_t)n, hipMemcpyHostToDevice);
+    hipError_t e = hipMalloc(&w->work_dev, sizeof(int) * 4 * (size_t)k);
+    if (e == hipSuccess) e = hipMemcpy(w->work_dev, h, sizeof(int) * 4 * (size_t)k, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&w->ustart_dev, sizeof(int) * (ds + 1));
     if (e == hipSuccess) e = hipMemcpy(w->ustart_dev, w->ustart_host, sizeof(int) * (ds + 1), hipMemcpyHostToDevice);
     free(h);
@@ -329,12 +337,15 @@ extern "C" int gpmpc_pack_create(gpmpc_pack** out, int n_train, int state_dim, i
             ok = build_worklist(p->Np, cfg[k][0], cfg[k][1], state_dim, mode ? p->npairs : 0,
                                 mode == 0 && (k == 0 || k == 4) && !p->tune.no_xcd_sort, &p->wl[mode][k]) == 0;
         }
-    // MEASURED NEGATIVE and therefore opt-in (GPMPC_SPLIT_TAIL=1, A/B only): N = 4096, ds = 6, one trajectory 3.65 -> 4.23 ms per rollout (launch 119 -> 138 us on
-    // 3840 tile workgroups, profiles/r05/ab15_split_tail.txt): the 768 narrow workgroups pay a whole prologue each and every workgroup re-reduces 18 % more partial sums.
-    if (ok && action_dim >= 1 && action_dim <= 2 && getenv("GPMPC_SPLIT_TAIL")) {
+    // Measured (tools/lib_ab.py, profiles/r05/ab17_runs.txt; ms per rollout of ONE trajectory, 256x64 tiles | runs): N = 4096, ds = 6, da = 1, H = 30
+    // 3.63 | 3.34; N = 3584, ds = 5, da = 1, H = 20 1.48 | 1.35; N = 4096, ds = 4, da = 2 1.44 | 1.37; but ds = 4, da = 1 (D = 5, five waves per
+    // SIMD) 1.25 | 1.35: there the plain list already streams the weights at 4.3 TB/s, the rate of the full-covariance pair kernel (the
+    // practical ceiling of this access pattern), and longer workgroups only lose its overlap of prologues with loops.  From D = 6.
+    if (ok && D >= 6 && !getenv("GPMPC_NO_RUNS")) {
         // (workgroup slots of the one-launch form on 256-row tiles: 4 waves per SIMD from D = 6, 5 below -- step_fused.h's launch bounds)
-        const int occ = D >= 6 ? 4 : 5;
-        if (build_worklist_split_tail(p->Np, state_dim, p->num_cu * occ, &p->wl[0][7]) < 0) ok = false;
+        const int occ = 4;
+        // (the launch carries 2 ds more workgroups behind the tiles -- mean sums and finish, step_fused.h --: they need slots of the same generation)
+        if (build_worklist_runs(p->Np, state_dim, p->num_cu * occ - 2 * state_dim, &p->wl[0][7]) < 0) ok = false;
     }
     // shared-lambda work lists (pair_kernel_sbs.h): "units" are groups of sh_ng GPs
     if (ok && state_dim >= 2 && action_dim >= 1 && action_dim <= 2) {

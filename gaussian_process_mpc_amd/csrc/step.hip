@@ -35,7 +35,7 @@ extern "C" int gpmpc_debug_head_stamps(unsigned long long* host_out) {
 struct RollArgs {
     // pack
     const double* XT; const double* beta; const double* lam; const double* sf;
-    int Np, ds, da, D;            // (padded size only: no rollout kernel may depend on the unpadded N, see gpmpc_pack_resize)
+    int Np, ds, da, D;            // (padded size only: no launch argument may depend on the unpadded N, see gpmpc_graph_cache_invalidate)
     // problem
     const double* x0; const double* U; int B, H;
     // state trajectory (outputs or workspace): [B][H+1][ds]
@@ -1071,8 +1071,9 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
         r->nwork = p->ds * p->sh_tiles[r->sh_list];           // partial sums per trajectory: [GP][tile]
         r->rgroup = r->sh_list != 1 ? ((tn.rgroup >= 1 && tn.rgroup <= 16) ? tn.rgroup : 4) : 1;
     }
-    // ONE trajectory on 256x64 tiles whose last workgroup generation would be mostly empty: the list with the split tail (pack.hip, work list 7)
-    if (r->fused == 2 && r->tiling == 2 && !r->shared && B == 1 && !shape && tn.tiling < 0 && p->wl[0][7].work_dev) {
+    // One trajectory (or a few) of a training set whose 256x64 tiles would take several workgroup generations: balanced runs of up to 256
+    // columns, ONE generation per trajectory (pack.hip, work list 7; step_fused.h, Q = 256)
+    if (r->fused == 2 && r->tiling == 2 && !r->shared && !shape && tn.tiling < 0 && p->wl[0][7].work_dev) {
         r->tiling = 7;
         r->nwork = p->wl[0][7].nwork;
     }
@@ -1267,7 +1268,7 @@ extern "C" int gpmpc_plan_describe(const gpmpc_pack* p, int B, int H, unsigned f
     GraphModeGuard mode((flags & GPMPC_USE_GRAPH) ? 1 : 0);
     plan_rollout(p, B, H, grad, true, &r, lowprec);
     const int S = split_count(p, r, B, lowprec, (flags & GPMPC_USE_GRAPH) == 0, 0, H, grad ? 1 : 0);
-    static const int cfg[8][2] = {{256, 256}, {64, 64}, {256, 64}, {64, 128}, {256, 128}, {256, 32}, {256, 16}, {256, 64}};
+    static const int cfg[8][2] = {{256, 256}, {64, 64}, {256, 64}, {64, 128}, {256, 128}, {256, 32}, {256, 16}, {256, 256}};
     const int D = p->D, ds = p->ds;
     char kern[160];
     const char* form;
@@ -1277,7 +1278,7 @@ extern "C" int gpmpc_plan_describe(const gpmpc_pack* p, int B, int H, unsigned f
         snprintf(kern, sizeof(kern), "k_traj_persist<%d,%d,%s,%d>x%dwaves", D, ds, grad ? "true" : "false", r.png, r.pwaves);
         wgs = B;
     } else if (r.fused == 2) {
-        const int q = (r.tiling == 2 || r.tiling == 7) ? 0 : cfg[r.tiling][1], ng = r.shared ? r.fng : 1;
+        const int q = r.tiling == 2 ? 0 : cfg[r.tiling][1], ng = r.shared ? r.fng : 1;
         const gpmpc_worklist& wsh = p->wl_sh[(r.fng == 2 && p->sh_ng != 2) ? 3 : 1];
         form = r.shared ? "fused_sb_shared" : "fused_sb";
         snprintf(kern, sizeof(kern), "k_step_fused<%d,%d,%s,%d,%d>", D, ds, grad ? "true" : "false", q, ng);
@@ -1416,7 +1417,7 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
         F.gscr = r.fused == 2 ? (double*)(ws + r.off_G) : nullptr;
         F.ncol = p->ncol_dev;
         for (int t = 1; t <= H; ++t) {
-            const int rc = timed_launch(GPMPC_TIME_FUSED, s, [&] { return launch_step_fused(p->D, grad, p->ds, r.fused == 2 ? ((r.tiling == 2 || r.tiling == 7) ? 0 : wl.jt) : r.fq, fsh ? r.fng : 1, F, t, s); });
+            const int rc = timed_launch(GPMPC_TIME_FUSED, s, [&] { return launch_step_fused(p->D, grad, p->ds, r.fused == 2 ? (r.tiling == 2 ? 0 : wl.jt) : r.fq, fsh ? r.fng : 1, F, t, s); });
             if (rc != GPMPC_OK) return rc;
         }
         A.part += (size_t)(H & 1) * B * nwg * r.nm;          // the tail finishes step H from the parity the last launch wrote
@@ -1515,8 +1516,9 @@ void gpmpc_graph_cache_free(void* c) {
 
 // The pack changed under its captured launch sequences -- gpmpc_pack_build found that the "every GP has the same lambda" property
 // flipped, which selects other kernels --: drop the instantiated graphs, keep the streams, events and staging buffers.
-// (gpmpc_pack_resize does NOT come here: no rollout kernel takes the unpadded size N -- RollArgs / FusedArgs carry only the padded
-// Np, structurally --, so replays stay valid on the refilled buffers.)
+// (gpmpc_pack_resize does NOT come here: no rollout kernel takes the unpadded size N as a launch ARGUMENT -- RollArgs / FusedArgs carry
+// only the padded Np, structurally; the tile kernels clip their column loops at ceil(N / 8) * 8 columns (round 5), but read that count
+// from device memory, `ncol`, which gpmpc_pack_build refreshes in stream order -- so replays stay valid on the refilled buffers.)
 void gpmpc_graph_cache_invalidate(void* c) {
     gpmpc_graph_cache* g = (gpmpc_graph_cache*)c;
     if (!g) return;

@@ -129,9 +129,9 @@ static __device__ unsigned long long g_fused_wg[2 * 8192];         // [start | e
 // exponent and the exp ONCE per pair and applies them to NG weight loads; work list wl_sh[1] (items {group, i0, j0, tile}),
 // partial sums laid out [GP][tile], one row of column data per trajectory instead of one per GP.
 template <int D, int NS2, bool GRAD, int Q, int NG = 1>
-__global__ __launch_bounds__(256, (Q == 0 || Q == 32 || Q == 16) ? (NG >= 3 ? 3 : ((NG == 2 || D >= GPMPC_FUSED_SB_W4_FROM) ? 4 : GPMPC_FUSED_SB_WAVES)) : 1)
+__global__ __launch_bounds__(256, (Q == 0 || Q == 32 || Q == 16 || Q == 256) ? (NG >= 3 ? 3 : ((NG == 2 || D >= GPMPC_FUSED_SB_W4_FROM) ? 4 : GPMPC_FUSED_SB_WAVES)) : 1)
 void k_step_fused(FusedArgs A, int t) {
-    constexpr bool SB = Q == 0 || Q == 32 || Q == 16;
+    constexpr bool SB = Q == 0 || Q == 32 || Q == 16 || Q == 256;      // (256: runs of up to 256 columns, work list 7 -- one generation of workgroups per trajectory)
     constexpr bool SH = NG > 1;
     static_assert(!SH || Q == 0, "the shared-lambda tile role runs on 256x64 tiles");
     constexpr int NC = Q == 0 ? 64 : Q;                                            // columns of a tile of the mid-size form
@@ -253,9 +253,10 @@ void k_step_fused(FusedArgs A, int t) {
         const int ir = i0 + 64 * w + lane;
 #pragma unroll
         for (int k = 0; k < D; ++k) xrow[k] = A.XT[(size_t)k * Np + (ir < Np ? ir : Np - 1)];
-        if (w == 0) {
+        if (w == 0 || NC > 64) {                                          // (runs of up to 256 columns: every wave fetches 64 of them)
+            const int cidx = NC > 64 ? tid : (lane & (NC - 1));
 #pragma unroll
-            for (int k = 0; k < D; ++k) xcol[k] = A.XT[(size_t)k * Np + (j0 + (lane & (NC - 1)) < Np ? j0 + (lane & (NC - 1)) : Np - 1)];      // (clamped: a narrow tile of list 7 may start within NC columns of the end)
+            for (int k = 0; k < D; ++k) xcol[k] = A.XT[(size_t)k * Np + (j0 + cidx < Np ? j0 + cidx : Np - 1)];      // (clamped: a run may end within NC columns of the end)
         }
     }
     if (role == 0 && !SB) {
@@ -291,7 +292,7 @@ void k_step_fused(FusedArgs A, int t) {
     constexpr int MG = 4;                                           // columns per group (two groups in flight)
     double mga[PIPE ? MG : 1];
     const int iw0_t = i0 + 64 * w;
-    const bool wave_on = role == 0 && iw0_t < Np && j0 >= iw0_t;    // tiles left of the wave's diagonal block carry no weight (wave-uniform)
+    const bool wave_on = role == 0 && iw0_t < Np && (NC > 64 ? j1 > iw0_t : j0 >= iw0_t);    // tiles left of the wave's diagonal block carry no weight (wave-uniform; runs, NC = 256: a run that ENDS left of it)
     __amdgpu_buffer_rsrc_t Mrs_t = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<double*>(A.M + (size_t)unit * Np * Np + (size_t)j0 * Np + (wave_on ? iw0_t : 0)), 0, 0x7fffffff, 0x00020000);
     if constexpr (EARLY) {
@@ -383,7 +384,7 @@ void k_step_fused(FusedArgs A, int t) {
 #pragma unroll
         for (int k = 0; k < D; ++k) { sck[k] = s_sck[k]; cv[k] = s_cv[k]; }
         double* __restrict__ Gs = A.gscr + ((size_t)b * A.ntile + blockIdx.x) * (size_t)(NC * GW);
-        if (w == 0) {                                                    // column rows of this tile, one column per lane (< NC)
+        if (w == 0 || NC > 64) {                                         // column rows of this tile, one column per lane (< NC); runs: per thread
             double g[GW], qh = 0.0;
 #pragma unroll
             for (int k = 0; k < GW; ++k) g[k] = 0.0;
@@ -395,8 +396,8 @@ void k_step_fused(FusedArgs A, int t) {
                 if (k < NS2) g[D + 1 + k] = h * h;
             }
             g[D] = GPMPC_EXP_NEG_INV_C * qh;
-            double2* dst = reinterpret_cast<double2*>(Gs + (size_t)(lane & (NC - 1)) * GW);
-            if (NC == 64 || lane < NC) {
+            double2* dst = reinterpret_cast<double2*>(Gs + (size_t)(NC > 64 ? tid : (lane & (NC - 1))) * GW);
+            if (NC >= 64 || lane < NC) {
 #pragma unroll
                 for (int k = 0; k < GW / 2; ++k) dst[k] = make_double2(g[2 * k], g[2 * k + 1]);
             }
@@ -512,7 +513,9 @@ void k_step_fused(FusedArgs A, int t) {
         for (int m = 0; m < NA; ++m) acc[m] = 0.0;
         __syncthreads();                                                 // G rows and exp table ready
         GPMPC_STAMP(4);
-        if (iw0 < Np && j0 >= iw0) {                                     // tiles left of the wave's diagonal block carry no weight
+        // (runs, NC = 256: a run may START left of this wave's diagonal block -- the wave enters at the block's first column, jst)
+        const int jst = (NC > 64 && iw0 > j0) ? iw0 - j0 : 0;
+        if (iw0 < Np && (NC > 64 ? j1 > iw0 : j0 >= iw0)) {              // tiles left of the wave's diagonal block carry no weight
             // the scratch slot was written by this workgroup a moment ago: take the address through an opaque asm so that the
             // constant-address-space loads below (scalar loads) cannot be moved in front of the stores and the barrier
             const double* Gl = Gs;
@@ -583,7 +586,7 @@ void k_step_fused(FusedArgs A, int t) {
             static_assert(8 % (2 * MGS) == 0 && MGS % KC == 0, "tiles carry multiples of 8 columns");
             double wa[MGS], wb[MGS];
 #pragma unroll
-            for (int q = 0; q < MGS; ++q) wa[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, q * Np * 8, 0));
+            for (int q = 0; q < MGS; ++q) wa[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, (jst + q) * Np * 8, 0));
             auto batch = [&](int j, const double* mw) {
                 double g[KC][GW];
 #pragma unroll
@@ -620,7 +623,7 @@ void k_step_fused(FusedArgs A, int t) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             };
-            for (int jc = 0; jc < ncl; jc += 2 * MGS) {
+            for (int jc = jst; jc < ncl; jc += 2 * MGS) {
 #pragma unroll
                 for (int q = 0; q < MGS; ++q)
                     wb[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Mrs, lane8, (jc + MGS + q) * Np * 8, 0));
@@ -639,7 +642,7 @@ void k_step_fused(FusedArgs A, int t) {
             }
 #else
             constexpr int CU = 4;
-            for (int jc = 0; jc < ncl; jc += CU) {
+            for (int jc = jst; jc < ncl; jc += CU) {
                 double mij[CU];
 #pragma unroll
                 for (int q = 0; q < CU; ++q)
@@ -892,7 +895,7 @@ void k_step_fused(FusedArgs A, int t) {
 
 template <int D, int NS2, bool GRAD, int Q, int NG = 1>
 static int launch_step_fused_one(const FusedArgs& a, int t, hipStream_t s) {
-    if ((Q == 0 || Q == 32 || Q == 16) && !a.gscr) return GPMPC_E_ARG;
+    if ((Q == 0 || Q == 32 || Q == 16 || Q == 256) && !a.gscr) return GPMPC_E_ARG;
     if (a.ntile < 1 || (NG > 1 && a.tiles < 1)) return GPMPC_E_ARG;
     hipLaunchKernelGGL((k_step_fused<D, NS2, GRAD, Q, NG>), dim3(a.ntile + 2 * NS2, a.B), dim3(256), 0, s, a, t);
     hipError_t e = hipGetLastError();
@@ -904,7 +907,7 @@ static int launch_step_fused_one(const FusedArgs& a, int t, hipStream_t s) {
 // or 0 / 32 / 16 (256 x 64 / 32 / 16 tiles, scalar-broadcast column loop: the mid-size form)
 template <int D>
 int gpmpc_launch_step_fused_D(bool grad, int ns2, int q, int ng, const FusedArgs& a, int t, hipStream_t s) {
-    if (a.nm != (grad ? 1 + 2 * D : 1) || (q != 0 && q != 1 && q != 4 && q != 16 && q != 32)) return GPMPC_E_ARG;
+    if (a.nm != (grad ? 1 + 2 * D : 1) || (q != 0 && q != 1 && q != 4 && q != 16 && q != 32 && q != 256)) return GPMPC_E_ARG;
     if (ng > 1) {                                       // one lambda for all GPs: groups of ng GPs per tile workgroup (q = 0 only)
         if (q != 0) return GPMPC_E_ARG;
 #define GPMPC_FUSED_SH(NGV, NSV)                                                                                   \
@@ -937,6 +940,10 @@ int gpmpc_launch_step_fused_D(bool grad, int ns2, int q, int ng, const FusedArgs
     GPMPC_FUSED_CASE(false, 32)
     GPMPC_FUSED_CASE(true, 16)
     GPMPC_FUSED_CASE(false, 16)
+    if constexpr (D >= 6) {                             // (runs: work list 7 exists from D = 6, pack.hip)
+        GPMPC_FUSED_CASE(true, 256)
+        GPMPC_FUSED_CASE(false, 256)
+    }
 #undef GPMPC_FUSED_CASE
     return GPMPC_E_ARG;
 }

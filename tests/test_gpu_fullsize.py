@@ -237,6 +237,49 @@ def test_c4_full_horizon_against_cport(G):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("N,ds,da,H", [(2500, 6, 1, 4), (3011, 5, 1, 3), (2700, 5, 2, 3), (4096, 6, 2, 2)])
+def test_one_trajectory_on_balanced_runs_against_cport(G, N, ds, da, H):
+    """Work list 7 (pack.hip::build_worklist_runs; step_fused.h, Q = 256): ONE trajectory of a training set whose 256x64 tiles would take
+    several workgroup generations runs on balanced runs of up to 256 columns.  Sizes that are no multiple of 64 / 256 (clipped and ragged
+    last runs, waves that enter a run at their diagonal block), D = 6 ... 8, objective + gradient and objective only, eager and as a graph,
+    held to the C port; and to the same library on the plain 256x64 list."""
+    import os
+    from oracle import cport, gpmpc_oracle as O
+    from gaussian_process_mpc_amd.synth import synth_problem
+    pb = synth_problem(11, N, ds, da, H, 1)
+    torch.set_num_threads(16)
+    kinv = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"]).Ky_inv.numpy()
+    pack = G.GPPack(pb["X"], pb["Y"], kinv, pb["lambdas"], pb["sigma_f"])
+    plan = pack.plan(1, H)
+    assert plan["tiling"] == "256x256" and plan["launches_per_step"] == 1 and ",256," in plan["kernel"].replace(" ", ""), plan
+    cost = G.CostParams(-1.0, pb["Q"], pb["R"])
+    c = cport.rollout(pb, kinv, -1.0, x0=pb["x0"], U=pb["U"], nthreads=16)
+    out = []
+    for graph in (False, True):
+        r = G.rollout(pack, pb["x0"], pb["U"], cost, graph=graph)
+        np.testing.assert_allclose(r["means"].cpu().numpy(), c["means"], rtol=1e-5, atol=1e-9)      # north star
+        np.testing.assert_allclose(r["vars"].cpu().numpy(), c["vars"], rtol=1e-4)                   # north star
+        np.testing.assert_allclose(r["cost"].cpu().numpy(), c["cost"], rtol=1e-6)
+        np.testing.assert_allclose(r["grad"].cpu().numpy(), c["grad"], rtol=1e-4, atol=1e-7)
+        out.append(r)
+    for k in ("means", "vars", "cost", "grad"):
+        assert torch.equal(out[0][k], out[1][k]), k                                                 # eager == replayed graph, bit for bit
+    rf = G.rollout(pack, pb["x0"], pb["U"], cost, want_grad=False)
+    np.testing.assert_allclose(rf["vars"].cpu().numpy(), c["vars"], rtol=1e-4)
+    np.testing.assert_allclose(rf["cost"].cpu().numpy(), c["cost"], rtol=1e-6)
+    os.environ["GPMPC_NO_RUNS"] = "1"                          # (read when a pack is created)
+    try:
+        plain = G.GPPack(pb["X"], pb["Y"], kinv, pb["lambdas"], pb["sigma_f"])
+    finally:
+        del os.environ["GPMPC_NO_RUNS"]
+    assert plain.plan(1, H)["tiling"] == "256x64", plain.plan(1, H)
+    rp = G.rollout(plain, pb["x0"], pb["U"], cost)
+    np.testing.assert_allclose(out[0]["vars"].cpu().numpy(), rp["vars"].cpu().numpy(), rtol=1e-9)
+    np.testing.assert_allclose(out[0]["grad"].cpu().numpy(), rp["grad"].cpu().numpy(), rtol=1e-7, atol=1e-12)
+    del pack, plain
+    torch.cuda.empty_cache()
+
+
 def test_n4096_ds4_single_and_pair_of_trajectories_against_cport(G):
     """N = 4096 with FOUR state dimensions (D = 5 instances: the one-launch-per-step form was extended to N <= ~4300 for them),
     B = 1 and B = 2, whole horizon H = 20, directly against the C port."""

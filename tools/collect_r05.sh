@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collects the judged artefacts of the round-5 build into gpurun_out/r05c/ (run through gpurun from the repo root or a staged copy;
 # tools/.githead must hold the HEAD the snapshot was taken at).  Copy the result into profiles/r05/ afterwards.
-#   bash tools/collect_r04.sh [trace|pmc|bench|maps|all]
+#   bash tools/collect_r05.sh [trace|pmc|pmc1|pmc2|pmc3|bench|maps|all]
 set -u
 R=$(pwd)
 O=$R/gpurun_out/r05c
@@ -21,8 +21,10 @@ if [ $STEP = all ] || [ $STEP = pmc ] || [ $STEP = pmc1 ]; then
 # PMC (separate passes, counters only)
 for c in C3 C4 C5; do bash tools/prof_pmc.sh $c > $O/pmc_$c.log 2>&1; cp gpurun_out/pmc_$c/pmc_$c.txt gpurun_out/pmc_$c/pmc_$c.json $O/ 2>/dev/null; done
 bash tools/prof_pmc.sh C3 --shared-lambda > $O/pmc_C3_shared.log 2>&1; cp gpurun_out/pmc_C3/pmc_C3.txt $O/pmc_C3_shared.txt; cp gpurun_out/pmc_C3/pmc_C3.json $O/pmc_C3_shared.json
-PMC_BATCH=256 PMC_STEPS=3 bash tools/prof_pmc.sh C3 --n-train 300 --batch 256 > $O/pmc_N300_B256.log 2>&1; cp gpurun_out/pmc_C3/pmc_C3.txt $O/pmc_N300_B256.txt; cp gpurun_out/pmc_C3/pmc_C3.json $O/pmc_N300_B256.json
-PMC_BATCH=256 PMC_STEPS=3 bash tools/prof_pmc.sh C3 --n-train 300 --batch 256 --shared-lambda > $O/pmc_N300_B256_shared.log 2>&1; cp gpurun_out/pmc_C3/pmc_C3.txt $O/pmc_N300_B256_shared.txt; cp gpurun_out/pmc_C3/pmc_C3.json $O/pmc_N300_B256_shared.json
+fi
+if [ $STEP = all ] || [ $STEP = pmc ] || [ $STEP = pmc3 ]; then
+PMC_KC=/tmp/kinv_N300.pt PMC_BATCH=256 PMC_STEPS=3 bash tools/prof_pmc.sh C3 --n-train 300 --batch 256 > $O/pmc_N300_B256.log 2>&1; cp gpurun_out/pmc_C3/pmc_C3.txt $O/pmc_N300_B256.txt; cp gpurun_out/pmc_C3/pmc_C3.json $O/pmc_N300_B256.json
+PMC_KC=/tmp/kinv_N300s.pt PMC_BATCH=256 PMC_STEPS=3 bash tools/prof_pmc.sh C3 --n-train 300 --batch 256 --shared-lambda > $O/pmc_N300_B256_shared.log 2>&1; cp gpurun_out/pmc_C3/pmc_C3.txt $O/pmc_N300_B256_shared.txt; cp gpurun_out/pmc_C3/pmc_C3.json $O/pmc_N300_B256_shared.json
 fi
 if [ $STEP = all ] || [ $STEP = pmc ] || [ $STEP = pmc2 ]; then
 PMC_BATCH=1 PMC_STEPS=3 bash tools/prof_pmc.sh C3 --batch 1 > $O/pmc_C3_B1.log 2>&1; cp gpurun_out/pmc_C3/pmc_C3.txt $O/pmc_C3_B1.txt; cp gpurun_out/pmc_C3/pmc_C3.json $O/pmc_C3_B1.json

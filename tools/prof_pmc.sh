@@ -14,8 +14,9 @@ BATCH=${PMC_BATCH:-$(python3 -c "import sys; sys.path.insert(0,'$ROOTD'); from g
 STEPS=${PMC_STEPS:-1}
 CMD="python3 bench.py --config $CFG --steps $STEPS --warmup 1 --no-cpu-baseline --no-extras --no-legs $*"
 # the inverse kernel matrices come from an UNPROFILED run: rocprofv3 --pmc segfaults inside rocSOLVER's 4096^2 LU (C4)
-KC=/tmp/kinv_$CFG.pt
-[ -f $KC ] || python3 $ROOTD/bench.py --config $CFG --steps 1 --warmup 0 --no-cpu-baseline --no-extras --no-legs --kinv-cache $KC > /dev/null 2>&1
+# (PMC_KC: its own cache file for a run whose extra arguments change the training set, e.g. --n-train)
+KC=${PMC_KC:-/tmp/kinv_$CFG.pt}
+[ -f $KC ] || python3 $ROOTD/bench.py --config $CFG --steps 1 --warmup 0 --no-cpu-baseline --no-extras --no-legs --kinv-cache $KC "$@" > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp
 P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
 P2="SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVES"

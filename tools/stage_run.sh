@@ -22,5 +22,10 @@ if ! /usr/local/graft/bin/gpurun --status 2>/dev/null | grep -Eq '"in_flight": *
     for d in .stage/*; do [ "$d" != ".stage/$NAME" ] && rm -rf "$d"; done
 fi
 CMD="cd .stage/$NAME && $*"
-( timeout $((TMO + 1500)) /usr/local/graft/bin/gpurun --timeout $TMO -- "$CMD" > gpurun_out/$NAME.log 2>&1 & )
+# (exit code 3 = no box or slot free, nothing ran and nothing was charged: ask again after two minutes, a few times; any other outcome is final)
+( for try in 1 2 3 4 5 6; do
+    timeout $((TMO + 1500)) /usr/local/graft/bin/gpurun --timeout $TMO -- "$CMD" > gpurun_out/$NAME.log 2>&1; rc=$?
+    [ $rc -eq 3 ] && grep -q "status=transient" gpurun_out/$NAME.log || break
+    sleep 120
+  done & )
 echo "launched $NAME: $CMD"
