@@ -188,6 +188,7 @@ struct FusedArgs {
     int ntile;                             // tile workgroups per trajectory (= nwork, except with one lambda for all GPs: groups x tiles)
     int tiles;                             // one lambda for all GPs: tiles per GP (partial sums are laid out [GP][tile], nwork = ds * tiles)
     const int* ncol;                       // device: columns that carry weight (N rounded up to 8, <= Np; gpmpc_pack::ncol_dev): tile column loops end there
+    int xcdmap;                            // 256-row forms, several trajectories: XCD-aware dispatch order (step_fused.h; set by the plan from B x ntile)
 };
 template <int D> int gpmpc_launch_step_fused_D(bool grad, int ns2, int q, int ng, const FusedArgs& a, int t, hipStream_t s);
 

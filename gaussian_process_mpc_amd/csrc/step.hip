@@ -1416,6 +1416,13 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
         F.sps = r.sps; F.nm = r.nm;
         F.gscr = r.fused == 2 ? (double*)(ws + r.off_G) : nullptr;
         F.ncol = p->ncol_dev;
+        // XCD-aware dispatch order (step_fused.h): measured against the natural order (tools/lib_ab.py, profiles/r05/ab19_xcdmap*.txt; N:ds:B
+        // gain): 2048:4: B = 2 -1 %, 3 +2 %, 4 +4 %, 6 +8 %, 8 +6 %; 1024:4: 2 / 4 -2.5 %, 8 +4 %, 16 / 24 level; 512:3: 32 / 64 +3 / +2 %; 300:4:
+        // 32 +16 %; one lambda: 2048:4:8 +8 %, 1024:4:32 +14 %, 512:3:64 +14 %, 300:4:64 +10 %: from about one workgroup generation on.
+        {
+            static const int force = getenv("GPMPC_XCDMAP") ? atoi(getenv("GPMPC_XCDMAP")) : -1;
+            F.xcdmap = force >= 0 ? (force && B > 1) : (B > 1 && (long)B * F.ntile > 1000);
+        }
         for (int t = 1; t <= H; ++t) {
             const int rc = timed_launch(GPMPC_TIME_FUSED, s, [&] { return launch_step_fused(p->D, grad, p->ds, r.fused == 2 ? (r.tiling == 2 ? 0 : wl.jt) : r.fq, fsh ? r.fng : 1, F, t, s); });
             if (rc != GPMPC_OK) return rc;

@@ -79,6 +79,9 @@ static __device__ unsigned long long g_fused_wg[2 * 8192];         // [start | e
 #ifndef GPMPC_FUSED_PZ_SB
 #define GPMPC_FUSED_PZ_SB 6     // ... of the 256-row forms: 384 per GP in the first round trip (N = 2048 on 256x32 tiles has 288), the rest 4 at a time
 #endif
+#ifndef GPMPC_FUSED_XCDMAP
+#define GPMPC_FUSED_XCDMAP 1      // XCD-aware dispatch order of the 256-row forms for several trajectories (A/B: profiles/r05/ab19_xcdmap.txt)
+#endif
 #ifndef GPMPC_FUSED_PIPE_EARLY
 #define GPMPC_FUSED_PIPE_EARLY 1    // first group requested in phase 0 (1) or when the column loop starts (0)
 #endif
@@ -149,11 +152,28 @@ void k_step_fused(FusedArgs A, int t) {
     __shared__ double s_mu[GPMPC_MAX_DS], s_var[GPMPC_MAX_DS], s_z0[GPMPC_MAX_DS], s_c[GPMPC_MAX_DS];
     __shared__ double s_spp[4 * D];
     __shared__ double s_uin[D], s_sin[D], s_sck[D], s_cv[D];     // input moments of step t and the pair transform h = sc (u - x)
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+#if !GPMPC_FUSED_XCDMAP
+    const int b = blockIdx.y; unsigned bx = blockIdx.x;
+#else
+    int b = blockIdx.y; unsigned bx = blockIdx.x;
+    // XCD-aware order for several trajectories (256-row forms): workgroups go to the 8 XCDs round-robin in dispatch order (x fastest), each
+    // XCD with its own L2.  In the natural order trajectory b + 1 visits a tile ntile + 2 ds workgroups after trajectory b -- another XCD as
+    // often as not, and long after the tile has left that L2: every trajectory streams every weight tile from the Infinity Cache again.  Here
+    // the dispatch order is (8 tiles) x (all trajectories) x (tile within the 8): tile k of EVERY trajectory runs on XCD k mod 8, the B visits
+    // next to each other in dispatch order; the role workgroups of all trajectories come last.
+    if (SB && Q != 256 && A.xcdmap) {                    // (not on runs, work list 7: a list for ONE trajectory)
+        const int gx = gridDim.x, L = (int)blockIdx.y * gx + (int)blockIdx.x, nt = A.ntile, nB = A.B;
+        const int nt8 = nt & ~7, full = nt8 * nB, allt = nt * nB;
+        if (L < full) { const int grp = L / (8 * nB), r = L - grp * 8 * nB; b = r >> 3; bx = grp * 8 + (r & 7); }
+        else if (L < allt) { const int rem = nt - nt8, L2 = L - full; b = L2 / rem; bx = nt8 + L2 - b * rem; }
+        else { const int nr = gx - nt, L3 = L - allt; b = L3 / nr; bx = nt + L3 - b * nr; }
+    }
+#endif
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int role = (int)blockIdx.x < A.ntile ? 0 : ((int)blockIdx.x < A.ntile + DS ? 1 : 2);     // tile | mean sums | finish
+    const int role = ((int)bx >= A.ntile) + ((int)bx >= A.ntile + DS);     // 0 tile | 1 mean sums | 2 finish  (as a sum of comparisons: the select form of the same value costs the D = 5 instances 13 VGPR spills -- block placement)
     const int Np = A.Np, pprev = (t - 1) & 1, pcur = t & 1;
-    const int am = role == 1 ? (int)blockIdx.x - A.ntile : (int)blockIdx.x - A.ntile - DS;         // GP of a non-tile workgroup
+    const int am = role == 1 ? (int)bx - A.ntile : (int)bx - A.ntile - DS;         // GP of a non-tile workgroup
 
     // All kernel arguments used below are read HERE, unconditionally (the empty asm is an unconditional use): left to
     // itself the compiler loads each field inside the branch that first needs it, one s_load + s_waitcnt after the other
@@ -195,8 +215,8 @@ void k_step_fused(FusedArgs A, int t) {
     double xrow[D], xcol[D], mpre[CW];
     double tabreg[(TABLE && !SB) ? TABN : 1];
     if (role == 0) {
-        const int item = (int)blockIdx.x / QQ;
-        jq = ((int)blockIdx.x - item * QQ) * NCOL;                                    // this workgroup's columns of every chunk
+        const int item = (int)bx / QQ;
+        jq = ((int)bx - item * QQ) * NCOL;                                    // this workgroup's columns of every chunk
         if (A.tri64) {
             const int T = Np >> 6, per = T * (T + 1) / 2;
             unit = item / per;
@@ -383,7 +403,7 @@ void k_step_fused(FusedArgs A, int t) {
         double sck[D], cv[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) { sck[k] = s_sck[k]; cv[k] = s_cv[k]; }
-        double* __restrict__ Gs = A.gscr + ((size_t)b * A.ntile + blockIdx.x) * (size_t)(NC * GW);
+        double* __restrict__ Gs = A.gscr + ((size_t)b * A.ntile + bx) * (size_t)(NC * GW);
         if (w == 0 || NC > 64) {                                         // column rows of this tile, one column per lane (< NC); runs: per thread
             double g[GW], qh = 0.0;
 #pragma unroll
@@ -683,8 +703,8 @@ void k_step_fused(FusedArgs A, int t) {
                 const double* r4 = &s_red[ww * 4 * NM + tid];
                 sum += (r4[0] + r4[NM]) + (r4[2 * NM] + r4[3 * NM]);
             }
-            A.part[(((size_t)pcur * A.B + b) * A.nwork + blockIdx.x) * A.nm + tid] = sum;
-            if (tid == 0) A.partz[((size_t)pcur * A.B + b) * A.nwork + blockIdx.x] = sum;
+            A.part[(((size_t)pcur * A.B + b) * A.nwork + bx) * A.nm + tid] = sum;
+            if (tid == 0) A.partz[((size_t)pcur * A.B + b) * A.nwork + bx] = sum;
         }
         GPMPC_STAMP(7);
         GPMPC_STAMP_REAL(13);
@@ -755,8 +775,8 @@ void k_step_fused(FusedArgs A, int t) {
                 const double* r4 = &s_red[ww * 4 * NM + tid];
                 s += (r4[0] + r4[NM]) + (r4[2 * NM] + r4[3 * NM]);
             }
-            A.part[(((size_t)pcur * A.B + b) * A.nwork + blockIdx.x) * A.nm + tid] = s;
-            if (tid == 0) A.partz[((size_t)pcur * A.B + b) * A.nwork + blockIdx.x] = s;
+            A.part[(((size_t)pcur * A.B + b) * A.nwork + bx) * A.nm + tid] = s;
+            if (tid == 0) A.partz[((size_t)pcur * A.B + b) * A.nwork + bx] = s;
         }
         GPMPC_STAMP(7);
         GPMPC_STAMP_REAL(13);
