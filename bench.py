@@ -336,6 +336,7 @@ LEGS = [
     ("C3_shared_lambda", ["--config", "C3", "--shared-lambda", "--steps", "5", "--warmup", "2"]),
     ("C3_B1_graph", ["--config", "C3", "--batch", "1", "--graph", "--steps", "100", "--warmup", "20"]),
     ("C4_B1_graph", ["--config", "C4", "--batch", "1", "--graph", "--steps", "20", "--warmup", "5"]),
+    ("C3_B8_graph", ["--config", "C3", "--batch", "8", "--graph", "--steps", "50", "--warmup", "10"]),
     ("C5_B1", ["--config", "C5", "--batch", "1", "--steps", "20", "--warmup", "5"]),
     ("N300_B256_shared_lambda", ["--config", "C3", "--n-train", "300", "--batch", "256", "--shared-lambda", "--steps", "20", "--warmup", "5"]),
     ("N300_B256", ["--config", "C3", "--n-train", "300", "--batch", "256", "--steps", "20", "--warmup", "5"]),

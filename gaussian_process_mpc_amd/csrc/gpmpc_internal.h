@@ -51,6 +51,7 @@ struct gpmpc_tuning {
     int fc_rsplit;   // GPMPC_FC_RSPLIT   workgroups per (trajectory, unit) of the head kernel of the two-launch form | 0 unset
     int fc_cu;       // GPMPC_FC_CU       columns per iteration of the pair kernel there: 1 | 2 | 4 | 0 unset
     int fc_tiling;   // GPMPC_FC_TILING   pair-kernel tiles of the two-launch form: 0 256x256 | 2 256x64 | 4 256x128 | -1 unset
+    int xcdmap;      // GPMPC_XCDMAP      XCD-aware dispatch order of the one-launch form for several trajectories (step_fused.h): 0 off | 1 on | -1 unset (by the size of the launch)
     int persist;     // GPMPC_PERSIST     whole-horizon kernel, one workgroup per trajectory (traj_persist.h): 0 off | 8 / 16 on with that many waves | -1 unset
 };
 void gpmpc_read_tuning(gpmpc_tuning* t);

@@ -272,6 +272,7 @@ void gpmpc_read_tuning(gpmpc_tuning* t) {
     t->split = geti("GPMPC_SPLIT", -1);
     t->fused_sb = geti("GPMPC_FUSED_SB", -1);
     t->persist = geti("GPMPC_PERSIST", -1);
+    t->xcdmap = geti("GPMPC_XCDMAP", -1);
     t->fc_form = geti("GPMPC_FC_FORM", -1);
     t->fc_tiling = geti("GPMPC_FC_TILING", -1);
     t->fc_rsplit = geti("GPMPC_FC_RSPLIT", 0);

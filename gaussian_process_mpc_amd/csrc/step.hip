@@ -878,7 +878,7 @@ int gpmpc_timed_pair_sbf(int D, bool grad, int ns2, int waves, const PairSbfArgs
 }
 
 #define GPMPC_PERSIST_MAXNP_HOST 1024
-struct RollPlan { int tiling, tb, waves, nwork, nm, pps, sps, sb, gw, rgroup, fused, fq, hchunks, hrows, shared, sh_list, colunroll /* columns per iteration of the sb kernel */, fng /* GPs per tile workgroup of the one-launch form with one lambda */, pwaves /* waves per workgroup of the whole-horizon kernel (fused = 3) */, png /* GPs per unit there: 1, or 2 with one lambda for all GPs */; size_t off_mpart; size_t off_G; size_t off_pp, off_sp, off_part, off_partz, off_jac, off_means, off_vars, total; };
+struct RollPlan { int tiling, tb, waves, nwork, nm, pps, sps, sb, gw, rgroup, fused, fq, hchunks, hrows, shared, sh_list, colunroll /* columns per iteration of the sb kernel */, fng /* GPs per tile workgroup of the one-launch form with one lambda */, pwaves /* waves per workgroup of the whole-horizon kernel (fused = 3) */, xcdmap /* one-launch form, several trajectories: XCD-aware dispatch order 0 | 1 | -1 by the size of the launch */, png /* GPs per unit there: 1, or 2 with one lambda for all GPs */; size_t off_mpart; size_t off_G; size_t off_pp, off_sp, off_part, off_partz, off_jac, off_means, off_vars, total; };
 
 // shape (optional): take every SHAPE decision (tiling, kernel, trajectories per wave, row chunks ...) from this plan of a larger
 // batch and only size the buffers for B: the sub-batches of a split call then run exactly the launches the whole batch would,
@@ -973,15 +973,18 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     // N = 1536, ds = 3, B = 24 / 32 x1.07 / 1.14; N = 2048, B = 10 x0.96)
     // ... but only beyond the reach of the one-launch form, which is ahead of it wherever both apply (N = 1024, B = 40 2.27 vs 2.57 ms;
     // N = 768, B = 72 2.35 vs 2.58; N = 600, B = 96 2.36 vs 2.64)
-    const long fsb_max = shared_on ? 7000 : (p->wl[0][2].nwork <= 200 ? 7000 : 4700);
+    const long fsb_max = shared_on ? 7000 : (p->wl[0][2].nwork <= 200 ? 9000 : (D <= 5 ? 7000 : 4700));      // (7000 at D <= 5 with the XCD-aware order: N = 2048, B = 12 two kernels on 256x128 tiles 2.70 | one launch 2.50 ms, B = 16 the other way round)           // (9000: N = 400, ds = 3, da = 2, B = 288 two-kernel form 2.09 | one launch per step 1.86 ms, profiles/r05/autotune_512_verbose.txt)
     const bool fsb_take = fsb_can && tn.fused_sb != 0 && wg2 <= fsb_max;
     // (Np = 512 -- two row tiles -- runs its mid range on the 256x128 tiling too: B = 288 / 320 / 384 / 640 x1.14 / 1.10 / 1.09 / 1.15 over 256x256,
     // profiles/r05/autotune_grid_second.txt)
     const bool mid512 = p->Np == 512 && B < 768 && !fsb_take && sb_ok && tb2 && (long)((B + 1) / 2) * p->wl[0][4].nwork >= 1600;
     const bool big128 = (!big || mid512) && !fsb_take && sb_ok && tb2 && (p->Np > 512 || mid512) && (long)((B + 1) / 2) * p->wl[0][4].nwork >= 1600;
     r->sb = (sb_ok && (big || mid)) ? 1 : 0;
+    // (round 5: a small training set stays on the one-launch form as far as that reaches -- N = 400, ds = 3, da = 2, B = 288: 256x256 tiles, two
+    // kernels per step 2.19 | one launch per step 1.88 ms, profiles/r05/autotune_grid_third.txt)
+    const bool big_small_fused = big && p->Np <= 512 && fsb_take && sb_ok && tn.tiling < 0;
     const bool many = (long)p->wl[0][1].nwork > 256L * p->ds;        // > 256 one-wave tiles per GP (N >= 1472)
-    r->tiling = (big && !(mid512 && big128)) ? 0 : (big128 ? 4 : (mid ? 2 : (many ? 3 : 1)));
+    r->tiling = big_small_fused ? 2 : ((big && !(mid512 && big128)) ? 0 : (big128 ? 4 : (mid ? 2 : (many ? 3 : 1))));
     if (r->tiling == 2 && narrow_ok && wg2 < 1000)           // 32 columns from ~300 workgroups of 64, 16 below (while the partial sums
         r->tiling = (wg2 >= 300 || p->wl[0][6].nwork > 1300) ? 5 : 6;      // of a trajectory stay within ~1300)
     // A training set whose LAST row tile is a quarter or half tile (Np = 320, 384: N = 257...384): its 256x64 workgroups carry one or
@@ -990,7 +993,10 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     // B = 128 / 160 x1.06; N = 400 (Np = 448) and N = 512: level, N = 200 (one row tile): level.
     // (not with one lambda for all GPs: there the 64-column tiles are ahead -- round 5 grid, profiles/r05/autotune_grid_first_shared.txt:
     // N = 300, ds = 4, B = 128 0.58 | 0.38 ms, ds = 2, B = 320 0.49 | 0.33)
-    if (r->tiling == 2 && fsb_take && p->Np > 256 && p->Np <= 384 && wg2 >= 1000 && !shared_on) r->tiling = 5;
+    // (round 5, with the XCD-aware dispatch order -- on from B = 2 unless switched off --: the 64-column tiles are ahead for distinct
+    // lambdas as well: N = 300, ds = 4, B = 64 / 96 / 128 0.298 | 0.274, 0.42 | 0.35, 0.55 | 0.45 ms; ds = 2, B = 64 0.171 | 0.162 --
+    // profiles/r05/autotune_xcd_verbose.txt: the rule stays for the natural order only)
+    if (r->tiling == 2 && fsb_take && p->Np > 256 && p->Np <= 384 && wg2 >= 1000 && !shared_on && tn.xcdmap == 0) r->tiling = 5;
     if (tn.pair_sb >= 0) {                                   // 0 = staged kernel, 1 = scalar broadcast
         r->sb = (tn.pair_sb != 0 && sb_ok) ? 1 : 0;
         r->tiling = r->sb ? (big ? 0 : (big128 ? 4 : 2)) : (big ? 0 : (many ? 3 : 1));
@@ -1082,10 +1088,11 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
     // (tools/env_ab.py --var GPMPC_SB_UNROLL: +8...14 % up to ~2 generations of workgroups, -4 % from ~4 on)
     r->colunroll = (r->sb && !r->shared && !lowprec && r->tiling == 2 && r->tb == 1 && tn.colunroll != 1 &&
                   ((long)B * r->nwork <= 4096 || tn.colunroll == 4)) ? 4 : 1;
+    r->xcdmap = tn.xcdmap;
     if (shape) {
         r->tiling = shape->tiling; r->tb = shape->tb; r->waves = shape->waves; r->nwork = shape->nwork; r->sb = shape->sb;
         r->rgroup = shape->rgroup; r->fused = shape->fused; r->fq = shape->fq; r->shared = shape->shared; r->sh_list = shape->sh_list; r->fng = shape->fng;
-        r->colunroll = shape->colunroll;
+        r->colunroll = shape->colunroll; r->xcdmap = shape->xcdmap;
     }
     // Whole-horizon kernel, one workgroup per trajectory (traj_persist.h): large batches of a small training set -- at least about one
     // trajectory per CU, X within the kernel's LDS budget.  r->fused = 3; r->pwaves = waves per workgroup.
@@ -1113,13 +1120,15 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
         const bool psh = shared_on && p->ds >= 2 && D >= 3 && D <= 6;                   // (= pshared below)
         const bool all_in_one = psh && ((p->ds == 4 && D == 5) || (p->ds == 3 && D <= 5));   // 16-wave workgroups run ALL GPs of the pack in one unit
         const double work = (double)p->ds * p->Np * p->Np;
-        double r8 = 1.4 + 4.0e-12 * work * work;                                         // (grid: 1.46 at N = 200, ds = 2; 1.53 at 300 / 2; ~1.7 at 200 / 4; > 2.05 at 300 / 4)
+        // (final grid of round 5, full 8-wave generation of 2 num_cu trajectories over a full 16-wave one of num_cu: 1.63 at N = 200, ds = 2; 1.93 at
+        // 300 / 2; 1.94 at 200 / 4; > 2.05 at 300 / 4 -- profiles/r05/autotune_grid_fourth.txt)
+        double r8 = work < 205.0e3 ? 1.25 + 3.3e-6 * work : 1.93 + 1.0e-6 * (work - 205.0e3);
         if (r8 > 2.2) r8 = 2.2;
         if (all_in_one) r8 *= 1.25;                                                      // (8-wave workgroups fall back to units of two GPs)
         const double cost16 = gens_cost(B, cu), cost8 = r8 * gens_cost(B, 2 * cu);
         const int Npq = p->Np;
-        double inv_e = Npq <= 256 ? (p->ds <= 2 ? 2.15 : 1.95) : (Npq <= 320 ? 1.55 : (Npq <= 384 ? 1.50 : (Npq <= 448 ? 1.45 : (Npq <= 512 ? 1.16 : (Npq <= 576 ? 1.10 : 1.05)))));
-        if (psh) inv_e *= p->ds <= 2 ? 1.0 : (Npq <= 448 ? 1.25 : 1.10);
+        double inv_e = Npq <= 256 ? (p->ds <= 2 ? 2.15 : 1.95) : (Npq <= 320 ? 1.40 : (Npq <= 384 ? 1.45 : (Npq <= 448 ? 1.45 : (Npq <= 512 ? 1.16 : (Npq <= 576 ? 1.10 : 1.14)))));      // (640: 1.14 -- B = 224 step-per-launch 2.43 | whole horizon 2.25 ms, B = 192 the other way round)
+        if (psh) inv_e *= p->ds <= 2 ? 1.0 : (Npq <= 448 ? 1.15 : 1.10);
         if (Npq >= 512 && B > 2 * cu && !psh) inv_e = 0.9;
         const double cost_spl = (double)B / cu * inv_e;
         int pw = 0;
@@ -1417,12 +1426,13 @@ static int enqueue_rollout(const gpmpc_pack* p, int B, int H, const double* x0, 
         F.gscr = r.fused == 2 ? (double*)(ws + r.off_G) : nullptr;
         F.ncol = p->ncol_dev;
         // XCD-aware dispatch order (step_fused.h): measured against the natural order (tools/lib_ab.py, profiles/r05/ab19_xcdmap*.txt; N:ds:B
-        // gain): 2048:4: B = 2 -1 %, 3 +2 %, 4 +4 %, 6 +8 %, 8 +6 %; 1024:4: 2 / 4 -2.5 %, 8 +4 %, 16 / 24 level; 512:3: 32 / 64 +3 / +2 %; 300:4:
-        // 32 +16 %; one lambda: 2048:4:8 +8 %, 1024:4:32 +14 %, 512:3:64 +14 %, 300:4:64 +10 %: from about one workgroup generation on.
-        {
-            static const int force = getenv("GPMPC_XCDMAP") ? atoi(getenv("GPMPC_XCDMAP")) : -1;
-            F.xcdmap = force >= 0 ? (force && B > 1) : (B > 1 && (long)B * F.ntile > 1000);
-        }
+        // gain): 2048:4: B = 2 -1 %, 3 +2 %, 4 +4 %, 6 +8 %, 8 +6 %; 1024:4: 2 -2 %, 4 -2.5 / +2 %, 8 +4 %, 16 / 24 level; 512:3: 32 / 64 +3 / +2 %;
+        // 300:4:32 +16 %; one lambda: 2048:4:8 +8 %, 1024:4:32 +14 %, 512:3:64 +14 %, 300:4:64 +10 %.  As a candidate of gpmpc_pack_autotune
+        // (autotune_xcd_verbose*.txt) it is the best or within the run-to-run spread (~3 %) of the best on every shape of the grid, also on
+        // SMALL grids (N = 300, ds = 2, B = 64 +21 %; N = 200, ds = 4, B = 64, one lambda +27 %): there the natural order puts the same
+        // tiles of every trajectory -- the heavy 256-row ones -- on the same XCDs, the remapped order rotates the remainder.  From B = 2 (B = 2 itself is level:
+        // N = 2048 0.579 | 0.580, N = 1024 0.283 | 0.284 ms; sub-batches of two gain: N = 2048, B = 4 as 2 x 2 0.925 | 0.911).
+        F.xcdmap = r.xcdmap >= 0 ? (r.xcdmap && B > 1) : B >= 2;
         for (int t = 1; t <= H; ++t) {
             const int rc = timed_launch(GPMPC_TIME_FUSED, s, [&] { return launch_step_fused(p->D, grad, p->ds, r.fused == 2 ? (r.tiling == 2 ? 0 : wl.jt) : r.fq, fsh ? r.fng : 1, F, t, s); });
             if (rc != GPMPC_OK) return rc;
@@ -1852,7 +1862,7 @@ static bool same_shape(const RollPlan& a, const RollPlan& b) {
     if (a.fused == 3 && b.fused == 3) return a.pwaves == b.pwaves && a.png == b.png;      // the whole-horizon kernel has no tiling
     return a.tiling == b.tiling && a.tb == b.tb && a.sb == b.sb && a.fused == b.fused && a.fq == b.fq && a.shared == b.shared &&
            a.sh_list == b.sh_list && a.fng == b.fng && a.colunroll == b.colunroll && a.hchunks == b.hchunks && a.pwaves == b.pwaves &&
-           a.rgroup == b.rgroup && a.nwork == b.nwork;
+           a.rgroup == b.rgroup && a.nwork == b.nwork && a.xcdmap == b.xcdmap;
 }
 
 extern "C" int gpmpc_pack_autotune(gpmpc_pack* p, int B, int H, unsigned flags, char* report, size_t report_bytes) {
@@ -1867,9 +1877,9 @@ extern "C" int gpmpc_pack_autotune(gpmpc_pack* p, int B, int H, unsigned flags, 
         if (tab->e[k].valid && tab->e[k].B == B && tab->e[k].H == H && tab->e[k].grad == (grad ? 1 : 0) && tab->e[k].graph == (use_graph ? 1 : 0)) tab->e[k].valid = 0;
     // ---- candidates: the default plan, then the plans the GPMPC_* overrides would force, de-duplicated -------------------------
     struct Cand { RollPlan r; int S; double ms; const char* why; };
-    Cand cand[40]; int nc = 0;
+    Cand cand[48]; int nc = 0;
     auto add = [&](const gpmpc_tuning& tn, int split, const char* why) {
-        if (nc >= 40) return;
+        if (nc >= 48) return;
         RollPlan r;
         plan_rollout(p, B, H, grad, true, &r, false, nullptr, &tn);
         int S = split_count(p, r, B, false, !use_graph, split);
@@ -1882,6 +1892,10 @@ extern "C" int gpmpc_pack_autotune(gpmpc_pack* p, int B, int H, unsigned flags, 
     { gpmpc_tuning t = base; t.fused_sb = 0; add(t, 0, "fused_sb=0"); }
     { gpmpc_tuning t = base; t.fused_sb = 1; add(t, 0, "fused_sb=1"); }
     for (int tl : {0, 2, 4, 5, 6}) { gpmpc_tuning t = base; t.tiling = tl; add(t, 0, "tiling"); t.fused_sb = 1; add(t, 0, "tiling+fused_sb=1"); t.fused_sb = 0; add(t, 0, "tiling+fused_sb=0"); }
+    for (int xm : {0, 1}) {                                      // (the one-launch forms with the other dispatch order)
+        gpmpc_tuning t = base; t.xcdmap = xm; t.persist = 0; add(t, 0, xm ? "xcdmap=1" : "xcdmap=0");
+        for (int tl : {2, 5, 6}) { gpmpc_tuning u = t; u.tiling = tl; u.fused_sb = 1; add(u, 0, xm ? "tiling+xcdmap=1" : "tiling+xcdmap=0"); }
+    }
     { gpmpc_tuning t = base; t.persist = 16; add(t, 0, "persist=16"); t.persist = 8; add(t, 0, "persist=8"); t.persist = 0; add(t, 0, "persist=0"); }
     { gpmpc_tuning t = base; t.pair_sb = 0; t.persist = 0; add(t, 0, "pair_sb=0"); t.fused = 0; add(t, 0, "pair_sb=0,fused=0"); }
     { gpmpc_tuning t = base; t.fused = 0; t.persist = 0; add(t, 0, "fused=0"); }
@@ -1915,14 +1929,17 @@ extern "C" int gpmpc_pack_autotune(gpmpc_pack* p, int B, int H, unsigned flags, 
     for (int k = 0; k < p->ds; ++k) cost.Q[k * p->ds + k] = 1.0;
     for (int k = 0; k < p->da; ++k) cost.R[k * p->da + k] = 0.01;
     const unsigned fl = grad ? GPMPC_WANT_GRAD : 0;
-    hipGraphExec_t execs[40] = {};
+    hipGraphExec_t execs[48] = {};
     const bool trace = getenv("GPMPC_AUTOTUNE_TRACE") != nullptr;      // diagnostic: names every candidate on stderr before it runs
     const bool was_timing = timing_on();
     if (was_timing) gpmpc_timing_enable(0);                   // per-kernel events cannot be recorded inside the captures below
     // ---- time every candidate: one captured graph (or the plain launches), one warm-up, then replays for >= ~2 ms or 3 times ----
     for (int pass = 0; pass < 2; ++pass)                          // two passes, the better time of each candidate: the first launches of a
-    for (int k = 0; k < nc && rc == GPMPC_OK; ++k) {              // process (code upload, cold caches) must not be charged to the default plan
-        if (pass == 1 && cand[k].ms < 0.0) continue;              // failed to enqueue in the first pass
+    for (int kk = 0; kk <= nc && rc == GPMPC_OK; ++kk) {          // process (code upload, cold caches) must not be charged to the default plan
+        // (the default plan is timed AGAIN at the end of each pass: measured first only, it came out 4 ... 8 % behind candidates that
+        // launch exactly the same kernels -- profiles/r05/autotune_grid_mid.txt, N = 2048, B = 6 / 8 --, whatever the position effect is)
+        const int k = kk == nc ? 0 : kk;
+        if ((pass == 1 || kk == nc) && cand[k].ms < 0.0) continue;              // failed to enqueue before
         const Cand& c = cand[k];
         if (trace) fprintf(stderr, "[autotune] pass %d candidate %d (%s): fused=%d tiling=%d sb=%d tb=%d shared=%d pwaves=%d colunroll=%d split=%d\n", pass, k, c.why,
                            c.r.fused, c.r.tiling, c.r.sb, c.r.tb, c.r.shared, c.r.pwaves, c.r.colunroll, c.S);
@@ -1973,7 +1990,7 @@ extern "C" int gpmpc_pack_autotune(gpmpc_pack* p, int B, int H, unsigned flags, 
             if (best < 0.0 || per < best) best = per;
         }
         if (r2 != GPMPC_OK) cand[k].ms = -1.0;
-        else if (pass == 0 || best < cand[k].ms) cand[k].ms = best;
+        else if ((pass == 0 && kk < nc) || best < cand[k].ms) cand[k].ms = best;
     }
     (void)hipStreamSynchronize(st);
     (void)hipDeviceSynchronize();
@@ -1995,9 +2012,9 @@ extern "C" int gpmpc_pack_autotune(gpmpc_pack* p, int B, int H, unsigned flags, 
         size_t off = 0;
         report[0] = 0;
         for (int k = 0; k < nc && off + 96 < report_bytes; ++k)
-            off += snprintf(report + off, report_bytes - off, "%s%s%s:fused=%d,tiling=%d,sb=%d,tb=%d,shared=%d,pwaves=%d,split=%d:%.5f",
+            off += snprintf(report + off, report_bytes - off, "%s%s%s:fused=%d,tiling=%d,sb=%d,tb=%d,shared=%d,pwaves=%d,xcdmap=%d,split=%d:%.5f",
                             k ? ";" : "", k == win ? "*" : "", cand[k].why, cand[k].r.fused, cand[k].r.tiling, cand[k].r.sb, cand[k].r.tb, cand[k].r.shared,
-                            cand[k].r.pwaves, cand[k].S, cand[k].ms);
+                            cand[k].r.pwaves, cand[k].r.xcdmap, cand[k].S, cand[k].ms);
     }
     if (ea) (void)hipEventDestroy(ea);
     if (eb) (void)hipEventDestroy(eb);

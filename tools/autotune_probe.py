@@ -32,7 +32,7 @@ for shape in a.shapes:
     best = min((r for r in res if r["ms"] > 0), key=lambda r: r["ms"])
     d0 = res[0]
     print(f"{shape:>18s} default {d0['ms']:9.4f} ms  best {best['ms']:9.4f} ms ({best['name']}: fused={best['fused']} tiling={best['tiling']} sb={best['sb']} "
-          f"tb={best['tb']} pwaves={best['pwaves']} split={best['split']})  default/best {d0['ms'] / best['ms']:.3f}   [{default['form']} {default['tiling']}]", flush=True)
+          f"tb={best['tb']} pwaves={best['pwaves']} xcdmap={best.get('xcdmap', -1)} split={best['split']})  default/best {d0['ms'] / best['ms']:.3f}   [{default['form']} {default['tiling']}]", flush=True)
     if a.verbose:
-        for r in res:
-            print("      ", r)
+        for r in sorted(res, key=lambda r: r['ms'] if r['ms'] > 0 else 1e9)[:10]:
+            print("      ", f"{r['ms']:9.4f}", r['name'], {k: v for k, v in r.items() if k not in ('ms', 'name')})

@@ -12,6 +12,7 @@ if [ $STEP = all ] || [ $STEP = trace ]; then
 for c in C3 C4 C5; do bash tools/prof_trace.sh $c > $O/trace_$c.log 2>&1; cp gpurun_out/trace_$c/kernel_stats_$c.csv gpurun_out/trace_$c/bench_traced_$c.json $O/ 2>/dev/null; done
 bash tools/prof_trace.sh C3 --shared-lambda > $O/trace_C3_shared.log 2>&1; cp gpurun_out/trace_C3/kernel_stats_C3.csv $O/kernel_stats_C3_shared.csv; cp gpurun_out/trace_C3/bench_traced_C3.json $O/bench_traced_C3_shared.json
 bash tools/prof_trace.sh C3 --batch 1 > $O/trace_C3_B1.log 2>&1; cp gpurun_out/trace_C3/kernel_stats_C3.csv $O/kernel_stats_C3_B1.csv; cp gpurun_out/trace_C3/bench_traced_C3.json $O/bench_traced_C3_B1.json
+bash tools/prof_trace.sh C3 --batch 8 > $O/trace_C3_B8.log 2>&1; cp gpurun_out/trace_C3/kernel_stats_C3.csv $O/kernel_stats_C3_B8.csv; cp gpurun_out/trace_C3/bench_traced_C3.json $O/bench_traced_C3_B8.json
 bash tools/prof_trace.sh C4 --batch 1 > $O/trace_C4_B1.log 2>&1; cp gpurun_out/trace_C4/kernel_stats_C4.csv $O/kernel_stats_C4_B1.csv; cp gpurun_out/trace_C4/bench_traced_C4.json $O/bench_traced_C4_B1.json
 bash tools/prof_trace.sh C5 --batch 1 > $O/trace_C5_B1.log 2>&1; cp gpurun_out/trace_C5/kernel_stats_C5.csv $O/kernel_stats_C5_B1.csv; cp gpurun_out/trace_C5/bench_traced_C5.json $O/bench_traced_C5_B1.json
 bash tools/prof_trace.sh C3 --n-train 300 --batch 256 > $O/trace_N300_B256.log 2>&1; cp gpurun_out/trace_C3/kernel_stats_C3.csv $O/kernel_stats_N300_B256.csv; cp gpurun_out/trace_C3/bench_traced_C3.json $O/bench_traced_N300_B256.json
@@ -28,6 +29,7 @@ PMC_KC=/tmp/kinv_N300s.pt PMC_BATCH=256 PMC_STEPS=3 bash tools/prof_pmc.sh C3 --
 fi
 if [ $STEP = all ] || [ $STEP = pmc ] || [ $STEP = pmc2 ]; then
 PMC_BATCH=1 PMC_STEPS=3 bash tools/prof_pmc.sh C3 --batch 1 > $O/pmc_C3_B1.log 2>&1; cp gpurun_out/pmc_C3/pmc_C3.txt $O/pmc_C3_B1.txt; cp gpurun_out/pmc_C3/pmc_C3.json $O/pmc_C3_B1.json
+PMC_BATCH=8 PMC_STEPS=3 bash tools/prof_pmc.sh C3 --batch 8 > $O/pmc_C3_B8.log 2>&1; cp gpurun_out/pmc_C3/pmc_C3.txt $O/pmc_C3_B8.txt; cp gpurun_out/pmc_C3/pmc_C3.json $O/pmc_C3_B8.json
 PMC_BATCH=1 PMC_STEPS=2 bash tools/prof_pmc.sh C4 --batch 1 > $O/pmc_C4_B1.log 2>&1; cp gpurun_out/pmc_C4/pmc_C4.txt $O/pmc_C4_B1.txt; cp gpurun_out/pmc_C4/pmc_C4.json $O/pmc_C4_B1.json
 PMC_BATCH=1 PMC_STEPS=3 bash tools/prof_pmc.sh C5 --batch 1 > $O/pmc_C5_B1.log 2>&1; cp gpurun_out/pmc_C5/pmc_C5.txt $O/pmc_C5_B1.txt; cp gpurun_out/pmc_C5/pmc_C5.json $O/pmc_C5_B1.json
 fi
@@ -40,7 +42,7 @@ for c in C1 C2; do
   python bench.py --config $c --steps 200 --warmup 20 --no-cpu-baseline --full-json --graph > $O/bench_${c}_graph.json 2>/dev/null
 done
 python bench.py --config C3 --steps 5 --warmup 2 --no-cpu-baseline --full-json --forward-only > $O/bench_C3_fwd.json 2>/dev/null
-for b in 1 4 16 32; do python bench.py --config C3 --batch $b --steps 20 --warmup 5 --no-cpu-baseline --full-json --graph > $O/bench_C3_B$b.json 2>/dev/null; done
+for b in 1 4 8 16 32; do python bench.py --config C3 --batch $b --steps 20 --warmup 5 --no-cpu-baseline --full-json --graph > $O/bench_C3_B$b.json 2>/dev/null; done
 python bench.py --config C4 --batch 1 --steps 10 --warmup 3 --no-cpu-baseline --full-json --graph > $O/bench_C4_B1.json 2>/dev/null
 for b in 1 2 4 8; do python bench.py --config C5 --batch $b --steps 20 --warmup 5 --no-cpu-baseline --full-json --no-extras > $O/bench_C5_B$b.json 2>/dev/null; done
 python bench.py --config C3 --n-train 300 --batch 256 --shared-lambda --steps 20 --warmup 5 --no-cpu-baseline --full-json --no-extras > $O/bench_N300_B256_shared.json 2>/dev/null

@@ -18,7 +18,7 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 torch.set_num_threads(16)
 KNOBS = ("GPMPC_PERSIST", "GPMPC_FUSED_SB", "GPMPC_PAIR_SB", "GPMPC_PAIR_TB", "GPMPC_TILING", "GPMPC_FUSED", "GPMPC_NO_FIRST", "GPMPC_HEAD_CHUNKS", "GPMPC_SHARED",
-         "GPMPC_SB_UNROLL", "GPMPC_SPLIT", "GPMPC_SHARED_NG")
+         "GPMPC_SB_UNROLL", "GPMPC_SPLIT", "GPMPC_SHARED_NG", "GPMPC_XCDMAP")
 SHAPES = {"auto": {}, "sb256": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "0"}, "sb64": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "2"},
           "sb_tb1": {"GPMPC_PAIR_SB": "1", "GPMPC_PAIR_TB": "1"}, "staged": {"GPMPC_PAIR_SB": "0", "GPMPC_FUSED": "0"},
           "staged_tb4": {"GPMPC_PAIR_SB": "0", "GPMPC_FUSED": "0", "GPMPC_PAIR_TB": "4"}, "nofirst": {"GPMPC_NO_FIRST": "1"},
@@ -33,6 +33,9 @@ SHAPES = {"auto": {}, "sb256": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "0"}, "sb6
           "fsb_off": {"GPMPC_FUSED_SB": "0"}, "fsb_ng2": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "2", "GPMPC_FUSED_SB": "1", "GPMPC_SHARED_NG": "2"},
           "fsb32": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "5", "GPMPC_FUSED_SB": "1"}, "fsb16": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "6", "GPMPC_FUSED_SB": "1"},
           "persist16": {"GPMPC_PERSIST": "16"}, "persist8": {"GPMPC_PERSIST": "8"}, "persist_off": {"GPMPC_PERSIST": "0"},      # round 4: whole-horizon kernel
+          # round 5: the one-launch forms in the XCD-aware dispatch order forced on (any B > 1) and off
+          "fsb_xcd1": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "2", "GPMPC_FUSED_SB": "1", "GPMPC_XCDMAP": "1"}, "fsb32_xcd1": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "5", "GPMPC_FUSED_SB": "1", "GPMPC_XCDMAP": "1"},
+          "xcd0": {"GPMPC_XCDMAP": "0"}, "xcd1_nopersist": {"GPMPC_XCDMAP": "1", "GPMPC_PERSIST": "0"},
           "sb128": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "4"}, "sb128_split2": {"GPMPC_PAIR_SB": "1", "GPMPC_TILING": "4", "GPMPC_SPLIT": "2"}}
 worst = {"means": 0.0, "vars": 0.0, "cost": 0.0, "grad": 0.0}
 bad = 0
