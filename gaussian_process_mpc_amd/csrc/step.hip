@@ -1120,14 +1120,15 @@ static void plan_rollout(const gpmpc_pack* p, int B, int H, bool grad, bool diag
         const bool psh = shared_on && p->ds >= 2 && D >= 3 && D <= 6;                   // (= pshared below)
         const bool all_in_one = psh && ((p->ds == 4 && D == 5) || (p->ds == 3 && D <= 5));   // 16-wave workgroups run ALL GPs of the pack in one unit
         const double work = (double)p->ds * p->Np * p->Np;
-        // (final grid of round 5, full 8-wave generation of 2 num_cu trajectories over a full 16-wave one of num_cu: 1.63 at N = 200, ds = 2; 1.93 at
-        // 300 / 2; 1.94 at 200 / 4; > 2.05 at 300 / 4 -- profiles/r05/autotune_grid_fourth.txt)
-        double r8 = work < 205.0e3 ? 1.25 + 3.3e-6 * work : 1.93 + 1.0e-6 * (work - 205.0e3);
+        // (an EFFECTIVE ratio, fitted on batches that end in a partly filled 8-wave generation; a refit on full generations -- 1.63 at N = 200, ds = 2,
+        // 1.93 at 300 / 2 and 200 / 4 -- with its own partial-generation term moved more shapes away from the measured best than it brought back:
+        // profiles/r05/autotune_grid_sixth.txt and the run before it)
+        double r8 = 1.4 + 4.0e-12 * work * work;                                         // (grid: 1.46 at N = 200, ds = 2; 1.53 at 300 / 2; ~1.7 at 200 / 4; > 2.05 at 300 / 4)
         if (r8 > 2.2) r8 = 2.2;
         if (all_in_one) r8 *= 1.25;                                                      // (8-wave workgroups fall back to units of two GPs)
         const double cost16 = gens_cost(B, cu), cost8 = r8 * gens_cost(B, 2 * cu);
         const int Npq = p->Np;
-        double inv_e = Npq <= 256 ? (p->ds <= 2 ? 2.15 : 1.95) : (Npq <= 320 ? 1.40 : (Npq <= 384 ? 1.45 : (Npq <= 448 ? 1.45 : (Npq <= 512 ? 1.16 : (Npq <= 576 ? 1.10 : 1.14)))));      // (640: 1.14 -- B = 224 step-per-launch 2.43 | whole horizon 2.25 ms, B = 192 the other way round)
+        double inv_e = Npq <= 256 ? (p->ds <= 2 ? 2.15 : 1.95) : (Npq <= 320 ? 1.50 : (Npq <= 384 ? 1.50 : (Npq <= 448 ? 1.45 : (Npq <= 512 ? 1.16 : (Npq <= 576 ? 1.10 : 1.14)))));      // (640: 1.14 -- B = 224 step-per-launch 2.43 | whole horizon 2.25 ms, B = 192 the other way round)
         if (psh) inv_e *= p->ds <= 2 ? 1.0 : (Npq <= 448 ? 1.15 : 1.10);
         if (Npq >= 512 && B > 2 * cu && !psh) inv_e = 0.9;
         const double cost_spl = (double)B / cu * inv_e;
