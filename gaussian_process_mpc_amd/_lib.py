@@ -85,6 +85,8 @@ SIGNATURES = {
     "gpmpc_rollout_fullcov_describe": (_i, [_vp, _i, _i, _u, ctypes.c_char_p, _sz]),
     "gpmpc_rollout_fullcov": (_i, [_vp, _i, _i, _vp, _vp, ctypes.POINTER(CostParamsC), _u, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "gpmpc_timing_enable": (_i, [_i]),
+    "gpmpc_debug_run_list": (_i, [_i, _i, _i, ctypes.POINTER(_i), _i, ctypes.POINTER(_i)]),
+    "gpmpc_debug_xcd_order": (_i, [_i, _i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "gpmpc_pair_kernel_time": (_i, [_dp, ctypes.POINTER(ctypes.c_longlong), _i]),
     "gpmpc_pair_kernel_time_class": (_i, [_i, _dp, ctypes.POINTER(ctypes.c_longlong)]),
     "gpmpc_matvec": (_i, [_i, _i, _vp, _vp, _vp, _vp]),

@@ -192,6 +192,15 @@ struct FusedArgs {
     int xcdmap;                            // 256-row forms, several trajectories: XCD-aware dispatch order (step_fused.h; set by the plan from B x ntile)
 };
 template <int D> int gpmpc_launch_step_fused_D(bool grad, int ns2, int q, int ng, const FusedArgs& a, int t, hipStream_t s);
+// XCD-aware dispatch order of the one-launch form (step_fused.h): linear workgroup id L of a (gx, nB) grid whose first nt columns are tile
+// workgroups -> (trajectory b, column bx).  Order: (8 tiles) x (all trajectories) x (tile within the 8), then the tiles beyond a multiple of 8 per
+// trajectory, then the gx - nt role workgroups per trajectory: a bijection of [0, gx nB) onto [0, nB) x [0, gx) (tests/test_host_cpu.py).
+__host__ __device__ inline void gpmpc_xcd_remap(int L, int gx, int nt, int nB, int* b, unsigned* bx) {
+    const int nt8 = nt & ~7, full = nt8 * nB, allt = nt * nB;
+    if (L < full) { const int grp = L / (8 * nB), r = L - grp * 8 * nB; *b = r >> 3; *bx = (unsigned)(grp * 8 + (r & 7)); }
+    else if (L < allt) { const int rem = nt - nt8, L2 = L - full; *b = L2 / rem; *bx = (unsigned)(nt8 + L2 - *b * rem); }
+    else { const int nr = gx - nt, L3 = L - allt; *b = L3 / nr; *bx = (unsigned)(nt + L3 - *b * nr); }
+}
 
 // Arguments of the trajectory-persistent whole-horizon kernel (traj_persist.h; instantiated per D in persist_d*.o)
 struct PersistArgs {

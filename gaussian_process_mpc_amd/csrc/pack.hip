@@ -215,22 +215,24 @@ static int build_worklist(int Np, int it, int jt, int ds, int npairs, bool xcd_s
 // (multiples of 8 columns; step_fused.h, Q = 256, reads a run's length from its item): one generation per trajectory, a third of the
 // prologues.  (A first attempt that only split the LAST partial generation into 256x16 tiles was slower: 3.65 -> 4.23 ms,
 // profiles/r05/ab15_split_tail.txt.)  Returns 1 when the list is not worth building (the plain list is about one generation already).
-static int build_worklist_runs(int Np, int ds, int slots, gpmpc_worklist* w) {
+// (host part: the items {unit, i0, j0, j1} as a malloc'd array, ustart[ds + 1]; returns the item count, 0 when the list is not worth building,
+// -1 on allocation failure)
+static int runs_host(int Np, int ds, int slots, int** items_out, int* ustart) {
     const int it = 256;
     int n64 = 0;
     for (int i0 = 0; i0 < Np; i0 += it) n64 += (Np - (i0 / 64) * 64 + 63) / 64;
     n64 *= ds;
-    if (slots < 64 || n64 <= slots + slots / 10) return 1;
+    if (slots < 64 || n64 <= slots + slots / 10) return 0;
     auto count = [&](int L) { int c = 0; for (int i0 = 0; i0 < Np; i0 += it) { const int span = Np - i0; c += (span + L - 1) / L; } return c * ds; };
     int L = 8;
     while (L < 256 && count(L) > slots) L += 8;
-    if (count(L) > slots) return 1;                                      // more than one generation even with the longest runs
+    if (count(L) > slots) return 0;                                      // more than one generation even with the longest runs
     const int n = count(L);
     int* h = (int*)malloc(sizeof(int) * 4 * (size_t)n);
     if (!h) return -1;
     int k = 0;
     for (int u = 0; u < ds; ++u) {
-        w->ustart_host[u] = k;
+        ustart[u] = k;
         for (int i0 = 0; i0 < Np; i0 += it) {
             const int span = Np - i0, runs = (span + L - 1) / L;
             int j = i0;
@@ -244,9 +246,18 @@ static int build_worklist_runs(int Np, int ds, int slots, gpmpc_worklist* w) {
             }
         }
     }
-    w->ustart_host[ds] = k;
+    ustart[ds] = k;
+    *items_out = h;
+    return k;
+}
+
+static int build_worklist_runs(int Np, int ds, int slots, gpmpc_worklist* w) {
+    int* h = nullptr;
+    const int k = runs_host(Np, ds, slots, &h, w->ustart_host);
+    if (k == 0) return 1;
+    if (k < 0) return -1;
     w->contiguous = 1;
-    w->it = it; w->waves = 4; w->jt = 256; w->nunits = ds; w->nwork = k;
+    w->it = 256; w->waves = 4; w->jt = 256; w->nunits = ds; w->nwork = k;
     w->perm_dev = nullptr;
     hipError_t e = hipMalloc(&w->work_dev, sizeof(int) * 4 * (size_t)k);
     if (e == hipSuccess) e = hipMemcpy(w->work_dev, h, sizeof(int) * 4 * (size_t)k, hipMemcpyHostToDevice);
@@ -254,6 +265,24 @@ static int build_worklist_runs(int Np, int ds, int slots, gpmpc_worklist* w) {
     if (e == hipSuccess) e = hipMemcpy(w->ustart_dev, w->ustart_host, sizeof(int) * (ds + 1), hipMemcpyHostToDevice);
     free(h);
     return e == hipSuccess ? 0 : -1;
+}
+
+// Host-side views of two pieces of launch geometry, for tests that run without a GPU (include/gpmpc.h, "launch geometry")
+extern "C" int gpmpc_debug_run_list(int n_padded, int state_dim, int slots, int* items_out, int capacity, int* n_items) {
+    if (n_padded < 64 || n_padded % 64 || state_dim < 1 || state_dim > GPMPC_MAX_DS || !n_items || capacity < 0 || (capacity > 0 && !items_out)) return GPMPC_E_ARG;
+    int* h = nullptr; int ust[GPMPC_MAX_DS + 1];
+    const int k = runs_host(n_padded, state_dim, slots, &h, ust);
+    if (k < 0) return GPMPC_E_ALLOC;
+    *n_items = k;
+    if (k > 0) { if (k <= capacity) memcpy(items_out, h, sizeof(int) * 4 * (size_t)k); free(h); }
+    return (k > capacity && capacity > 0) ? GPMPC_E_ARG : GPMPC_OK;
+}
+extern "C" int gpmpc_debug_xcd_order(int linear_id, int grid_x, int n_tile, int n_traj, int* traj, int* column) {
+    if (!traj || !column || grid_x < 1 || n_tile < 1 || n_tile > grid_x || n_traj < 1 || linear_id < 0 || (long)linear_id >= (long)grid_x * n_traj) return GPMPC_E_ARG;
+    unsigned bx = 0;
+    gpmpc_xcd_remap(linear_id, grid_x, n_tile, n_traj, traj, &bx);
+    *column = (int)bx;
+    return GPMPC_OK;
 }
 
 void gpmpc_read_tuning(gpmpc_tuning* t) {

@@ -163,11 +163,8 @@ void k_step_fused(FusedArgs A, int t) {
     // the dispatch order is (8 tiles) x (all trajectories) x (tile within the 8): tile k of EVERY trajectory runs on XCD k mod 8, the B visits
     // next to each other in dispatch order; the role workgroups of all trajectories come last.
     if (SB && Q != 256 && A.xcdmap) {                    // (not on runs, work list 7: a list for ONE trajectory)
-        const int gx = gridDim.x, L = (int)blockIdx.y * gx + (int)blockIdx.x, nt = A.ntile, nB = A.B;
-        const int nt8 = nt & ~7, full = nt8 * nB, allt = nt * nB;
-        if (L < full) { const int grp = L / (8 * nB), r = L - grp * 8 * nB; b = r >> 3; bx = grp * 8 + (r & 7); }
-        else if (L < allt) { const int rem = nt - nt8, L2 = L - full; b = L2 / rem; bx = nt8 + L2 - b * rem; }
-        else { const int nr = gx - nt, L3 = L - allt; b = L3 / nr; bx = nt + L3 - b * nr; }
+        const int gx = gridDim.x;
+        gpmpc_xcd_remap((int)blockIdx.y * gx + (int)blockIdx.x, gx, A.ntile, A.B, &b, &bx);
     }
 #endif
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -306,6 +306,16 @@ int gpmpc_pair_kernel_time(double* total_ms, long long* launches, int reset);
  * gpmpc_pair_kernel_time(..., 1). */
 int gpmpc_pair_kernel_time_class(int kernel_class, double* total_ms, long long* launches);
 
+/* Launch geometry, host-side views (no device work; for tests without a GPU).
+ * gpmpc_debug_run_list: the balanced-run work list of the one-launch form for ONE trajectory of a large training set (items
+ *   {GP, first row, first column, end column}; n_padded = N rounded up to 64; slots = workgroup slots of the device minus the
+ *   2 state_dim role workgroups).  *n_items = 0 when the plain 256x64 list is within 1.1 generations.  items_out holds 4 * capacity ints
+ *   (capacity = 0: count only).
+ * gpmpc_debug_xcd_order: (trajectory, grid column) that workgroup `linear_id` of a (grid_x, n_traj) grid with n_tile tile columns runs in
+ *   the XCD-aware dispatch order. */
+int gpmpc_debug_run_list(int n_padded, int state_dim, int slots, int* items_out, int capacity, int* n_items);
+int gpmpc_debug_xcd_order(int linear_id, int grid_x, int n_tile, int n_traj, int* traj, int* column);
+
 /* ---------------------------------------------------------------------------
  * GP prediction at test points (GaussianProcessRegression.compute_pred_train_covariance /
  * predict_latent_vars, src/gpr.py:253-332) for ONE GP given by raw arrays.

@@ -80,6 +80,58 @@ def test_abi_argument_validation_without_device(built):
     assert lib.gpmpc_device_count() >= 0
 
 
+def test_xcd_aware_dispatch_order_is_a_bijection_and_keeps_a_tile_on_its_xcd(built):
+    """step_fused.h re-derives (trajectory, grid column) from the linear workgroup id (gpmpc_internal.h::gpmpc_xcd_remap, the same inline
+    function on host and device).  Every (trajectory, column) must be visited exactly once -- a hole or a double visit is a missing or a
+    twice-written partial sum --, and tile k of EVERY trajectory must sit on XCD k mod 8 (linear id mod 8) as long as k is within the last
+    multiple of 8: that is what the order is for."""
+    lib = built.lib()
+    b, c = ctypes.c_int(), ctypes.c_int()
+    for nt, ds, B in [(576, 4, 8), (577, 4, 3), (7, 2, 5), (8, 2, 2), (24, 4, 64), (163, 6, 2), (1, 1, 4), (40, 3, 33)]:
+        gx = nt + 2 * ds
+        seen = set()
+        for L in range(gx * B):
+            assert lib.gpmpc_debug_xcd_order(L, gx, nt, B, ctypes.byref(b), ctypes.byref(c)) == 0
+            assert 0 <= b.value < B and 0 <= c.value < gx
+            seen.add((b.value, c.value))
+            if c.value < (nt & ~7):
+                assert L % 8 == c.value % 8, (nt, B, L, b.value, c.value)
+            if c.value >= nt:                                       # role workgroups come after every tile workgroup
+                assert L >= nt * B
+        assert len(seen) == gx * B, (nt, ds, B)
+    assert lib.gpmpc_debug_xcd_order(10, 8, 9, 2, ctypes.byref(b), ctypes.byref(c)) == -1       # more tile columns than columns
+    assert lib.gpmpc_debug_xcd_order(16, 8, 4, 2, ctypes.byref(b), ctypes.byref(c)) == -1       # id beyond the grid
+
+
+def test_balanced_run_list_covers_every_column_once_within_one_generation(built):
+    """pack.hip::build_worklist_runs (host part): for ONE trajectory of a large training set every 256-row tile row of every GP is cut into
+    runs of at most 256 columns, multiples of 8, contiguous from the tile row's first column to the padded size, and the whole list fits the
+    workgroup slots it was built for; small training sets get no list."""
+    lib = built.lib()
+    n = ctypes.c_int()
+    for Np, ds, slots in [(4096, 6, 1024 - 12), (2560, 6, 1012), (3072, 5, 1014), (2752, 5, 1014), (4096, 7, 1010), (4032, 6, 1012)]:
+        assert lib.gpmpc_debug_run_list(Np, ds, slots, None, 0, ctypes.byref(n)) == 0
+        k = n.value
+        assert 0 < k <= slots, (Np, ds, slots, k)
+        items = (ctypes.c_int * (4 * k))()
+        assert lib.gpmpc_debug_run_list(Np, ds, slots, items, k, ctypes.byref(n)) == 0 and n.value == k
+        it = np.array(items[:]).reshape(k, 4)
+        assert (np.diff(it[:, 0]) >= 0).all() and set(it[:, 0]) == set(range(ds))            # unit-contiguous, every GP present
+        for u in range(ds):
+            for i0 in range(0, Np, 256):
+                runs = it[(it[:, 0] == u) & (it[:, 1] == i0)]
+                assert len(runs) >= 1 and runs[0, 2] == i0 and runs[-1, 3] == Np
+                assert (runs[1:, 2] == runs[:-1, 3]).all()                                    # contiguous, no overlap
+                lens = runs[:, 3] - runs[:, 2]
+                assert (lens > 0).all() and (lens <= 256).all() and (lens % 8 == 0).all()
+        lens = it[:, 3] - it[:, 2]
+        assert lens.max() - np.median(lens) <= 16                                             # balanced: equal runs up to the 8-column grain
+    assert lib.gpmpc_debug_run_list(2048, 4, 1016, None, 0, ctypes.byref(n)) == 0 and n.value == 0      # about one generation already
+    assert lib.gpmpc_debug_run_list(320, 4, 1016, None, 0, ctypes.byref(n)) == 0 and n.value == 0
+    assert lib.gpmpc_debug_run_list(100, 4, 1016, None, 0, ctypes.byref(n)) == -1                       # not a padded size
+    assert lib.gpmpc_debug_run_list(8192, 8, 1008, None, 0, ctypes.byref(n)) == 0 and n.value == 0      # more than one generation even at 256 columns
+
+
 def test_product_never_touches_the_oracle():
     """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import oracle/."""
     pat = re.compile(r"^\s*(from|import)\s+oracle\b", re.M)
