@@ -334,6 +334,7 @@ LEGS = [
     ("C4", ["--config", "C4", "--steps", "3", "--warmup", "1"]),
     ("C5", ["--config", "C5", "--steps", "3", "--warmup", "1"]),
     ("C3_shared_lambda", ["--config", "C3", "--shared-lambda", "--steps", "5", "--warmup", "2"]),
+    ("C5_shared_lambda", ["--config", "C5", "--shared-lambda", "--steps", "3", "--warmup", "1"]),
     ("C3_B1_graph", ["--config", "C3", "--batch", "1", "--graph", "--steps", "100", "--warmup", "20"]),
     ("C4_B1_graph", ["--config", "C4", "--batch", "1", "--graph", "--steps", "20", "--warmup", "5"]),
     ("C3_B8_graph", ["--config", "C3", "--batch", "8", "--graph", "--steps", "50", "--warmup", "10"]),
@@ -588,7 +589,11 @@ def run_rank(args):
         rollouts = B * world * args.steps
         value = rollouts / elapsed
         pairs_per_launch = B * ds * N * (N + 1) / 2                 # one horizon step, all trajectories and GPs
-        if fullcov:                                                 # + ds(ds-1)/2 cross units over all N^2 ordered pairs
+        # (one lambda, 2 <= ds <= 4: the cross units run in their own kernel, pair_kernel_sbfx.h -- beside the timed launch at small batches --;
+        # the timed launch then covers the variance units only, and so do its pair count and weight bytes)
+        fc_plan = pack.plan_fullcov(B, H, want_grad=want_grad) if fullcov else {}
+        cross_elsewhere = bool(fc_plan.get("shared_cross_units"))
+        if fullcov and not cross_elsewhere:                         # + ds(ds-1)/2 cross units over all N^2 ordered pairs
             pairs_per_launch += B * (ds * (ds - 1) / 2) * N * N
         shared = bool(pack.shared_lambda) and not fullcov and os.environ.get("GPMPC_SHARED", "") != "0"
         fl, slots = pair_work(D, ds, want_grad, fullcov, shared)
@@ -628,7 +633,7 @@ def run_rank(args):
             pairs_per_launch *= H
         pairs_per_launch /= n_sub
         achieved = pairs_per_launch * fl / launch_s / 1e12
-        m_bytes = 8 * (ds * N * (N + 1) / 2 + (ds * (ds - 1) / 2 * N * N if fullcov else 0))     # M read once per launch
+        m_bytes = 8 * (ds * N * (N + 1) / 2 + (ds * (ds - 1) / 2 * N * N if (fullcov and not cross_elsewhere) else 0))     # M read once per launch
         sm = "sbf" if fullcov else ("sbs" if shared else "sb")
         traffic, traffic_src = (None, None) if args.n_train else measured_traffic(args.config, B, want_grad, sm)
         ng = 0

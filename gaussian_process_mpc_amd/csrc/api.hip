@@ -60,6 +60,16 @@ int gpmpc_launch_pair_sbf(int D, bool grad, int ns2, int waves, const PairSbfArg
     return GPMPC_E_ARG;
 }
 
+int gpmpc_launch_pair_sbfx(int D, bool grad, int ns2, const PairSbfxArgs& a, hipStream_t s) {
+    switch (D) {
+        case 3: return gpmpc_launch_pair_sbfx_D<3>(grad, ns2, a, s);
+        case 4: return gpmpc_launch_pair_sbfx_D<4>(grad, ns2, a, s);
+        case 5: return gpmpc_launch_pair_sbfx_D<5>(grad, ns2, a, s);
+        case 6: return gpmpc_launch_pair_sbfx_D<6>(grad, ns2, a, s);
+    }
+    return GPMPC_E_ARG;
+}
+
 // K*[r][i] = sf^2 exp(-1/2 sum_k (xp_rk - x_ik)^2 / lambda_k)      (src/gpr.py:266-283)
 __global__ void k_cross_kernel(const double* __restrict__ Xp, int p, const double* __restrict__ X, int N, int D,
                                const double* __restrict__ lam, double sf2, double* __restrict__ K) {

@@ -421,7 +421,7 @@ extern "C" int gpmpc_debug_fc_stamps(unsigned long long* host_out) {      // [64
 }
 #endif
 
-struct FcPlan2 { int tiling, waves, nwork, nunits, nm, pps, sps, gw, rsplit, cu; size_t off_part0, off_pp, off_sp0, off_sp1, off_part, off_G, off_dmu, off_dmS, off_dcu, off_dcS, total; };
+struct FcPlan2 { int tiling, waves, nwork, nunits, nm, pps, sps, gw, rsplit, cu, fcs /* one lambda: the cross units by pair_kernel_sbfx.h */, ntri /* work items of the variance units */; size_t off_part0, off_pp, off_sp0, off_sp1, off_part, off_G, off_dmu, off_dmS, off_dcu, off_dcS, total; };
 
 // 1: the two-launch form applies and is taken (GPMPC_FC_FORM = 0 / 1 forces)
 static int plan_fc2(const gpmpc_pack* p, int B, int H, bool grad, FcPlan2* r) {
@@ -429,13 +429,29 @@ static int plan_fc2(const gpmpc_pack* p, int B, int H, bool grad, FcPlan2* r) {
     // Measured over N = 300 ... 2048, B = 1 ... 128 (profiles/r04/fullcov_small_batch_ab.txt): the two-launch form wins while the
     // large-tile launch of the four-launch form is below ~16 k workgroups, and at any batch for N <= 512; its tiles: the narrowest
     // whose launch stays within ~16 k workgroups.
-    const long w256 = (long)B * p->wl[1][0].nwork;
+    // One lambda for all GPs, 2 <= ds <= 4 (pair_kernel_sbfx.h: the cross units in ONE pass over the pairs, no weight stream): taken where it
+    // is ahead of the per-unit kernels -- tools/fullcov_ab.py --shared-lambda, profiles/r05/fullcov_shared_ab*.txt, ms per rollout call per-unit |
+    // shared: N = 2048, ds = 4: B = 1 1.47 | 1.63, 2 2.23 | 1.84, 4 3.99 | 2.81, 16 13.1 | 8.09, 64 47.9 | 28.0, 256 192 | 119 (two launches per step at
+    // ANY batch: the four-launch form has no shared variant); N = 1024: B = 4 1.30 | 1.63, 8 2.20 | 1.92, 64 12.8 | 8.87; N = 512, ds = 3: B = 32
+    // 1.35 | 1.55, 64 2.37 | 2.16; N = 300, ds = 4: B = 32 0.89 | 0.92, 64 1.37 | 1.11; ds = 2 (ONE cross unit): never.  Below the threshold a launch
+    // is a chain of latencies and the cross-unit kernel's wave waits ~1 k cycles per column (a flat ~35 us per horizon step).
+    const bool fcs_can = p->shared_lambda && p->fcs_rows && p->tune.shared != 0 && p->tune.fc_shared != 0 &&
+                         (p->tune.fc_shared == 1 || (double)B * p->Np * p->Np * p->npairs >= 3.5e7);
+    const long w256 = fcs_can ? 0 : (long)B * p->wl[1][0].nwork;
     if (p->tune.fc_form != 1 && w256 >= 16384 && p->Np > 512) return 0;
-    r->tiling = (long)B * p->wl[1][2].nwork <= 16384 ? 2 : ((long)B * p->wl[1][4].nwork <= 16384 ? 4 : 0);
+    r->tiling = (long)B * (fcs_can ? p->wl[1][2].ustart_host[p->ds] : p->wl[1][2].nwork) <= 16384 ? 2 : ((long)B * (fcs_can ? p->wl[1][4].ustart_host[p->ds] : p->wl[1][4].nwork) <= 16384 ? 4 : 0);
     if (p->tune.fc_tiling == 0 || p->tune.fc_tiling == 2 || p->tune.fc_tiling == 4) r->tiling = p->tune.fc_tiling;
     const gpmpc_worklist& w = p->wl[1][r->tiling];
     const size_t ds = p->ds, D = p->D, HB = (size_t)(grad ? H : 0) * B;
     r->waves = w.waves; r->nwork = w.nwork; r->nunits = w.nunits;
+    // One lambda for all GPs (2 <= ds <= 4): the cross units share transform, exponent and -- up to beta_a,i beta_b,j -- their weights; one pass
+    // of pair_kernel_sbfx.h over the pairs serves all of them without a weight stream, pair_kernel_sbf.h keeps the variance units (their
+    // weights hold K_a^-1).  A trajectory's partial-sum slots: the variance units' work items, then pairs x 64x64 tiles.  GPMPC_FC_SHARED=0: off.
+    {
+        r->fcs = (fcs_can && p->fcs_ustart_dev[r->tiling]) ? 1 : 0;
+        r->ntri = w.ustart_host[p->ds];
+        if (r->fcs) r->nwork = p->fcs_total[r->tiling];
+    }
     r->nm = gpmpc_num_moments(p->D, false, grad);
     // workgroups per (trajectory, unit) of the head kernel: one per 256 rows of column rows while the launch stays within ~4 per CU
     {
@@ -448,7 +464,7 @@ static int plan_fc2(const gpmpc_pack* p, int B, int H, bool grad, FcPlan2* r) {
     // (N = 2048, B = 1: 68 -> 57 us per launch, 4.7 TB/s of weights; N = 300 ... 1024 at B = 1: -12 %); 1 (8 instead of 5 waves per
     // SIMD) once the chip is full
     {
-        const long wgs = (long)B * r->nwork;
+        const long wgs = (long)B * (r->fcs ? r->ntri : r->nwork);
         r->cu = (wgs < 6000 && !(p->Np < 512 && wgs >= 1024)) ? 2 : 1;
         if (p->tune.fc_cu == 1 || p->tune.fc_cu == 2 || p->tune.fc_cu == 4) r->cu = p->tune.fc_cu;
     }
@@ -476,7 +492,7 @@ static int run_fc2(const gpmpc_pack* p, const FcPlan2& r, FcArgs& T, bool grad, 
     M.N = p->N; M.Np = p->Np; M.ds = p->ds; M.D = p->D; M.nq = B;
     M.pp = (double*)(ws + r.off_pp); M.part = (double*)(ws + r.off_part);
     M.pps = r.pps; M.sps = r.sps; M.nwork = r.nwork; M.nunits = r.nunits; M.nm = r.nm; M.grad = grad ? 1 : 0;
-    M.ustart = p->wl[1][r.tiling].ustart_dev;
+    M.ustart = r.fcs ? p->fcs_ustart_dev[r.tiling] : p->wl[1][r.tiling].ustart_dev;
     M.pair_ab = p->pair_ab_dev; M.npairs = p->npairs;
     M.G = (double*)(ws + r.off_G); M.gw = r.gw; M.ns2 = p->ds;
     A.x0 = T.x0; A.U = T.U; A.B = B; A.H = H; A.da = p->da;
@@ -488,6 +504,16 @@ static int run_fc2(const gpmpc_pack* p, const FcPlan2& r, FcArgs& T, bool grad, 
     Q.M = p->M; Q.XT = p->XT; Q.pp = M.pp; Q.G = M.G; Q.part = M.part; Q.work = p->wl[1][r.tiling].work_dev;
     Q.Np = p->Np; Q.B = B; Q.nunits = r.nunits; Q.nwork = r.nwork; Q.pps = r.pps; Q.nm = r.nm; Q.ntri = p->ds;
     Q.cu = r.cu; Q.part0 = (double*)(ws + r.off_part0); A.part0 = Q.part0;
+    Q.pstride = 0;
+    PairSbfxArgs X;
+    memset(&X, 0, sizeof(X));
+    if (r.fcs) {
+        Q.nwork = r.ntri; Q.pstride = r.nwork;                       // the variance units' items only, within the trajectory's full set of slots
+        X.XT = p->XT; X.lam = p->lam; X.beta = p->beta; X.sf = p->sf; X.pp = M.pp; X.G = M.G; X.rows = p->fcs_rows;
+        X.part = M.part; X.part0 = Q.part0; X.pair_ab = p->pair_ab_dev;
+        X.Np = p->Np; X.N = p->N; X.B = B; X.nunits = r.nunits; X.unit0 = p->ds; X.pps = r.pps; X.nm = r.nm;
+        X.tj = p->fcs_tj; X.ntile = p->fcs_ntile; X.base = p->fcs_base[r.tiling]; X.pstride = r.nwork;
+    }
     for (int t = 1; t <= H + 1; ++t) {
         M.sp = sp[t & 1]; A.sp_prev = sp[(t - 1) & 1];
         if (grad && t >= 2) {
@@ -499,6 +525,9 @@ static int run_fc2(const gpmpc_pack* p, const FcPlan2& r, FcArgs& T, bool grad, 
         hipLaunchKernelGGL(k_fc_head<D>, dim3(B, r.nunits, t > H ? 1 : r.rsplit + 2), dim3(256), 0, s, A, t);
         if (t > H) break;
         if (int rc = gpmpc_timed_pair_sbf(p->D, grad, p->ds, r.waves, Q, s)) return rc;
+        // (the cross-unit kernel BESIDE this launch on a side stream was built and measured: N = 2048, B = 1 1.775 -> 1.751 ms, B = 2 2.02 -> 2.17 ms:
+        // no gain, one stream)
+        if (r.fcs) if (int rc = gpmpc_launch_pair_sbfx(p->D, grad, p->ds, X, s)) return rc;
     }
     GPMPC_HIP(hipGetLastError());
     return GPMPC_OK;
@@ -550,8 +579,8 @@ extern "C" int gpmpc_rollout_fullcov_describe(const gpmpc_pack* p, int B, int H,
     if (plan_fc2(p, B, H, grad, &r2)) {
         const gpmpc_worklist& w = p->wl[1][r2.tiling];
         snprintf(out, out_bytes, "form=two_launch tiling=%dx%d workgroups=%ld columns_per_iteration=%d head_workgroups_per_unit=%d "
-                 "kernel=gpmpc_pair_kernel_sbf<%d,%d,%s,%d>", w.it, w.jt, (long)B * r2.nwork, r2.cu, r2.rsplit, p->D, p->ds,
-                 grad ? "true" : "false", r2.cu);
+                 "kernel=gpmpc_pair_kernel_sbf<%d,%d,%s,%d>%s shared_cross_units=%d", w.it, w.jt, (long)B * (r2.fcs ? r2.ntri : r2.nwork), r2.cu, r2.rsplit, p->D, p->ds,
+                 grad ? "true" : "false", r2.cu, r2.fcs ? "+gpmpc_pair_kernel_sbfx" : "", r2.fcs);
     } else {
         snprintf(out, out_bytes, "form=four_launch tiling=by_gpmpc_moment_match workgroups=0 columns_per_iteration=1 "
                  "head_workgroups_per_unit=1 kernel=gpmpc_pair_kernel_sbf<%d,%d,%s,1>|staged", p->D, p->ds, grad ? "true" : "false");

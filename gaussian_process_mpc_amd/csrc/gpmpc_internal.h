@@ -51,6 +51,7 @@ struct gpmpc_tuning {
     int fc_rsplit;   // GPMPC_FC_RSPLIT   workgroups per (trajectory, unit) of the head kernel of the two-launch form | 0 unset
     int fc_cu;       // GPMPC_FC_CU       columns per iteration of the pair kernel there: 1 | 2 | 4 | 0 unset
     int fc_tiling;   // GPMPC_FC_TILING   pair-kernel tiles of the two-launch form: 0 256x256 | 2 256x64 | 4 256x128 | -1 unset
+    int fc_shared;   // GPMPC_FC_SHARED   full-covariance rollout with one lambda for all GPs: cross units through pair_kernel_sbfx.h 0 off | 1 wherever it can run | -1 unset (by the size of the launch)
     int xcdmap;      // GPMPC_XCDMAP      XCD-aware dispatch order of the one-launch form for several trajectories (step_fused.h): 0 off | 1 on | -1 unset (by the size of the launch)
     int persist;     // GPMPC_PERSIST     whole-horizon kernel, one workgroup per trajectory (traj_persist.h): 0 off | 8 / 16 on with that many waves | -1 unset
 };
@@ -66,6 +67,11 @@ struct gpmpc_pack {
     int fullcov;    // cross-covariance weight matrices are allocated and kept up to date
     int pair_a[GPMPC_MAX_PAIRS > 0 ? GPMPC_MAX_PAIRS : 1], pair_b[GPMPC_MAX_PAIRS > 0 ? GPMPC_MAX_PAIRS : 1];
     int* pair_ab_dev;   // [npairs][2]
+    // one lambda for all GPs, full-covariance rollout (pair_kernel_sbfx.h): constant column rows [Np][fcs_rw] (refreshed by every build while
+    // `fullcov`), and per tri-unit tiling k of wl[1][k] the unit offsets into a trajectory's partial-sum slots: tri units as in that work list,
+    // cross unit pr at fcs_base[k] + pr * fcs_ntile
+    double* fcs_rows; int fcs_rw, fcs_ntile, fcs_tj;
+    int* fcs_ustart_dev[8]; int fcs_base[8], fcs_total[8];
     int ncol_host;      // the value last written to ncol_dev
     int* ncol_dev;      // [1] columns that carry weight: N rounded up to 8 (<= Np); written by every pack build (traj_persist.h reads it)
     double* X;      // dev [Np][D], rows >= N zero
@@ -141,7 +147,22 @@ struct PairSbfArgs {
     int Np, B, nunits, nwork, pps, nm, ntri;
     int cu;               // columns per loop iteration: 1 | 2 | 4 (pair_kernel_sbf.h)
     double* part0;        // [B][nwork]: the Z0 partial sums once more, contiguous (k_fc_head sums them for EVERY unit in every workgroup), or null
+    int pstride;          // partial-sum slots per trajectory when the launch covers only the FIRST nwork of them (one lambda: the cross units' slots are
+                          // written by pair_kernel_sbfx.h); 0 = nwork
 };
+// Arguments of the cross-unit pair kernel for packs with one lambda for all GPs (pair_kernel_sbfx.h)
+struct PairSbfxArgs {
+    const double* XT; const double* lam; const double* beta; const double* sf;
+    const double* pp; const double* G;     // as PairSbfArgs: the records / column rows of unit `unit0` (any cross unit: they are all alike)
+    const double* rows;                    // pack constant: [Np][RW] = [x_j (D) | C/4 sum_k x_jk^2 / lambda_k | beta_c,j (ds) | pad]
+    double* part; double* part0;           // partial sums, slots base + pair * ntile + tile of a trajectory's pstride slots
+    const int* pair_ab;
+    int Np, N, B, nunits, unit0, pps, nm;
+    int tj, ntile;                         // column tiles per row block, tiles per trajectory ((Np / 64) * tj)
+    int base, pstride;
+};
+template <int D> int gpmpc_launch_pair_sbfx_D(bool grad, int ns2, const PairSbfxArgs& a, hipStream_t s);
+int gpmpc_launch_pair_sbfx(int D, bool grad, int ns2, const PairSbfxArgs& a, hipStream_t s);
 static inline int gpmpc_sbf_gw(int D, int ns2) { return (D + 1 + ns2 * (ns2 + 1) / 2 + 1) & ~1; }
 int gpmpc_launch_pair_sbf(int D, bool grad, int ns2, int waves, const PairSbfArgs& a, hipStream_t s);
 template <int D> int gpmpc_launch_pair_sbf_D(bool grad, int ns2, int waves, const PairSbfArgs& a, hipStream_t s);

@@ -316,7 +316,7 @@ static int run_mom(const gpmpc_pack* p, MomArgs& A, const MomPlan& r, bool grad,
     if (r.sbf) {
         PairSbfArgs Q;
         Q.M = p->M; Q.XT = p->XT; Q.pp = A.pp; Q.G = A.G; Q.part = A.part; Q.work = P.work;
-        Q.Np = p->Np; Q.B = A.nq; Q.nunits = r.nunits; Q.nwork = r.nwork; Q.pps = r.pps; Q.nm = r.nm; Q.ntri = p->ds; Q.cu = 1; Q.part0 = nullptr;
+        Q.Np = p->Np; Q.B = A.nq; Q.nunits = r.nunits; Q.nwork = r.nwork; Q.pps = r.pps; Q.nm = r.nm; Q.ntri = p->ds; Q.cu = 1; Q.part0 = nullptr; Q.pstride = 0;
         rc = gpmpc_timed_pair_sbf(D, grad, A.ns2, r.waves, Q, s);
     } else {
         rc = gpmpc_timed_pair(D, false, grad, r.tb, P.colsplit ? 4 : r.waves, P, s);

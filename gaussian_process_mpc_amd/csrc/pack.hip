@@ -114,6 +114,46 @@ __global__ void k_build_ky(const double* __restrict__ X, int n, int D, const dou
     Ky[(size_t)i * n + j] = kf + (i == j ? noise_var : 0.0);
 }
 
+// One lambda for all GPs, full-covariance rollout (pair_kernel_sbfx.h): the constant part of a column j of every cross unit,
+//   rows[j] = [x_jk (D) | (N/ln2)/4 sum_k x_jk^2 / lambda_k | beta_c,j (c < ds) | pad],   beta = 0 for padded columns
+__global__ void k_pack_fcs_rows(const double* __restrict__ beta, const double* __restrict__ XT, const double* __restrict__ lam,
+                                int N, int Np, int D, int ds, int rw, double* __restrict__ rows) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Np) return;
+    double* r = rows + (size_t)j * rw;
+    double e = 0.0;
+    for (int k = 0; k < D; ++k) { const double x = XT[(size_t)k * Np + j]; r[k] = x; e = fma(x * x, 1.0 / lam[k], e); }
+    r[D] = (0.25 * 0x1.71547652b82fep+11) * e;               // (GPMPC_EXP_NEG_INV_C: the exponent travels scaled, fast_exp.h)
+    for (int c = 0; c < ds; ++c) r[D + 1 + c] = j < N ? beta[(size_t)c * Np + j] : 0.0;
+    for (int k = D + 1 + ds; k < rw; ++k) r[k] = 0.0;
+}
+
+// (allocations on first use; the rows are refreshed by every build while the pack serves the full-covariance rollout with one lambda)
+static int fcs_refresh(gpmpc_pack* p, hipStream_t s) {
+    if (!p->fullcov || p->npairs == 0 || !p->shared_lambda || p->ds < 2 || p->ds > 4 || p->D - p->ds < 1 || p->D - p->ds > 2) return GPMPC_OK;
+    if (!p->fcs_rows) {
+        p->fcs_rw = (p->D + 1 + p->ds + 1) & ~1;
+        p->fcs_tj = p->Np / 64; p->fcs_ntile = p->fcs_tj * (p->fcs_tj + 1) / 2;   // 64 x 64 tiles of the upper triangle (pair_kernel_sbfx.h)
+        if (hipMalloc(&p->fcs_rows, sizeof(double) * (size_t)p->Np * p->fcs_rw) != hipSuccess) { p->fcs_rows = nullptr; return GPMPC_E_ALLOC; }
+        for (int k : {0, 2, 4}) {
+            const gpmpc_worklist& w = p->wl[1][k];
+            if (!w.work_dev) continue;
+            int ust[GPMPC_MAX_DS + GPMPC_MAX_PAIRS + 1];
+            const int ntri = w.ustart_host[p->ds];
+            for (int u = 0; u <= p->ds; ++u) ust[u] = w.ustart_host[u];
+            for (int pr = 1; pr <= p->npairs; ++pr) ust[p->ds + pr] = ntri + pr * p->fcs_ntile;
+            p->fcs_base[k] = ntri; p->fcs_total[k] = ntri + p->npairs * p->fcs_ntile;
+            const size_t nb = sizeof(int) * (p->ds + p->npairs + 1);
+            if (hipMalloc(&p->fcs_ustart_dev[k], nb) != hipSuccess) { p->fcs_ustart_dev[k] = nullptr; return GPMPC_E_ALLOC; }
+            GPMPC_HIP(hipMemcpy(p->fcs_ustart_dev[k], ust, nb, hipMemcpyHostToDevice));
+        }
+    }
+    hipLaunchKernelGGL(k_pack_fcs_rows, dim3((p->Np + 255) / 256), dim3(256), 0, s, p->beta, p->XT, p->lam, p->N, p->Np, p->D, p->ds,
+                       p->fcs_rw, p->fcs_rows);
+    GPMPC_HIP(hipGetLastError());
+    return GPMPC_OK;
+}
+
 // Cross-covariance weights of the GP pair (a, b), a < b:  element (i,j) at [j*Np + i]
 //   beta_a[i] beta_b[j] sfa^2 sfb^2 exp(-1/2 sum_k (x_ik - x_jk)^2 / (lambda_ak + lambda_bk))
 // (the x-independent factor of k_a(x,x_i) k_b(x,x_j), src/tools/uncertainty_prop.py:448-460 as a Gaussian product).
@@ -302,6 +342,7 @@ void gpmpc_read_tuning(gpmpc_tuning* t) {
     t->fused_sb = geti("GPMPC_FUSED_SB", -1);
     t->persist = geti("GPMPC_PERSIST", -1);
     t->xcdmap = geti("GPMPC_XCDMAP", -1);
+    t->fc_shared = geti("GPMPC_FC_SHARED", -1);
     t->fc_form = geti("GPMPC_FC_FORM", -1);
     t->fc_tiling = geti("GPMPC_FC_TILING", -1);
     t->fc_rsplit = geti("GPMPC_FC_RSPLIT", 0);
@@ -422,6 +463,8 @@ extern "C" int gpmpc_pack_destroy(gpmpc_pack* p) {
     gpmpc_tuned_free(p->tuned);
     gpmpc_lock_destroy(p->lock);
     if (p->pair_ab_dev) (void)hipFree(p->pair_ab_dev);
+    if (p->fcs_rows) (void)hipFree(p->fcs_rows);
+    for (int k = 0; k < 8; ++k) if (p->fcs_ustart_dev[k]) (void)hipFree(p->fcs_ustart_dev[k]);
     for (int mode = 0; mode < 2; ++mode)
         for (int k = 0; k < 8; ++k) {
             if (p->wl[mode][k].work_dev) (void)hipFree(p->wl[mode][k].work_dev);
@@ -490,6 +533,7 @@ static int pack_build_impl(gpmpc_pack* p, const double* X_dev, const double* Y_d
     if (p->fullcov && p->npairs > 0)
         hipLaunchKernelGGL(k_pack_cross, dim3((p->Np + 255) / 256, p->Np, p->npairs), dim3(256), 0, s, p->beta, p->XT, p->lam,
                            p->sf, p->pair_ab_dev, p->N, p->Np, p->D, p->ds, p->M + (size_t)p->ds * p->Np * p->Np);
+    if (int rcf = fcs_refresh(p, s)) return rcf;
     {   // the column count that carries weight (traj_persist.h): re-sent when it changes (every 8th observation of a growing set)
         int nc = ((p->N + 7) / 8) * 8;
         if (nc > p->Np) nc = p->Np;
@@ -525,6 +569,7 @@ extern "C" int gpmpc_pack_enable_fullcov(gpmpc_pack* p, void* stream) {
         hipLaunchKernelGGL(k_pack_cross, dim3((p->Np + 255) / 256, p->Np, p->npairs), dim3(256), 0, s, p->beta, p->XT, p->lam,
                            p->sf, p->pair_ab_dev, p->N, p->Np, p->D, p->ds, p->M + (size_t)p->ds * p->Np * p->Np);
         GPMPC_HIP(hipGetLastError());
+        if (int rcf = fcs_refresh(p, s)) return rcf;
     }
     return GPMPC_OK;
 }

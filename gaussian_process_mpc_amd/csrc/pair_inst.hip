@@ -3,6 +3,7 @@
 #include "pair_kernel.h"
 #include "pair_kernel_sb.h"
 #include "pair_kernel_sbf.h"
+#include "pair_kernel_sbfx.h"
 #include "pair_kernel_sbs.h"
 #ifndef GPMPC_PAIR_D
 #error "compile with -DGPMPC_PAIR_D=<D>"
@@ -10,6 +11,7 @@
 template int gpmpc_launch_pair_D<GPMPC_PAIR_D>(bool, bool, int, int, const PairArgs&, hipStream_t);
 template int gpmpc_launch_pair_sb_D<GPMPC_PAIR_D>(bool, int, int, int, const PairSbArgs&, hipStream_t);
 template int gpmpc_launch_pair_sbf_D<GPMPC_PAIR_D>(bool, int, int, const PairSbfArgs&, hipStream_t);
+template int gpmpc_launch_pair_sbfx_D<GPMPC_PAIR_D>(bool, int, const PairSbfxArgs&, hipStream_t);
 template int gpmpc_launch_pair_sbs_D<GPMPC_PAIR_D>(bool, int, int, const PairSbsArgs&, hipStream_t);
 
 #if defined(GPMPC_SB_STAMPS) && GPMPC_PAIR_D == 5

@@ -174,8 +174,9 @@ __global__ __launch_bounds__(256, (CU == 2 && GRAD && D <= 5) ? GPMPC_SBF_MINWG 
             const double* r4 = &s_red[ww * 4 * NM + m];
             s += (r4[0] + r4[NM]) + (r4[2 * NM] + r4[3 * NM]);
         }
-        A.part[((size_t)b * A.nwork + wi) * A.nm + m] = s;
-        if (m == 0 && A.part0) A.part0[(size_t)b * A.nwork + wi] = s;
+        const size_t stride = A.pstride > 0 ? A.pstride : A.nwork;        // (slots per trajectory: more than this launch's items with one lambda)
+        A.part[((size_t)b * stride + wi) * A.nm + m] = s;
+        if (m == 0 && A.part0) A.part0[(size_t)b * stride + wi] = s;
     }
 }
 

@@ -99,6 +99,68 @@ def test_diag_rollout_every_shape_vs_cport(G, ds, da):
         np.testing.assert_allclose(f["vars"].cpu().numpy(), r["vars"].cpu().numpy(), rtol=1e-7)
 
 
+@pytest.mark.parametrize("ds,da,N", [(2, 1, 110), (2, 2, 200), (3, 1, 110), (3, 2, 130), (4, 1, 110), (4, 2, 300), (4, 1, 449), (5, 1, 110)])
+def test_fullcov_rollout_with_one_lambda_vs_cport(G, ds, da, N, monkeypatch):
+    """Full-covariance rollout of a pack whose GPs share their length-scales (the reference's experiments): from two to four state
+    dimensions the cross units of the two-launch form run through pair_kernel_sbfx.h (one pass over the pairs for ALL of them, no weight
+    stream, beta_a,i beta_b,j applied to shared sums), the variance units through pair_kernel_sbf.h.  Held to the C port (which knows
+    nothing about shared length-scales) and to the same library with the sharing switched off; ds = 5 keeps the per-unit kernels."""
+    from oracle import cport, gpmpc_oracle as O
+    from gaussian_process_mpc_amd.synth import synth_problem
+    H = 3
+    bmax = 24 if N == 449 else 5
+    pb = synth_problem(80 + 8 * ds + da, N, ds, da, H, bmax, shared_lambda=True)
+    pb["Q"] = pb["Q"] + 0.02 * (np.ones((ds, ds)) - np.eye(ds))
+    kinv = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"]).Ky_inv.numpy()
+    pack = G.GPPack(pb["X"], pb["Y"], kinv, pb["lambdas"], pb["sigma_f"])
+    cost = G.CostParams(-1.0, pb["Q"], pb["R"])
+    rng = np.random.default_rng(ds * 10 + da)
+    pack.enable_fullcov()                            # (rollout_fullcov does it on first use; the plan is asked for before that here)
+    # the plan takes the shared form from B Np^2 pairs >= 3.5e7 (fullcov.hip::plan_fc2): forced on for the small shapes of this test
+    # (GPMPC_FC_SHARED=1), and taken by the default plan at N = 449 (Np = 512), ds = 4, B = 24
+    forced = {"GPMPC_FC_SHARED": "1"}
+    cases = [(1, forced), (3, forced), (5, dict(forced, GPMPC_FC_TILING="4")), (2, dict(forced, GPMPC_FC_TILING="0"))]
+    if N == 449:
+        cases.append((24, None))
+        assert pack.plan_fullcov(3, H)["shared_cross_units"] == 0
+    for B, env in cases:
+        for k, v in (env or {}).items():
+            monkeypatch.setenv(k, v)
+        pack.reload_tuning()
+        plan = pack.plan_fullcov(B, H)
+        assert plan["form"] == "two_launch" and plan["shared_cross_units"] == (1 if ds <= 4 else 0), plan
+        r = G.rollout_fullcov(pack, pb["x0"][:B], pb["U"][:B], cost)
+        f = G.rollout_fullcov(pack, pb["x0"][:B], pb["U"][:B], cost, want_grad=False)
+        for k in (env or {}):
+            monkeypatch.delenv(k)
+        pack.reload_tuning()
+        assert all(torch.isfinite(v).all() for v in r.values())
+        pick = [0, B - 1]
+        dirs = rng.normal(size=(2, 2, H, da))
+        c = cport.rollout_fullcov(pb, kinv, -1.0, x0=pb["x0"][pick], U=pb["U"][pick], dirs=dirs, nthreads=8)
+        np.testing.assert_allclose(r["means"][pick].cpu().numpy(), c["means"], rtol=1e-5, atol=1e-9, err_msg=f"B={B}")
+        np.testing.assert_allclose(r["covs"][pick].cpu().numpy(), c["covs"], rtol=1e-4, atol=1e-6 * np.abs(c["covs"]).max(), err_msg=f"B={B}")
+        np.testing.assert_allclose(r["cost"][pick].cpu().numpy(), c["cost"], rtol=1e-6, err_msg=f"B={B}")
+        g = r["grad"][pick].cpu().numpy()
+        for k in range(2):
+            for d in range(2):
+                np.testing.assert_allclose(float((g[k] * dirs[k, d]).sum()), c["ddir"][k, d], rtol=1e-4, atol=1e-7, err_msg=f"B={B} {k} {d}")
+        np.testing.assert_allclose(f["cost"].cpu().numpy(), r["cost"].cpu().numpy(), rtol=1e-9)
+        np.testing.assert_allclose(f["covs"].cpu().numpy(), r["covs"].cpu().numpy(), rtol=1e-9, atol=1e-14)
+    # the same pack with the sharing off and forced on: the forms agree far inside the tolerance against the C port
+    monkeypatch.setenv("GPMPC_FC_SHARED", "0")
+    pack.reload_tuning()
+    assert pack.plan_fullcov(3, H)["shared_cross_units"] == 0
+    u = G.rollout_fullcov(pack, pb["x0"][:3], pb["U"][:3], cost)
+    monkeypatch.setenv("GPMPC_FC_SHARED", "1")
+    pack.reload_tuning()
+    r = G.rollout_fullcov(pack, pb["x0"][:3], pb["U"][:3], cost)
+    monkeypatch.delenv("GPMPC_FC_SHARED")
+    pack.reload_tuning()
+    for key in ("means", "covs", "cost", "grad"):
+        np.testing.assert_allclose(r[key].cpu().numpy(), u[key].cpu().numpy(), rtol=1e-5, atol=1e-8 * float(u[key].abs().max()), err_msg=key)
+
+
 @pytest.mark.parametrize("ds,da", [(2, 1), (2, 2), (3, 1), (3, 2), (4, 1), (4, 2), (5, 1), (5, 2), (6, 1), (6, 2)])
 def test_fullcov_rollout_every_shape_vs_cport(G, ds, da, monkeypatch):
     """Full-covariance rollout (config 5 semantics): the staged kernel (small batch) and pair_kernel_sbf.h (large batch)

@@ -11,6 +11,7 @@ if [ $STEP = all ] || [ $STEP = trace ]; then
 # kernel traces (rocprofv3 --kernel-trace --stats)
 for c in C3 C4 C5; do bash tools/prof_trace.sh $c > $O/trace_$c.log 2>&1; cp gpurun_out/trace_$c/kernel_stats_$c.csv gpurun_out/trace_$c/bench_traced_$c.json $O/ 2>/dev/null; done
 bash tools/prof_trace.sh C3 --shared-lambda > $O/trace_C3_shared.log 2>&1; cp gpurun_out/trace_C3/kernel_stats_C3.csv $O/kernel_stats_C3_shared.csv; cp gpurun_out/trace_C3/bench_traced_C3.json $O/bench_traced_C3_shared.json
+bash tools/prof_trace.sh C5 --shared-lambda > $O/trace_C5_shared.log 2>&1; cp gpurun_out/trace_C5/kernel_stats_C5.csv $O/kernel_stats_C5_shared.csv; cp gpurun_out/trace_C5/bench_traced_C5.json $O/bench_traced_C5_shared.json
 bash tools/prof_trace.sh C3 --batch 1 > $O/trace_C3_B1.log 2>&1; cp gpurun_out/trace_C3/kernel_stats_C3.csv $O/kernel_stats_C3_B1.csv; cp gpurun_out/trace_C3/bench_traced_C3.json $O/bench_traced_C3_B1.json
 bash tools/prof_trace.sh C3 --batch 8 > $O/trace_C3_B8.log 2>&1; cp gpurun_out/trace_C3/kernel_stats_C3.csv $O/kernel_stats_C3_B8.csv; cp gpurun_out/trace_C3/bench_traced_C3.json $O/bench_traced_C3_B8.json
 bash tools/prof_trace.sh C4 --batch 1 > $O/trace_C4_B1.log 2>&1; cp gpurun_out/trace_C4/kernel_stats_C4.csv $O/kernel_stats_C4_B1.csv; cp gpurun_out/trace_C4/bench_traced_C4.json $O/bench_traced_C4_B1.json
@@ -36,6 +37,8 @@ fi
 if [ $STEP = all ] || [ $STEP = bench ]; then
 python bench.py > $O/bench_C3.json 2> $O/bench_C3.err; grep '^BENCH_FULL ' $O/bench_C3.err | sed 's/^BENCH_FULL //' > $O/bench_C3_full.json || echo "bench C3 failed"
 python bench.py --config C3 --shared-lambda --no-cpu-baseline --full-json --no-legs > $O/bench_C3_shared.json 2>/dev/null || echo "bench C3 shared failed"
+python bench.py --config C5 --shared-lambda --steps 5 --warmup 2 --no-cpu-baseline --full-json > $O/bench_C5_shared.json 2>/dev/null || echo "bench C5 shared failed"
+for b in 1 8 64; do python bench.py --config C5 --shared-lambda --batch $b --steps 10 --warmup 3 --no-cpu-baseline --full-json --no-extras > $O/bench_C5_shared_B$b.json 2>/dev/null; done
 for c in C4 C5; do python bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline --full-json > $O/bench_$c.json 2>/dev/null || echo "bench $c failed"; done
 for c in C1 C2; do
   python bench.py --config $c --steps 200 --warmup 20 --no-cpu-baseline --full-json > $O/bench_$c.json 2>/dev/null

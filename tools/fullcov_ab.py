@@ -16,7 +16,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--shapes", default="2048:4:1:20,1024:4:1:20,512:3:1:20,300:4:1:10")
 ap.add_argument("--batches", default="1,2,4,8,16")
 ap.add_argument("--forms", default="old:0:-1,two64:1:2,two128:1:4,two256:1:0,default:-1:-1",
-                help="name:GPMPC_FC_FORM:GPMPC_FC_TILING[:GPMPC_FC_CU[:GPMPC_FC_RSPLIT]] (-1: unset)")
+                help="name:GPMPC_FC_FORM:GPMPC_FC_TILING[:GPMPC_FC_CU[:GPMPC_FC_RSPLIT[:GPMPC_FC_SHARED]]] (-1: unset)")
+ap.add_argument("--shared-lambda", action="store_true", help="one lambda for all GPs (the reference's experiments)")
 args = ap.parse_args()
 dev = g.require_gpu()
 forms = [f.split(":") for f in args.forms.split(",")]
@@ -24,7 +25,7 @@ forms = [f.split(":") for f in args.forms.split(",")]
 for shape in args.shapes.split(","):
     N, ds, da, H = (int(v) for v in shape.split(":"))
     bmax = max(int(b) for b in args.batches.split(","))
-    pb = synth_problem(3, N, ds, da, H, bmax)
+    pb = synth_problem(3, N, ds, da, H, bmax, shared_lambda=args.shared_lambda)
     X = torch.as_tensor(pb["X"], device=dev)
     Y = torch.as_tensor(pb["Y"], device=dev)
     kinv = []
@@ -44,7 +45,8 @@ for shape in args.shapes.split(","):
             name, form, tiling = spec[:3]
             cu = spec[3] if len(spec) > 3 else "-1"
             rsp = spec[4] if len(spec) > 4 else "-1"
-            for k, v in (("GPMPC_FC_FORM", form), ("GPMPC_FC_TILING", tiling), ("GPMPC_FC_CU", cu), ("GPMPC_FC_RSPLIT", rsp)):
+            fsh = spec[5] if len(spec) > 5 else "-1"
+            for k, v in (("GPMPC_FC_FORM", form), ("GPMPC_FC_TILING", tiling), ("GPMPC_FC_CU", cu), ("GPMPC_FC_RSPLIT", rsp), ("GPMPC_FC_SHARED", fsh)):
                 if v == "-1":
                     os.environ.pop(k, None)
                 else:
@@ -67,5 +69,5 @@ for shape in args.shapes.split(","):
                 err = max(float((r[k] - ref[k]).abs().max() / ref[k].abs().max()) for k in ("cost", "grad", "covs"))
             line += f"  {name}: {dt * 1e3:8.3f} ms ~{err:.0e}"
         print(line, flush=True)
-    for k in ("GPMPC_FC_FORM", "GPMPC_FC_TILING", "GPMPC_FC_CU", "GPMPC_FC_RSPLIT"):
+    for k in ("GPMPC_FC_FORM", "GPMPC_FC_TILING", "GPMPC_FC_CU", "GPMPC_FC_RSPLIT", "GPMPC_FC_SHARED"):
         os.environ.pop(k, None)

@@ -34,15 +34,20 @@ for case in range(n_cases):
           "two128": {"GPMPC_FC_FORM": "1", "GPMPC_FC_TILING": "4"}, "two256c4": {"GPMPC_FC_FORM": "1", "GPMPC_FC_TILING": "0", "GPMPC_FC_CU": "4"},
           "two64c1r3": {"GPMPC_FC_FORM": "1", "GPMPC_FC_TILING": "2", "GPMPC_FC_CU": "1", "GPMPC_FC_RSPLIT": "3"},
           "two64c2r1": {"GPMPC_FC_FORM": "1", "GPMPC_FC_TILING": "2", "GPMPC_FC_CU": "2", "GPMPC_FC_RSPLIT": "1"}}
-    for k in ("GPMPC_FC_FORM", "GPMPC_FC_TILING", "GPMPC_FC_CU", "GPMPC_FC_RSPLIT"):
+    for k in ("GPMPC_FC_FORM", "GPMPC_FC_TILING", "GPMPC_FC_CU", "GPMPC_FC_RSPLIT", "GPMPC_FC_SHARED"):
         os.environ.pop(k, None)
     os.environ.update(FC[fc])
+    # round 5: one lambda for all GPs on 40 % of the cases, the shared cross-unit kernel (pair_kernel_sbfx.h) forced on / off / by the plan
+    shared = bool(rng.random() < 0.4)
+    fsh = str(rng.choice(["on", "on", "off", "plan"])) if shared else "plan"
+    if fsh != "plan":
+        os.environ["GPMPC_FC_SHARED"] = "1" if fsh == "on" else "0"
     os.environ.pop("GPMPC_PAIR_SB", None)
     if sb == "staged":
         os.environ["GPMPC_PAIR_SB"] = "0"
     elif sb == "sbf":
         os.environ["GPMPC_PAIR_SB"] = "1"
-    pb = synth_problem(7000 + case, N, ds, da, H, B)
+    pb = synth_problem(7000 + case, N, ds, da, H, B, shared_lambda=shared)
     pb["Q"] = pb["Q"] + 0.02 * (np.ones((ds, ds)) - np.eye(ds))
     kinv = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"]).Ky_inv.numpy()
     pack = g.GPPack(pb["X"], pb["Y"], kinv, pb["lambdas"], pb["sigma_f"])
@@ -58,9 +63,10 @@ for case in range(n_cases):
     dd = np.array([float((gr[k] * dirs[k, 0]).sum()) for k in range(len(pick))])
     err["ddir"] = rel(dd, c["ddir"][:, 0], 1e-3)
     finite = all(bool(torch.isfinite(v).all()) for v in r.values())
+    lab = ("sh-" + fsh) if shared else "distinct"
     ok = finite and err["means"] < 1e-5 and err["covs"] < 1e-4 and err["cost"] < 1e-6 and err["ddir"] < 1e-4
     bad += 0 if ok else 1
-    print(f"case {case:3d}: N={N:4d} ds={ds} da={da} H={H} B={B:4d} gamma={gamma:g} {sb:6s} {fc:9s} "
+    print(f"case {case:3d}: N={N:4d} ds={ds} da={da} H={H} B={B:4d} gamma={gamma:g} {sb:6s} {fc:9s} {lab:8s} "
           + " ".join(f"{k} {v:.1e}" for k, v in err.items()) + ("" if ok else "   <-- FAIL"), flush=True)
     for k in worst:
         worst[k] = max(worst[k], err[k])
