@@ -635,7 +635,8 @@ def run_rank(args):
         achieved = pairs_per_launch * fl / launch_s / 1e12
         m_bytes = 8 * (ds * N * (N + 1) / 2 + (ds * (ds - 1) / 2 * N * N if (fullcov and not cross_elsewhere) else 0))     # M read once per launch
         sm = "sbf" if fullcov else ("sbs" if shared else "sb")
-        traffic, traffic_src = (None, None) if args.n_train else measured_traffic(args.config, B, want_grad, sm)
+        # (no sidecar for the launch that covers the variance units only: the recorded counters belong to the per-unit launch)
+        traffic, traffic_src = (None, None) if (args.n_train or cross_elsewhere) else measured_traffic(args.config, B, want_grad, sm)
         ng = 0
         if shared:                                             # GPs per workgroup: gpmpc_sbs_group (gpmpc_internal.h)
             cap = max(2, min(4, 48 // (1 + D + ds)))

@@ -421,7 +421,7 @@ extern "C" int gpmpc_debug_fc_stamps(unsigned long long* host_out) {      // [64
 }
 #endif
 
-struct FcPlan2 { int tiling, waves, nwork, nunits, nm, pps, sps, gw, rsplit, cu, fcs /* one lambda: the cross units by pair_kernel_sbfx.h */, ntri /* work items of the variance units */; size_t off_part0, off_pp, off_sp0, off_sp1, off_part, off_G, off_dmu, off_dmS, off_dcu, off_dcS, total; };
+struct FcPlan2 { int tiling, waves, nwork, nunits, nm, pps, sps, gw, rsplit, cu, fcs /* one lambda: the cross units by pair_kernel_sbfx.h */, fcs_q /* its tile width: 0 64 columns | 1 16 */, ntri /* work items of the variance units */; size_t off_part0, off_pp, off_sp0, off_sp1, off_part, off_G, off_dmu, off_dmS, off_dcu, off_dcS, total; };
 
 // 1: the two-launch form applies and is taken (GPMPC_FC_FORM = 0 / 1 forces)
 static int plan_fc2(const gpmpc_pack* p, int B, int H, bool grad, FcPlan2* r) {
@@ -448,9 +448,12 @@ static int plan_fc2(const gpmpc_pack* p, int B, int H, bool grad, FcPlan2* r) {
     // of pair_kernel_sbfx.h over the pairs serves all of them without a weight stream, pair_kernel_sbf.h keeps the variance units (their
     // weights hold K_a^-1).  A trajectory's partial-sum slots: the variance units' work items, then pairs x 64x64 tiles.  GPMPC_FC_SHARED=0: off.
     {
-        r->fcs = (fcs_can && p->fcs_ustart_dev[r->tiling]) ? 1 : 0;
+        r->fcs = (fcs_can && p->fcs_ustart_dev[r->tiling][0]) ? 1 : 0;
         r->ntri = w.ustart_host[p->ds];
-        if (r->fcs) r->nwork = p->fcs_total[r->tiling];
+        // 16-column tiles while the 64-column ones would put fewer than two waves on a SIMD (a wave's column takes ~1.2 k cycles on its own:
+        // scalar loads of two rows, the dependent exponent and exp, ds x 17 accumulations)
+        r->fcs_q = (r->fcs && (long)B * p->fcs_ntile[0] < 2 * 4 * (long)(p->num_cu > 0 ? p->num_cu : 256)) ? 1 : 0;
+        if (r->fcs) r->nwork = p->fcs_total[r->tiling][r->fcs_q];
     }
     r->nm = gpmpc_num_moments(p->D, false, grad);
     // workgroups per (trajectory, unit) of the head kernel: one per 256 rows of column rows while the launch stays within ~4 per CU
@@ -492,7 +495,7 @@ static int run_fc2(const gpmpc_pack* p, const FcPlan2& r, FcArgs& T, bool grad, 
     M.N = p->N; M.Np = p->Np; M.ds = p->ds; M.D = p->D; M.nq = B;
     M.pp = (double*)(ws + r.off_pp); M.part = (double*)(ws + r.off_part);
     M.pps = r.pps; M.sps = r.sps; M.nwork = r.nwork; M.nunits = r.nunits; M.nm = r.nm; M.grad = grad ? 1 : 0;
-    M.ustart = r.fcs ? p->fcs_ustart_dev[r.tiling] : p->wl[1][r.tiling].ustart_dev;
+    M.ustart = r.fcs ? p->fcs_ustart_dev[r.tiling][r.fcs_q] : p->wl[1][r.tiling].ustart_dev;
     M.pair_ab = p->pair_ab_dev; M.npairs = p->npairs;
     M.G = (double*)(ws + r.off_G); M.gw = r.gw; M.ns2 = p->ds;
     A.x0 = T.x0; A.U = T.U; A.B = B; A.H = H; A.da = p->da;
@@ -512,7 +515,7 @@ static int run_fc2(const gpmpc_pack* p, const FcPlan2& r, FcArgs& T, bool grad, 
         X.XT = p->XT; X.lam = p->lam; X.beta = p->beta; X.sf = p->sf; X.pp = M.pp; X.G = M.G; X.rows = p->fcs_rows;
         X.part = M.part; X.part0 = Q.part0; X.pair_ab = p->pair_ab_dev;
         X.Np = p->Np; X.N = p->N; X.B = B; X.nunits = r.nunits; X.unit0 = p->ds; X.pps = r.pps; X.nm = r.nm;
-        X.tj = p->fcs_tj; X.ntile = p->fcs_ntile; X.base = p->fcs_base[r.tiling]; X.pstride = r.nwork;
+        X.tj = p->fcs_tj; X.ntile = p->fcs_ntile[r.fcs_q]; X.jt = r.fcs_q ? 16 : 64; X.base = p->fcs_base[r.tiling]; X.pstride = r.nwork;
     }
     for (int t = 1; t <= H + 1; ++t) {
         M.sp = sp[t & 1]; A.sp_prev = sp[(t - 1) & 1];
@@ -579,8 +582,8 @@ extern "C" int gpmpc_rollout_fullcov_describe(const gpmpc_pack* p, int B, int H,
     if (plan_fc2(p, B, H, grad, &r2)) {
         const gpmpc_worklist& w = p->wl[1][r2.tiling];
         snprintf(out, out_bytes, "form=two_launch tiling=%dx%d workgroups=%ld columns_per_iteration=%d head_workgroups_per_unit=%d "
-                 "kernel=gpmpc_pair_kernel_sbf<%d,%d,%s,%d>%s shared_cross_units=%d", w.it, w.jt, (long)B * (r2.fcs ? r2.ntri : r2.nwork), r2.cu, r2.rsplit, p->D, p->ds,
-                 grad ? "true" : "false", r2.cu, r2.fcs ? "+gpmpc_pair_kernel_sbfx" : "", r2.fcs);
+                 "kernel=gpmpc_pair_kernel_sbf<%d,%d,%s,%d>%s shared_cross_units=%d cross_tile_columns=%d", w.it, w.jt, (long)B * (r2.fcs ? r2.ntri : r2.nwork), r2.cu, r2.rsplit, p->D, p->ds,
+                 grad ? "true" : "false", r2.cu, r2.fcs ? "+gpmpc_pair_kernel_sbfx" : "", r2.fcs, r2.fcs ? (r2.fcs_q ? 16 : 64) : 0);
     } else {
         snprintf(out, out_bytes, "form=four_launch tiling=by_gpmpc_moment_match workgroups=0 columns_per_iteration=1 "
                  "head_workgroups_per_unit=1 kernel=gpmpc_pair_kernel_sbf<%d,%d,%s,1>|staged", p->D, p->ds, grad ? "true" : "false");

@@ -70,8 +70,10 @@ struct gpmpc_pack {
     // one lambda for all GPs, full-covariance rollout (pair_kernel_sbfx.h): constant column rows [Np][fcs_rw] (refreshed by every build while
     // `fullcov`), and per tri-unit tiling k of wl[1][k] the unit offsets into a trajectory's partial-sum slots: tri units as in that work list,
     // cross unit pr at fcs_base[k] + pr * fcs_ntile
-    double* fcs_rows; int fcs_rw, fcs_ntile, fcs_tj;
-    int* fcs_ustart_dev[8]; int fcs_base[8], fcs_total[8];
+    double* fcs_rows; int fcs_rw, fcs_tj;
+    // (two tile widths: 64 columns per wave for launches that fill the chip, 16 for small ones -- four times the waves, each a quarter as long)
+    int fcs_ntile[2];                                  // tiles per trajectory: [0] 64 x 64, [1] 64 x 16
+    int* fcs_ustart_dev[8][2]; int fcs_base[8], fcs_total[8][2];
     int ncol_host;      // the value last written to ncol_dev
     int* ncol_dev;      // [1] columns that carry weight: N rounded up to 8 (<= Np); written by every pack build (traj_persist.h reads it)
     double* X;      // dev [Np][D], rows >= N zero
@@ -158,7 +160,7 @@ struct PairSbfxArgs {
     double* part; double* part0;           // partial sums, slots base + pair * ntile + tile of a trajectory's pstride slots
     const int* pair_ab;
     int Np, N, B, nunits, unit0, pps, nm;
-    int tj, ntile;                         // column tiles per row block, tiles per trajectory ((Np / 64) * tj)
+    int tj, ntile, jt;                     // 64-row blocks per side, tiles per trajectory (T (T + 1) / 2 * 64 / jt), columns per tile (64 | 16)
     int base, pstride;
 };
 template <int D> int gpmpc_launch_pair_sbfx_D(bool grad, int ns2, const PairSbfxArgs& a, hipStream_t s);

@@ -133,7 +133,8 @@ static int fcs_refresh(gpmpc_pack* p, hipStream_t s) {
     if (!p->fullcov || p->npairs == 0 || !p->shared_lambda || p->ds < 2 || p->ds > 4 || p->D - p->ds < 1 || p->D - p->ds > 2) return GPMPC_OK;
     if (!p->fcs_rows) {
         p->fcs_rw = (p->D + 1 + p->ds + 1) & ~1;
-        p->fcs_tj = p->Np / 64; p->fcs_ntile = p->fcs_tj * (p->fcs_tj + 1) / 2;   // 64 x 64 tiles of the upper triangle (pair_kernel_sbfx.h)
+        p->fcs_tj = p->Np / 64;
+        p->fcs_ntile[0] = p->fcs_tj * (p->fcs_tj + 1) / 2; p->fcs_ntile[1] = 4 * p->fcs_ntile[0];   // 64 x 64 | 64 x 16 tiles of the upper triangle (pair_kernel_sbfx.h)
         if (hipMalloc(&p->fcs_rows, sizeof(double) * (size_t)p->Np * p->fcs_rw) != hipSuccess) { p->fcs_rows = nullptr; return GPMPC_E_ALLOC; }
         for (int k : {0, 2, 4}) {
             const gpmpc_worklist& w = p->wl[1][k];
@@ -141,11 +142,14 @@ static int fcs_refresh(gpmpc_pack* p, hipStream_t s) {
             int ust[GPMPC_MAX_DS + GPMPC_MAX_PAIRS + 1];
             const int ntri = w.ustart_host[p->ds];
             for (int u = 0; u <= p->ds; ++u) ust[u] = w.ustart_host[u];
-            for (int pr = 1; pr <= p->npairs; ++pr) ust[p->ds + pr] = ntri + pr * p->fcs_ntile;
-            p->fcs_base[k] = ntri; p->fcs_total[k] = ntri + p->npairs * p->fcs_ntile;
+            p->fcs_base[k] = ntri;
             const size_t nb = sizeof(int) * (p->ds + p->npairs + 1);
-            if (hipMalloc(&p->fcs_ustart_dev[k], nb) != hipSuccess) { p->fcs_ustart_dev[k] = nullptr; return GPMPC_E_ALLOC; }
-            GPMPC_HIP(hipMemcpy(p->fcs_ustart_dev[k], ust, nb, hipMemcpyHostToDevice));
+            for (int q = 0; q < 2; ++q) {
+                for (int pr = 1; pr <= p->npairs; ++pr) ust[p->ds + pr] = ntri + pr * p->fcs_ntile[q];
+                p->fcs_total[k][q] = ntri + p->npairs * p->fcs_ntile[q];
+                if (hipMalloc(&p->fcs_ustart_dev[k][q], nb) != hipSuccess) { p->fcs_ustart_dev[k][q] = nullptr; return GPMPC_E_ALLOC; }
+                GPMPC_HIP(hipMemcpy(p->fcs_ustart_dev[k][q], ust, nb, hipMemcpyHostToDevice));
+            }
         }
     }
     hipLaunchKernelGGL(k_pack_fcs_rows, dim3((p->Np + 255) / 256), dim3(256), 0, s, p->beta, p->XT, p->lam, p->N, p->Np, p->D, p->ds,
@@ -464,7 +468,7 @@ extern "C" int gpmpc_pack_destroy(gpmpc_pack* p) {
     gpmpc_lock_destroy(p->lock);
     if (p->pair_ab_dev) (void)hipFree(p->pair_ab_dev);
     if (p->fcs_rows) (void)hipFree(p->fcs_rows);
-    for (int k = 0; k < 8; ++k) if (p->fcs_ustart_dev[k]) (void)hipFree(p->fcs_ustart_dev[k]);
+    for (int k = 0; k < 8; ++k) for (int q = 0; q < 2; ++q) if (p->fcs_ustart_dev[k][q]) (void)hipFree(p->fcs_ustart_dev[k][q]);
     for (int mode = 0; mode < 2; ++mode)
         for (int k = 0; k < 8; ++k) {
             if (p->wl[mode][k].work_dev) (void)hipFree(p->wl[mode][k].work_dev);

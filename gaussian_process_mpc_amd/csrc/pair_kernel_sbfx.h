@@ -14,7 +14,7 @@
 #include "gpmpc_internal.h"
 #include "fast_exp.h"
 
-// One wave per 64 x 64 tile of the UPPER TRIANGLE (the shared transform makes Q_ij f(p_i + q_j) symmetric in (i, j), so
+// One wave per 64 x 64 (or 64 x 16: small launches) tile of the UPPER TRIANGLE (the shared transform makes Q_ij f(p_i + q_j) symmetric in (i, j), so
 //     S_ab = sum_ij beta_a,i beta_b,j W_ij = sum_i [beta_a,i T_b,i + beta_b,i T_a,i],   T_c,i = sum_{j >= i} w_ij beta_c,j W_ij,  w_ii = 1/2, w_ij = 1 (j > i)
 // -- half the pairs of the full square, all ds accumulator sets); four tiles per workgroup: one exp table in LDS for four waves.
 __device__ __forceinline__ void gpmpc_sbfx_tri_decode(int q, int T, int* r_out, int* c_out) {      // (as step_fused.h::gpmpc_tri_decode)
@@ -45,10 +45,12 @@ __global__ __launch_bounds__(256, 2) void gpmpc_pair_kernel_sbfx(PairSbfxArgs A)
     const int tile = live ? tile_r : A.ntile - 1;
     double* s_red = s_redw[w];
     const int Np = A.Np;
+    // tile -> (64-row block ti, 64-column block tjx >= ti, piece of A.jt columns of that block)
+    const int per = 64 / A.jt, blk = tile / per, sub = tile - blk * per;
     int ti, tjx;
-    gpmpc_sbfx_tri_decode(tile, Np >> 6, &ti, &tjx);
+    gpmpc_sbfx_tri_decode(blk, Np >> 6, &ti, &tjx);
     ti = __builtin_amdgcn_readfirstlane(ti); tjx = __builtin_amdgcn_readfirstlane(tjx);
-    const int i0 = ti * 64, j0 = tjx * 64;
+    const int i0 = ti * 64, j0 = tjx * 64 + sub * A.jt, jn = A.jt;
     const int i = i0 + lane;                                   // (Np is a multiple of 64)
     const double* __restrict__ prm = A.pp + ((size_t)b * A.nunits + A.unit0) * A.pps;
     const double* __restrict__ G = A.G + ((size_t)b * A.nunits + A.unit0) * Np * GW;
@@ -102,10 +104,10 @@ __global__ __launch_bounds__(256, 2) void gpmpc_pair_kernel_sbfx(PairSbfxArgs A)
             }
         }
     };
-    if (j0 > i0) {                                             // (wave-uniform)
-        for (int jc = j0; jc < j0 + 64; ++jc) column(jc, 1.0, false);
-    } else {                                                   // diagonal tile: column j of row i counts once (j > i), half (j = i) or not at all
-        for (int jl = 0; jl < 64; ++jl) column(j0 + jl, jl > lane ? 1.0 : (jl == lane ? 0.5 : 0.0), true);
+    if (tjx > ti) {                                            // (wave-uniform)
+        for (int jc = j0; jc < j0 + jn; ++jc) column(jc, 1.0, false);
+    } else {                                                   // diagonal block: column j of row i counts once (j > i), half (j = i) or not at all
+        for (int jc = j0; jc < j0 + jn; ++jc) { const int jl = jc - i0; column(jc, jl > lane ? 1.0 : (jl == lane ? 0.5 : 0.0), true); }
     }
 
     // row-side combination in place (pair_kernel_sbf.h, same expressions): acc[c] -> the 1 + D + NW moments of column GP c that can be non-zero
@@ -177,7 +179,7 @@ static int launch_pair_sbfx_one(const PairSbfxArgs& a, hipStream_t s) {
 // the rollout's shapes only: ns2 = state_dim in {D - 1, D - 2}, 2 <= state_dim <= 4 (ds accumulator sets of 1 + D + ds (ds + 1) / 2 doubles per lane)
 template <int D>
 int gpmpc_launch_pair_sbfx_D(bool grad, int ns2, const PairSbfxArgs& a, hipStream_t s) {
-    if (a.nm != (grad ? 1 + D + D * (D + 1) / 2 : 1) || ns2 < 2 || ns2 > 4 || a.ntile < 1) return GPMPC_E_ARG;
+    if (a.nm != (grad ? 1 + D + D * (D + 1) / 2 : 1) || ns2 < 2 || ns2 > 4 || a.ntile < 1 || (a.jt != 64 && a.jt != 16)) return GPMPC_E_ARG;
 #define GPMPC_SBFX_CASE(GR, NSV)                                                                              \
     if constexpr ((NSV) >= 2 && (NSV) <= 4 && (NSV) < D) if (grad == GR && ns2 == (NSV)) return launch_pair_sbfx_one<D, ((NSV) >= 2 && (NSV) <= 4 && (NSV) < D) ? (NSV) : 2, GR>(a, s);
     GPMPC_SBFX_CASE(true, D - 1) GPMPC_SBFX_CASE(true, D - 2) GPMPC_SBFX_CASE(false, D - 1) GPMPC_SBFX_CASE(false, D - 2)
