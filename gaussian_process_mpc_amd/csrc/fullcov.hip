@@ -450,9 +450,10 @@ static int plan_fc2(const gpmpc_pack* p, int B, int H, bool grad, FcPlan2* r) {
     {
         r->fcs = (fcs_can && p->fcs_ustart_dev[r->tiling][0]) ? 1 : 0;
         r->ntri = w.ustart_host[p->ds];
-        // 16-column tiles while the 64-column ones would put fewer than two waves on a SIMD (a wave's column takes ~1.2 k cycles on its own:
-        // scalar loads of two rows, the dependent exponent and exp, ds x 17 accumulations)
-        r->fcs_q = (r->fcs && (long)B * p->fcs_ntile[0] < 2 * 4 * (long)(p->num_cu > 0 ? p->num_cu : 256)) ? 1 : 0;
+        // 16-column tiles for the smallest launches (a wave's column takes ~1.2 k cycles on its own: scalar loads of two rows, the dependent exponent
+        // and exp, ds x 17 accumulations -- four times the waves, each a quarter as long: N = 2048, B = 1 1.63 -> 1.56 ms, N = 1024, B = 1 1.53 -> 1.12,
+        // N = 300, ds = 4, B = 1 0.75 -> 0.55; from ~800 tiles of 64 columns the wide ones are ahead: N = 2048, B = 2 1.84 | 2.02 -- fullcov_shared_ab2.txt)
+        r->fcs_q = (r->fcs && (long)B * p->fcs_ntile[0] < 800) ? 1 : 0;
         if (r->fcs) r->nwork = p->fcs_total[r->tiling][r->fcs_q];
     }
     r->nm = gpmpc_num_moments(p->D, false, grad);

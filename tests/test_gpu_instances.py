@@ -108,7 +108,7 @@ def test_fullcov_rollout_with_one_lambda_vs_cport(G, ds, da, N, monkeypatch):
     from oracle import cport, gpmpc_oracle as O
     from gaussian_process_mpc_amd.synth import synth_problem
     H = 3
-    bmax = 60 if N == 449 else 5
+    bmax = 24 if N == 449 else 5
     pb = synth_problem(80 + 8 * ds + da, N, ds, da, H, bmax, shared_lambda=True)
     pb["Q"] = pb["Q"] + 0.02 * (np.ones((ds, ds)) - np.eye(ds))
     kinv = O.GPBundle(pb["X"], pb["Y"], pb["lambdas"], pb["sigma_f"], pb["sigma_n"]).Ky_inv.numpy()
@@ -117,11 +117,11 @@ def test_fullcov_rollout_with_one_lambda_vs_cport(G, ds, da, N, monkeypatch):
     rng = np.random.default_rng(ds * 10 + da)
     pack.enable_fullcov()                            # (rollout_fullcov does it on first use; the plan is asked for before that here)
     # the plan takes the shared form from B Np^2 pairs >= 3.5e7 (fullcov.hip::plan_fc2): forced on for the small shapes of this test
-    # (GPMPC_FC_SHARED=1), and taken by the default plan at N = 449 (Np = 512), ds = 4, B = 24 / 60
+    # (GPMPC_FC_SHARED=1), and taken by the default plan at N = 449 (Np = 512), ds = 4, B = 24
     forced = {"GPMPC_FC_SHARED": "1"}
     cases = [(1, forced), (3, forced), (5, dict(forced, GPMPC_FC_TILING="4")), (2, dict(forced, GPMPC_FC_TILING="0"))]
-    if N == 449:                                     # (B = 24: 16-column tiles -- fewer than two waves per SIMD on 64 columns --, B = 60: 64-column tiles)
-        cases += [(24, None), (60, None)]
+    if N == 449:                                     # (B = 24, 36 tiles of 64 columns each: 864 -> 64-column tiles by the default plan; the forced small batches: 16-column tiles)
+        cases += [(24, None)]
         assert pack.plan_fullcov(3, H)["shared_cross_units"] == 0
     for B, env in cases:
         for k, v in (env or {}).items():
@@ -130,7 +130,7 @@ def test_fullcov_rollout_with_one_lambda_vs_cport(G, ds, da, N, monkeypatch):
         plan = pack.plan_fullcov(B, H)
         assert plan["form"] == "two_launch" and plan["shared_cross_units"] == (1 if ds <= 4 else 0), plan
         if ds <= 4:
-            assert plan["cross_tile_columns"] == (64 if B == 60 else 16), plan
+            assert plan["cross_tile_columns"] == (64 if B == 24 else 16), plan
         r = G.rollout_fullcov(pack, pb["x0"][:B], pb["U"][:B], cost)
         f = G.rollout_fullcov(pack, pb["x0"][:B], pb["U"][:B], cost, want_grad=False)
         for k in (env or {}):
