@@ -48,6 +48,8 @@ __global__ __launch_bounds__(256, 2) void gpmpc_pair_kernel_sbfx(PairSbfxArgs A)
     // tile -> (64-row block ti, 64-column block tjx >= ti, piece of A.jt columns of that block)
     const int per = 64 / A.jt, blk = tile / per, sub = tile - blk * per;
     int ti, tjx;
+    // (measured and dropped: a column-major block order -- the four waves of a workgroup on the SAME column rows -- and three waves per SIMD
+    // (12 VGPR spills): both level at B = 2 ... 256, N = 2048: the kernel is near its issue bound there, a third of it prologue and row sums)
     gpmpc_sbfx_tri_decode(blk, Np >> 6, &ti, &tjx);
     ti = __builtin_amdgcn_readfirstlane(ti); tjx = __builtin_amdgcn_readfirstlane(tjx);
     const int i0 = ti * 64, j0 = tjx * 64 + sub * A.jt, jn = A.jt;
