@@ -454,6 +454,13 @@ static int plan_fc2(const gpmpc_pack* p, int B, int H, bool grad, FcPlan2* r) {
         // and exp, ds x 17 accumulations -- four times the waves, each a quarter as long: N = 2048, B = 1 1.63 -> 1.56 ms, N = 1024, B = 1 1.53 -> 1.12,
         // N = 300, ds = 4, B = 1 0.75 -> 0.55; from ~800 tiles of 64 columns the wide ones are ahead: N = 2048, B = 2 1.84 | 2.02 -- fullcov_shared_ab2.txt)
         r->fcs_q = (r->fcs && (long)B * p->fcs_ntile[0] < 800) ? 1 : 0;
+        // ... and up to 256 columns per wave once the launch fills the chip many times over (N = 2048, ds = 4: B = 16 8.5 | 9.5 ms, B = 64 29.0 | 28.0,
+        // B = 256 116.0 | 109.4; GPMPC_FC_XTILE=0|1|2 forces a width)
+        if (r->fcs && (long)B * p->fcs_ntile[0] >= 24000 && p->fcs_tiles256_dev) r->fcs_q = 2;
+        {
+            static const int xt = getenv("GPMPC_FC_XTILE") ? atoi(getenv("GPMPC_FC_XTILE")) : -1;
+            if (r->fcs && xt >= 0 && xt <= 2 && (xt < 2 || p->fcs_tiles256_dev)) r->fcs_q = xt;
+        }
         if (r->fcs) r->nwork = p->fcs_total[r->tiling][r->fcs_q];
     }
     r->nm = gpmpc_num_moments(p->D, false, grad);
@@ -516,7 +523,8 @@ static int run_fc2(const gpmpc_pack* p, const FcPlan2& r, FcArgs& T, bool grad, 
         X.XT = p->XT; X.lam = p->lam; X.beta = p->beta; X.sf = p->sf; X.pp = M.pp; X.G = M.G; X.rows = p->fcs_rows;
         X.part = M.part; X.part0 = Q.part0; X.pair_ab = p->pair_ab_dev;
         X.Np = p->Np; X.N = p->N; X.B = B; X.nunits = r.nunits; X.unit0 = p->ds; X.pps = r.pps; X.nm = r.nm;
-        X.tj = p->fcs_tj; X.ntile = p->fcs_ntile[r.fcs_q]; X.jt = r.fcs_q ? 16 : 64; X.base = p->fcs_base[r.tiling]; X.pstride = r.nwork;
+        X.tj = p->fcs_tj; X.ntile = p->fcs_ntile[r.fcs_q]; X.jt = r.fcs_q == 1 ? 16 : (r.fcs_q == 2 ? 256 : 64); X.tiles = r.fcs_q == 2 ? p->fcs_tiles256_dev : nullptr;
+        X.base = p->fcs_base[r.tiling]; X.pstride = r.nwork;
     }
     for (int t = 1; t <= H + 1; ++t) {
         M.sp = sp[t & 1]; A.sp_prev = sp[(t - 1) & 1];
@@ -584,7 +592,7 @@ extern "C" int gpmpc_rollout_fullcov_describe(const gpmpc_pack* p, int B, int H,
         const gpmpc_worklist& w = p->wl[1][r2.tiling];
         snprintf(out, out_bytes, "form=two_launch tiling=%dx%d workgroups=%ld columns_per_iteration=%d head_workgroups_per_unit=%d "
                  "kernel=gpmpc_pair_kernel_sbf<%d,%d,%s,%d>%s shared_cross_units=%d cross_tile_columns=%d", w.it, w.jt, (long)B * (r2.fcs ? r2.ntri : r2.nwork), r2.cu, r2.rsplit, p->D, p->ds,
-                 grad ? "true" : "false", r2.cu, r2.fcs ? "+gpmpc_pair_kernel_sbfx" : "", r2.fcs, r2.fcs ? (r2.fcs_q ? 16 : 64) : 0);
+                 grad ? "true" : "false", r2.cu, r2.fcs ? "+gpmpc_pair_kernel_sbfx" : "", r2.fcs, r2.fcs ? (r2.fcs_q == 1 ? 16 : (r2.fcs_q == 2 ? 256 : 64)) : 0);
     } else {
         snprintf(out, out_bytes, "form=four_launch tiling=by_gpmpc_moment_match workgroups=0 columns_per_iteration=1 "
                  "head_workgroups_per_unit=1 kernel=gpmpc_pair_kernel_sbf<%d,%d,%s,1>|staged", p->D, p->ds, grad ? "true" : "false");

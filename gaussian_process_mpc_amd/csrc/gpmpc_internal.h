@@ -72,8 +72,9 @@ struct gpmpc_pack {
     // cross unit pr at fcs_base[k] + pr * fcs_ntile
     double* fcs_rows; int fcs_rw, fcs_tj;
     // (two tile widths: 64 columns per wave for launches that fill the chip, 16 for small ones -- four times the waves, each a quarter as long)
-    int fcs_ntile[2];                                  // tiles per trajectory: [0] 64 x 64, [1] 64 x 16
-    int* fcs_ustart_dev[8][2]; int fcs_base[8], fcs_total[8][2];
+    int fcs_ntile[3];                                  // tiles per trajectory: [0] 64 x 64, [1] 64 x 16, [2] 64 x (up to) 256 (listed in fcs_tiles256_dev)
+    int* fcs_ustart_dev[8][3]; int fcs_base[8], fcs_total[8][3];
+    int* fcs_tiles256_dev;                             // [fcs_ntile[2]][3] = {64-row block, first column, columns}: row block ti's columns from 64 ti on, in chunks of 256
     int ncol_host;      // the value last written to ncol_dev
     int* ncol_dev;      // [1] columns that carry weight: N rounded up to 8 (<= Np); written by every pack build (traj_persist.h reads it)
     double* X;      // dev [Np][D], rows >= N zero
@@ -160,7 +161,8 @@ struct PairSbfxArgs {
     double* part; double* part0;           // partial sums, slots base + pair * ntile + tile of a trajectory's pstride slots
     const int* pair_ab;
     int Np, N, B, nunits, unit0, pps, nm;
-    int tj, ntile, jt;                     // 64-row blocks per side, tiles per trajectory (T (T + 1) / 2 * 64 / jt), columns per tile (64 | 16)
+    int tj, ntile, jt;                     // 64-row blocks per side, tiles per trajectory (T (T + 1) / 2 * 64 / jt), columns per tile (64 | 16; 256: from `tiles`)
+    const int* tiles;                      // jt = 256: [ntile][3] = {64-row block, first column, columns}; else null
     int base, pstride;
 };
 template <int D> int gpmpc_launch_pair_sbfx_D(bool grad, int ns2, const PairSbfxArgs& a, hipStream_t s);

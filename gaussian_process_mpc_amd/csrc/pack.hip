@@ -135,6 +135,22 @@ static int fcs_refresh(gpmpc_pack* p, hipStream_t s) {
         p->fcs_rw = (p->D + 1 + p->ds + 1) & ~1;
         p->fcs_tj = p->Np / 64;
         p->fcs_ntile[0] = p->fcs_tj * (p->fcs_tj + 1) / 2; p->fcs_ntile[1] = 4 * p->fcs_ntile[0];   // 64 x 64 | 64 x 16 tiles of the upper triangle (pair_kernel_sbfx.h)
+        {   // ... and row block ti's columns from its diagonal block on in chunks of 256 (launches that fill the chip: a third of a 64-column
+            // wave's time is prologue and row sums)
+            const int T = p->fcs_tj;
+            int n2 = 0;
+            for (int ti = 0; ti < T; ++ti) n2 += (p->Np - 64 * ti + 255) / 256;
+            int* h = (int*)malloc(sizeof(int) * 3 * (size_t)n2);
+            if (!h) return GPMPC_E_ALLOC;
+            int k = 0;
+            for (int ti = 0; ti < T; ++ti)
+                for (int j0 = 64 * ti; j0 < p->Np; j0 += 256) { h[3 * k] = ti; h[3 * k + 1] = j0; h[3 * k + 2] = p->Np - j0 < 256 ? p->Np - j0 : 256; ++k; }
+            p->fcs_ntile[2] = n2;
+            hipError_t e = hipMalloc(&p->fcs_tiles256_dev, sizeof(int) * 3 * (size_t)n2);
+            if (e == hipSuccess) e = hipMemcpy(p->fcs_tiles256_dev, h, sizeof(int) * 3 * (size_t)n2, hipMemcpyHostToDevice);
+            free(h);
+            if (e != hipSuccess) return GPMPC_E_ALLOC;
+        }
         if (hipMalloc(&p->fcs_rows, sizeof(double) * (size_t)p->Np * p->fcs_rw) != hipSuccess) { p->fcs_rows = nullptr; return GPMPC_E_ALLOC; }
         for (int k : {0, 2, 4}) {
             const gpmpc_worklist& w = p->wl[1][k];
@@ -144,7 +160,7 @@ static int fcs_refresh(gpmpc_pack* p, hipStream_t s) {
             for (int u = 0; u <= p->ds; ++u) ust[u] = w.ustart_host[u];
             p->fcs_base[k] = ntri;
             const size_t nb = sizeof(int) * (p->ds + p->npairs + 1);
-            for (int q = 0; q < 2; ++q) {
+            for (int q = 0; q < 3; ++q) {
                 for (int pr = 1; pr <= p->npairs; ++pr) ust[p->ds + pr] = ntri + pr * p->fcs_ntile[q];
                 p->fcs_total[k][q] = ntri + p->npairs * p->fcs_ntile[q];
                 if (hipMalloc(&p->fcs_ustart_dev[k][q], nb) != hipSuccess) { p->fcs_ustart_dev[k][q] = nullptr; return GPMPC_E_ALLOC; }
@@ -468,7 +484,8 @@ extern "C" int gpmpc_pack_destroy(gpmpc_pack* p) {
     gpmpc_lock_destroy(p->lock);
     if (p->pair_ab_dev) (void)hipFree(p->pair_ab_dev);
     if (p->fcs_rows) (void)hipFree(p->fcs_rows);
-    for (int k = 0; k < 8; ++k) for (int q = 0; q < 2; ++q) if (p->fcs_ustart_dev[k][q]) (void)hipFree(p->fcs_ustart_dev[k][q]);
+    for (int k = 0; k < 8; ++k) for (int q = 0; q < 3; ++q) if (p->fcs_ustart_dev[k][q]) (void)hipFree(p->fcs_ustart_dev[k][q]);
+    if (p->fcs_tiles256_dev) (void)hipFree(p->fcs_tiles256_dev);
     for (int mode = 0; mode < 2; ++mode)
         for (int k = 0; k < 8; ++k) {
             if (p->wl[mode][k].work_dev) (void)hipFree(p->wl[mode][k].work_dev);

