@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--steps", type=int, default=25)
     ap.add_argument("--horizon", type=int, default=10)
     ap.add_argument("--gamma", type=float, default=1e-5)
+    ap.add_argument("--starts", type=int, default=1, help="K > 1: lock-step multi-start solve, one batched rollout per tick (mpc.n_starts)")
     args = ap.parse_args()
 
     rng = np.random.default_rng(0)
@@ -42,6 +43,7 @@ def main():
     mpc.dynamics.append_train_data(S, A, NS)
     mpc.set_lb([-2.0]); mpc.set_ub([2.0])
     mpc.set_xref(np.zeros(2))
+    mpc.n_starts = args.starts
 
     sim = Simulator(mpc, plant, num_iters=args.steps, incremental=True)
     t0 = time.perf_counter()
